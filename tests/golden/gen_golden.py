@@ -1,0 +1,240 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the COMPILED REFERENCE HEADERS (oracle/_ref).
+
+Run in the build container (where /root/reference exists):
+
+    make -C oracle && python tests/golden/gen_golden.py
+
+Every expected output below is produced by the reference's own code
+(labs/lab3/.../sparse-matrix.h and project/src/PhotoMontage/sparse-matrix.h, compiled
+unmodified by oracle/Makefile); inputs come from coursecomputationalphotography_amd.synth.
+The fixtures are data only (inputs + expected outputs); they pin both the C oracle and the
+HIP kernels on the GPU box, where the reference does not exist.
+
+The Poisson-assembly fixture (assembly_*.npz) is the one exception: the reference assembly
+needs Eigen/OpenCV, which are absent, so its expected outputs come from a literal scipy
+transcription of the triplet loop (PhotoMontage.cpp:551-592) written in this file.
+"""
+import os
+import sys
+
+import numpy as np
+import scipy.sparse as sp
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), "..", ".."))
+sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402
+from coursecomputationalphotography_amd import synth  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+KS = (1, 2, 10, 50)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"wrote {name}: {os.path.getsize(path)} bytes")
+
+
+def colour_perm(colour):
+    return np.argsort(colour, kind="stable").astype(np.int32)
+
+
+def ref_multicolour(R, O, v, c, r, colour, b, k):
+    """Reference gaussSeidel on P A P^T (colour-major rows) mapped back to natural order."""
+    perm = colour_perm(colour)
+    pv, pc, pr = O.permute_csr(v, c, r, perm)
+    xp = R.gs_csr(pv, pc, pr, b[perm], 0.0, k)
+    x = np.empty_like(xp)
+    x[perm] = xp
+    return x
+
+
+def gen_known_answer(R):
+    # labs/lab3/src/OpenCVHW1/main6.cc:238-249
+    A = np.array([[10, -1, 2, 0], [-1, 11, -1, 3], [2, -1, 10, -1], [0, 3, -1, 8]], dtype=np.float64)
+    b = np.array([6, 25, -11, 15], dtype=np.float64)
+    iters = np.stack([R.lab3_known_answer(0.0, k) for k in range(1, 9)])
+    final, cg = R.lab3_known_answer(1e-6, 1000, with_cg=True)
+    save("known_answer_4x4.npz", A=A, b=b, gs_iterates=iters, gs_final=final, cg_final=cg)
+
+
+def gen_insert_scenario(R):
+    # labs/lab3/src/OpenCVHW1/main6.cc:193-231 (input data of the five insert cases)
+    rows = [0, 0, 0, 2, 2]
+    cols = [0, 3, 4, 0, 2]
+    vals = [1, 1, 0, 8, 1]
+    ops = [(0, 1, 0), (0, 0, 0), (1, 2, 2), (8, 0, 0), (9, 1, 1)]
+    dense_int = R.lab3_int_insert_scenario(rows, cols, vals, ops, 3, 5)
+    dense_dbl = R.vector_insert_scenario(rows, cols, vals, ops, 3, 5)
+    # a longer seeded scenario on the project header
+    g = synth.rng(77)
+    nr, nc = 7, 9
+    dense0 = np.where(g.uniform(size=(nr, nc)) < 0.35, g.integers(1, 9, (nr, nc)), 0).astype(np.float64)
+    dense0[-1, -1] = 5.0                      # pin the shape (n_rows/n_cols are estimated from data)
+    zero_mask = g.uniform(size=(nr, nc)) < 0.15  # explicit zeros -> slack
+    rr, cc = np.nonzero((dense0 != 0) | zero_mask)
+    vv = dense0[rr, cc]
+    ops2 = [(float(g.integers(0, 4) * g.integers(0, 2)), int(g.integers(0, nr)), int(g.integers(0, nc)))
+            for _ in range(40)]
+    # NOTE: on this random scenario the reference insert() diverges from its own dense-mirror
+    # criterion (CheckEqual, main6.cc:19-33) on ~7 of 40 steps (memmove counts in
+    # insertNoneZero/insertZero, sparse-matrix.h:183-237), so only the INPUTS are stored; the
+    # facade test checks the mirror semantics the reference test asserts.  ref_steps_ok records
+    # which steps the compiled reference got right, for DESIGN.md.
+    dense2 = R.vector_insert_scenario(rr, cc, vv, ops2, nr, nc)
+    mirror = np.zeros((nr, nc)); mirror[rr, cc] = vv
+    ok = []
+    for k, (v, r_, c_) in enumerate(ops2):
+        mirror[r_, c_] = v
+        ok.append(bool(np.array_equal(mirror, dense2[k + 1])))
+        mirror = dense2[k + 1].copy()
+    save("insert_scenarios.npz", rows=np.int32(rows), cols=np.int32(cols), vals=np.float64(vals),
+         ops=np.float64(ops), dense_int=dense_int, dense_dbl=dense_dbl,
+         rows2=rr.astype(np.int32), cols2=cc.astype(np.int32), vals2=vv, ops2=np.float64(ops2),
+         ref_steps_ok=np.array(ok), shape2=np.int32([nr, nc]))
+
+
+def gen_poisson(R, O, W, H):
+    v, c, r = synth.poisson_csr(W, H)
+    ov, oc, orr = O.poisson_csr(W, H)
+    assert np.array_equal(v, ov) and np.array_equal(c, oc) and np.array_equal(r, orr)
+    b, xt = synth.poisson_system(W, H, 1234)
+    spmv = R.spmv_csr(v, c, r, xt)
+    assert np.array_equal(spmv, b), "synth.poisson_apply must equal the reference applyToVector"
+    colour = oracle.grid_colour(W, H)
+    arrays = dict(W=np.int32(W), H=np.int32(H), x_true=xt, b=b, spmv_x_true=spmv)
+    for k in KS:
+        arrays[f"x_lex_k{k}"] = R.gs_csr(v, c, r, b, 0.0, k)
+        arrays[f"x_rb_k{k}"] = ref_multicolour(R, O, v, c, r, colour, b, k)
+    # residual vector r = b - A x after 10 red-black iterations (applyToVector + vecsub)
+    arrays["resid_rb_k10"] = b - R.spmv_csr(v, c, r, arrays["x_rb_k10"])
+    # L1 step (manhattonDist(x_k, x_{k-1})) of the red-black run, k = 1, 2, 10
+    prev = np.ones(W * H)
+    l1 = []
+    for k in (1, 2):
+        l1.append(R.manhatton_dist(arrays[f"x_rb_k{k}"], prev))
+        prev = arrays[f"x_rb_k{k}"]
+    x9 = ref_multicolour(R, O, v, c, r, colour, b, 9)
+    l1.append(R.manhatton_dist(arrays["x_rb_k10"], x9))
+    arrays["l1_step_rb_k1_2_10"] = np.float64(l1)
+    # three-channel variant (config 2 shape): seeds 1234/1235/1236, 10 red-black iterations
+    b3 = np.stack([synth.poisson_system(W, H, s)[0] for s in (1234, 1235, 1236)])
+    arrays["b3"] = b3
+    arrays["x3_rb_k10"] = np.stack([ref_multicolour(R, O, v, c, r, colour, b3[i], 10) for i in range(3)])
+    save(f"poisson_{W}x{H}.npz", **arrays)
+
+
+def gen_mask(R, O):
+    mask = synth.disc_mask(61, 47, seed=4321, n_discs=9, rmin=600, rmax=1500, brush=300)
+    v, c, r, colour, ys, xs = synth.masked_laplacian_csr(mask)
+    n = len(ys)
+    xt = synth.x_true(n, 4321)
+    b = R.spmv_csr(v, c, r, xt)
+    assert np.array_equal(b, synth.csr_apply(v, c, r, xt))
+    arrays = dict(mask=mask, values=v, cols=c, row_offset=r, colour=colour, x_true=xt, b=b)
+    for k in KS:
+        arrays[f"x_lex_k{k}"] = R.gs_csr(v, c, r, b, 0.0, k)
+        arrays[f"x_rb_k{k}"] = ref_multicolour(R, O, v, c, r, colour, b, k)
+    save("mask_61x47.npz", **arrays)
+
+
+def gen_slack_ingest(R):
+    """initializeFromEigenRowMajor with per-row slack (non_zeros != NULL, sparse-matrix.h:560-589)
+    and with trailing empty rows in compressed form (:592-619)."""
+    g = synth.rng(99)
+    n = 12
+    dense = np.where(g.uniform(size=(n, n)) < 0.3, g.uniform(-2, 2, (n, n)), 0.0)
+    dense += np.diag(4.0 + g.uniform(size=n))
+    dense[n - 2:, :] = 0.0                      # two trailing all-zero rows
+    vals, cols, rowo, nnz = [], [], [], []
+    for i in range(n):
+        rowo.append(len(vals))
+        (cc,) = np.nonzero(dense[i])
+        vals += list(dense[i, cc]); cols += list(cc)
+        nnz.append(len(cc))
+        if i < n - 2:
+            slack = int(g.integers(0, 3))      # uncompressed Eigen rows carry free slots
+            vals += [0.0] * slack; cols += [0] * slack
+    rowo.append(len(vals))
+    vals, cols, rowo, nnz = np.float64(vals), np.int32(cols), np.int32(rowo), np.int32(nnz)
+    d_slack, r1, c1 = R.dense_eigen(vals, cols, rowo, n, n, nnz)
+    xin = g.uniform(-1, 1, n)
+    spmv_slack = R.spmv_csr(vals, cols, rowo, xin, non_zeros=nnz)
+    b = g.uniform(-5, 5, n)
+    gs_slack = R.gs_csr(vals, cols, rowo, b, 0.0, 7, non_zeros=nnz)
+    # compressed variant of the same matrix
+    cv, ccols, crow = [], [], [0]
+    for i in range(n):
+        (cc,) = np.nonzero(dense[i])
+        cv += list(dense[i, cc]); ccols += list(cc); crow.append(len(cv))
+    cv, ccols, crow = np.float64(cv), np.int32(ccols), np.int32(crow)
+    d_comp, _, _ = R.dense_eigen(cv, ccols, crow, n, n)
+    gs_comp = R.gs_csr(cv, ccols, crow, b, 0.0, 7)
+    assert np.array_equal(d_slack, dense) and np.array_equal(d_comp, dense)
+    save("slack_ingest_12.npz", dense=dense, values=vals, cols=cols, row_offset=rowo, non_zeros=nnz,
+         xin=xin, spmv=spmv_slack, b=b, gs_k7=gs_slack, c_values=cv, c_cols=ccols, c_row_offset=crow,
+         c_gs_k7=gs_comp)
+
+
+def scipy_assembly(W, H, gx, gy, channel, constraint):
+    """Literal transcription of the triplet loop + Eigen products (PhotoMontage.cpp:545-592)."""
+    rows, cols, vals = [], [], []
+    b = np.zeros(2 * W * H + 1)
+    for y in range(H - 1):
+        for x in range(W - 1):
+            col_xy = W * y + x
+            row_xy = 2 * col_xy
+            rows += [row_xy, row_xy]; cols += [col_xy, col_xy + 1]; vals += [-1.0, 1.0]
+            b[row_xy] = gx[y, x, channel]
+            rows += [row_xy + 1, row_xy + 1]; cols += [col_xy, col_xy + W]; vals += [-1.0, 1.0]
+            b[row_xy + 1] = gy[y, x, channel]
+    rows.append(2 * W * H); cols.append(0); vals.append(1.0)
+    b[2 * W * H] = constraint
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(2 * W * H + 1, W * H))
+    ATA = (A.T @ A).tocsr()
+    ATA.sort_indices()
+    ATA.eliminate_zeros()
+    return ATA, A.T @ b
+
+
+def gen_assembly(O):
+    arrays = {}
+    g = synth.rng(2024)
+    for (W, H) in ((5, 4), (7, 7), (3, 6), (16, 12)):
+        # integer-valued gradients in [-255, 255], as GradientAt produces (PhotoMontage.cpp:402-406)
+        gx = g.integers(-255, 256, (H, W, 3)).astype(np.float32)
+        gy = g.integers(-255, 256, (H, W, 3)).astype(np.float32)
+        cons = [int(t) for t in g.integers(0, 256, 3)]
+        v, c, r = synth.poisson_csr(W, H)
+        atb = []
+        for ch in range(3):
+            ATA, ATb = scipy_assembly(W, H, gx, gy, ch, cons[ch])
+            assert np.array_equal(ATA.indptr, r) and np.array_equal(ATA.indices, c) and np.array_equal(ATA.data, v)
+            atb.append(ATb)
+            mine = O.poisson_rhs(gx, gy, ch, cons[ch])
+            assert np.array_equal(mine, ATb), np.abs(mine - ATb).max()
+        key = f"{W}x{H}"
+        arrays[f"gx_{key}"] = gx; arrays[f"gy_{key}"] = gy
+        arrays[f"constraint_{key}"] = np.int32(cons)
+        arrays[f"atb_{key}"] = np.stack(atb)
+        arrays[f"values_{key}"] = v; arrays[f"cols_{key}"] = c; arrays[f"row_offset_{key}"] = r
+    save("assembly.npz", **arrays)
+
+
+def main():
+    oracle.build()
+    R = oracle.Ref()
+    O = oracle.Oracle()
+    gen_known_answer(R)
+    gen_insert_scenario(R)
+    for (W, H) in ((8, 8), (17, 13), (64, 64)):
+        gen_poisson(R, O, W, H)
+    gen_mask(R, O)
+    gen_slack_ingest(R)
+    gen_assembly(O)
+
+
+if __name__ == "__main__":
+    main()
