@@ -1,0 +1,320 @@
+"""ctypes binding of libccp_gs.so (the C ABI declared in include/ccp_gs.h).
+
+This is plumbing for tests, bench.py and the multi-GPU driver: the product is the shared
+library.  There is no CPU fallback — if the library is missing, or no HIP device is usable,
+the calls raise (``CcpError``) instead of computing anything on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libccp_gs.so")
+
+CCP_OK = 0
+ORDER_LEXICOGRAPHIC = 0
+ORDER_MULTICOLOUR = 1
+
+# every symbol include/ccp_gs.h declares (tests check the library exports all of them)
+ABI_SYMBOLS = (
+    "ccp_status_string", "ccp_abi_version", "ccp_device_count",
+    "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_set_colouring",
+    "ccp_csr_gauss_seidel", "ccp_csr_apply_to_vector", "ccp_csr_residual_norm2",
+    "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
+    "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
+    "ccp_grid_get_b_host", "ccp_grid_fill_x", "ccp_grid_b_from_x", "ccp_grid_randomize_x",
+    "ccp_grid_sweep", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel",
+    "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_store_u8",
+    "ccp_grid_set_x_u8", "ccp_grid_last_timing",
+)
+
+
+class CcpError(RuntimeError):
+    def __init__(self, status: int, what: str):
+        self.status = status
+        super().__init__(f"{what}: status {status} ({status_string(status)})")
+
+
+class Report(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("converged", C.c_int32),
+                ("last_l1_step", C.c_double), ("seconds", C.c_double)]
+
+
+class GridDesc(C.Structure):
+    _fields_ = [("width", C.c_int32), ("height", C.c_int32), ("channels", C.c_int32),
+                ("row_begin", C.c_int32), ("row_count", C.c_int32), ("ghost", C.c_int32),
+                ("device", C.c_int32), ("flags", C.c_int32)]
+
+
+class GridLayout(C.Structure):
+    _fields_ = [("x_dev", C.c_void_p), ("b_dev", C.c_void_p), ("pitch", C.c_int64),
+                ("local_rows", C.c_int32), ("ghost_top", C.c_int32), ("ghost_bottom", C.c_int32),
+                ("channels", C.c_int32)]
+
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """dlopen libccp_gs.so; raises FileNotFoundError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(
+            f"{LIB_PATH} is missing: build it with `make -C coursecomputationalphotography_amd/csrc` "
+            "(or __graft_entry__.build()).  There is no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.ccp_status_string.restype = C.c_char_p
+    L.ccp_status_string.argtypes = [C.c_int]
+    vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+    L.ccp_csr_create.argtypes = [C.c_int, C.POINTER(vp)]
+    L.ccp_csr_destroy.argtypes = [vp]
+    L.ccp_csr_upload.argtypes = [vp, i32, i32, i64, vp, vp, vp, vp]
+    L.ccp_csr_set_colouring.argtypes = [vp, vp, i32]
+    L.ccp_csr_gauss_seidel.argtypes = [vp, vp, vp, vp, dbl, i32, i32, i32, C.POINTER(Report)]
+    L.ccp_csr_apply_to_vector.argtypes = [vp, vp, vp]
+    L.ccp_csr_residual_norm2.argtypes = [vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl)]
+    L.ccp_grid_create.argtypes = [C.POINTER(GridDesc), C.POINTER(vp)]
+    L.ccp_grid_destroy.argtypes = [vp]
+    L.ccp_grid_get_layout.argtypes = [vp, C.POINTER(GridLayout)]
+    L.ccp_grid_set_stream.argtypes = [vp, vp]
+    L.ccp_grid_synchronize.argtypes = [vp]
+    for name in ("ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host", "ccp_grid_get_b_host"):
+        getattr(L, name).argtypes = [vp, i32, vp, i32, i32]
+    L.ccp_grid_fill_x.argtypes = [vp, dbl]
+    L.ccp_grid_b_from_x.argtypes = [vp]
+    L.ccp_grid_randomize_x.argtypes = [vp, C.c_uint64, dbl, dbl]
+    L.ccp_grid_sweep.argtypes = [vp, i32]
+    L.ccp_grid_sweep_l1.argtypes = [vp, vp]
+    L.ccp_grid_halo_refreshed.argtypes = [vp]
+    L.ccp_grid_gauss_seidel.argtypes = [vp, dbl, i32, i32, C.POINTER(Report)]
+    L.ccp_grid_residual_norm2.argtypes = [vp, vp]
+    L.ccp_grid_abs_sum.argtypes = [vp, vp]
+    L.ccp_grid_assemble_rhs.argtypes = [vp, vp, vp, i64, vp]
+    L.ccp_grid_store_u8.argtypes = [vp, vp, i64]
+    L.ccp_grid_set_x_u8.argtypes = [vp, vp, i64]
+    L.ccp_grid_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
+    _lib = L
+    return L
+
+
+def status_string(status: int) -> str:
+    try:
+        return load().ccp_status_string(status).decode()
+    except Exception:
+        return "?"
+
+
+def check(status: int, what: str) -> None:
+    if status != CCP_OK:
+        raise CcpError(status, what)
+
+
+def device_count() -> int:
+    return int(load().ccp_device_count())
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def _i32(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+class CsrMatrix:
+    """Device-resident slack-CSR matrix (ccp_csr_*)."""
+
+    def __init__(self, device: int = 0):
+        self.L = load()
+        self.h = C.c_void_p()
+        check(self.L.ccp_csr_create(device, C.byref(self.h)), "ccp_csr_create")
+        self.n_rows = self.n_cols = 0
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.ccp_csr_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, n_rows, n_cols, values, col_offset, row_begin, row_num_nze):
+        values, col_offset = _f64(values), _i32(col_offset)
+        row_begin, row_num_nze = _i32(row_begin), _i32(row_num_nze)
+        check(self.L.ccp_csr_upload(self.h, n_rows, n_cols, len(values), _ptr(values), _ptr(col_offset),
+                                    _ptr(row_begin), _ptr(row_num_nze)), "ccp_csr_upload")
+        self.n_rows, self.n_cols = n_rows, n_cols
+        return self
+
+    def upload_compressed(self, values, col_offset, row_offset, n_cols=None):
+        """Compressed CSR (n+1 offsets) -> the slack arrays with zero slack."""
+        row_offset = _i32(row_offset)
+        n = len(row_offset) - 1
+        return self.upload(n, n if n_cols is None else n_cols, values, col_offset, row_offset[:-1],
+                           np.diff(row_offset))
+
+    def set_colouring(self, colour, n_colours=None):
+        if colour is None:
+            check(self.L.ccp_csr_set_colouring(self.h, None, 0), "ccp_csr_set_colouring")
+            return self
+        colour = _i32(colour)
+        nc = int(colour.max()) + 1 if n_colours is None else n_colours
+        check(self.L.ccp_csr_set_colouring(self.h, _ptr(colour), nc), "ccp_csr_set_colouring")
+        return self
+
+    def gauss_seidel(self, b, epsilon=1e-6, max_iteration=1000, x0=None, check_every=1,
+                     ordering=ORDER_MULTICOLOUR):
+        b = _f64(b)
+        x0a = None if x0 is None else _f64(x0)
+        x = np.empty(self.n_cols, dtype=np.float64)
+        rep = Report()
+        check(self.L.ccp_csr_gauss_seidel(self.h, _ptr(b), _ptr(x0a), _ptr(x), epsilon, max_iteration,
+                                          check_every, ordering, C.byref(rep)), "ccp_csr_gauss_seidel")
+        return x, rep
+
+    def apply_to_vector(self, v):
+        v = _f64(v)
+        out = np.empty(self.n_rows, dtype=np.float64)
+        check(self.L.ccp_csr_apply_to_vector(self.h, _ptr(v), _ptr(out)), "ccp_csr_apply_to_vector")
+        return out
+
+    def residual_norm2(self, b, x):
+        b, x = _f64(b), _f64(x)
+        rr, bb = C.c_double(), C.c_double()
+        check(self.L.ccp_csr_residual_norm2(self.h, _ptr(b), _ptr(x), C.byref(rr), C.byref(bb)),
+              "ccp_csr_residual_norm2")
+        return rr.value, bb.value
+
+
+class Grid:
+    """Structured Poisson grid block (ccp_grid_*)."""
+
+    def __init__(self, width, height, channels=1, row_begin=0, row_count=None, ghost=0, device=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        row_count = height if row_count is None else row_count
+        self.desc = GridDesc(width, height, channels, row_begin, row_count, ghost, device, 0)
+        check(self.L.ccp_grid_create(C.byref(self.desc), C.byref(self.h)), "ccp_grid_create")
+        self.layout = GridLayout()
+        check(self.L.ccp_grid_get_layout(self.h, C.byref(self.layout)), "ccp_grid_get_layout")
+        self.W, self.H, self.C = width, height, channels
+        self.row_begin, self.row_count = row_begin, row_count
+        self.first_local_row = row_begin - self.layout.ghost_top       # image row of local row 0
+        self.local_rows = self.layout.local_rows
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.ccp_grid_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_handle: int):
+        check(self.L.ccp_grid_set_stream(self.h, C.c_void_p(stream_handle)), "ccp_grid_set_stream")
+
+    def synchronize(self):
+        check(self.L.ccp_grid_synchronize(self.h), "ccp_grid_synchronize")
+
+    def _rows(self, first_row, n_rows):
+        if first_row is None:
+            first_row = self.first_local_row
+        if n_rows is None:
+            n_rows = self.local_rows - (first_row - self.first_local_row)
+        return first_row, n_rows
+
+    def set_b(self, rows, channel=0, first_row=None):
+        rows = _f64(rows).reshape(-1, self.W)
+        first_row, _ = self._rows(first_row, None)
+        check(self.L.ccp_grid_set_b_host(self.h, channel, _ptr(rows), first_row, rows.shape[0]), "ccp_grid_set_b_host")
+
+    def set_x(self, rows, channel=0, first_row=None):
+        rows = _f64(rows).reshape(-1, self.W)
+        first_row, _ = self._rows(first_row, None)
+        check(self.L.ccp_grid_set_x_host(self.h, channel, _ptr(rows), first_row, rows.shape[0]), "ccp_grid_set_x_host")
+
+    def get_x(self, channel=0, first_row=None, n_rows=None) -> np.ndarray:
+        first_row, n_rows = self._rows(first_row, n_rows)
+        out = np.empty((n_rows, self.W), dtype=np.float64)
+        check(self.L.ccp_grid_get_x_host(self.h, channel, _ptr(out), first_row, n_rows), "ccp_grid_get_x_host")
+        return out
+
+    def get_b(self, channel=0, first_row=None, n_rows=None) -> np.ndarray:
+        first_row, n_rows = self._rows(first_row, n_rows)
+        out = np.empty((n_rows, self.W), dtype=np.float64)
+        check(self.L.ccp_grid_get_b_host(self.h, channel, _ptr(out), first_row, n_rows), "ccp_grid_get_b_host")
+        return out
+
+    def get_x_owned(self, channel=0) -> np.ndarray:
+        return self.get_x(channel, self.row_begin, self.row_count)
+
+    def fill_x(self, value=1.0):
+        check(self.L.ccp_grid_fill_x(self.h, value), "ccp_grid_fill_x")
+
+    def randomize_x(self, seed, lo=0.0, hi=255.0):
+        check(self.L.ccp_grid_randomize_x(self.h, seed, lo, hi), "ccp_grid_randomize_x")
+
+    def b_from_x(self):
+        check(self.L.ccp_grid_b_from_x(self.h), "ccp_grid_b_from_x")
+
+    def sweep(self, iterations):
+        check(self.L.ccp_grid_sweep(self.h, iterations), "ccp_grid_sweep")
+
+    def sweep_l1(self) -> np.ndarray:
+        out = np.empty(self.C, dtype=np.float64)
+        check(self.L.ccp_grid_sweep_l1(self.h, _ptr(out)), "ccp_grid_sweep_l1")
+        return out
+
+    def halo_refreshed(self):
+        check(self.L.ccp_grid_halo_refreshed(self.h), "ccp_grid_halo_refreshed")
+
+    def gauss_seidel(self, epsilon=1e-6, max_iteration=1000, check_every=1):
+        reps = (Report * self.C)()
+        check(self.L.ccp_grid_gauss_seidel(self.h, epsilon, max_iteration, check_every, reps), "ccp_grid_gauss_seidel")
+        return list(reps)
+
+    def residual_norm2(self):
+        out = np.empty(2 * self.C, dtype=np.float64)
+        check(self.L.ccp_grid_residual_norm2(self.h, _ptr(out)), "ccp_grid_residual_norm2")
+        return out[:self.C].copy(), out[self.C:].copy()
+
+    def abs_sum(self) -> np.ndarray:
+        out = np.empty(self.C, dtype=np.float64)
+        check(self.L.ccp_grid_abs_sum(self.h, _ptr(out)), "ccp_grid_abs_sum")
+        return out
+
+    def assemble_rhs(self, gx: np.ndarray, gy: np.ndarray, constraint):
+        gx = np.ascontiguousarray(gx, dtype=np.float32)
+        gy = np.ascontiguousarray(gy, dtype=np.float32)
+        cons = _i32(constraint)
+        check(self.L.ccp_grid_assemble_rhs(self.h, _ptr(gx), _ptr(gy), gx.strides[0], _ptr(cons)), "ccp_grid_assemble_rhs")
+
+    def store_u8(self) -> np.ndarray:
+        out = np.zeros((self.H, self.W, self.C), dtype=np.uint8)
+        check(self.L.ccp_grid_store_u8(self.h, _ptr(out), out.strides[0]), "ccp_grid_store_u8")
+        return out
+
+    def set_x_u8(self, image: np.ndarray):
+        image = np.ascontiguousarray(image, dtype=np.uint8)
+        check(self.L.ccp_grid_set_x_u8(self.h, _ptr(image), image.strides[0]), "ccp_grid_set_x_u8")
+
+    def last_timing(self):
+        ms, n = C.c_float(), C.c_int32()
+        check(self.L.ccp_grid_last_timing(self.h, C.byref(ms), C.byref(n)), "ccp_grid_last_timing")
+        return ms.value, n.value

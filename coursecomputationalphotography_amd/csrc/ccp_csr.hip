@@ -1,0 +1,485 @@
+// ccp_csr.hip — C ABI of the general slack-CSR path (Gauss-Seidel, SpMV, residual).
+// See include/ccp_gs.h.  Host side: schedule construction (colouring / level scheduling) and the
+// sliced-ELL re-tiling; device side: ccp_csr_kernels.hpp.
+#include "ccp_csr_kernels.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+using namespace ccp;
+
+namespace {
+
+// Sliced-ELL image of the matrix for one row schedule, resident on the device.
+struct Schedule {
+    bool built = false;
+    int n_groups = 0;                    // colours or levels, swept in order
+    std::vector<int> group_slice_ptr;    // [n_groups+1] slices of each group
+    std::vector<long> group_block_off;   // [n_groups+1] partial-sum block offsets
+    int n_slices = 0;
+    DevBuf<long> slice_off;
+    DevBuf<int> slice_width, slice_row0, slice_rows, cols, perm;
+    DevBuf<double> vals;
+    void reset()
+    {
+        built = false;
+        n_groups = n_slices = 0;
+        group_slice_ptr.clear();
+        group_block_off.clear();
+        slice_off.release(); slice_width.release(); slice_row0.release(); slice_rows.release();
+        cols.release(); perm.release(); vals.release();
+    }
+    SellView view() const
+    {
+        return SellView{slice_off.p, slice_width.p, slice_row0.p, slice_rows.p, cols.p, vals.p};
+    }
+};
+
+}  // namespace
+
+struct ccp_csr {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool uploaded = false;
+    int n_rows = 0, n_cols = 0;
+    // host copy of the live entries in compressed form (slack removed), storage order kept
+    std::vector<long> row_ptr;
+    std::vector<int> col;
+    std::vector<double> val;
+    std::vector<int> user_colour;
+    int user_n_colours = 0;
+    Schedule natural;        // identity order, one group: SpMV / residual
+    Schedule multicolour;    // colour-major, columns sorted by permuted index (reference on P A P^T)
+    Schedule lexicographic;  // level-major, original storage order kept inside a row
+    DevBuf<double> x, b, tmp, partial;
+    DevBuf<CsrSolveState> state;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int bind(ccp_csr *m)
+{
+    if (!m) return CCP_ERR_BAD_ARG;
+    if (hipSetDevice(m->device) != hipSuccess) return CCP_ERR_NO_DEVICE;
+    return CCP_OK;
+}
+
+// lower[i] = rows j < i coupled to i (a_ij != 0 or a_ji != 0, structurally).
+void build_lower(const ccp_csr *m, std::vector<long> &lptr, std::vector<int> &lidx)
+{
+    const int n = m->n_rows;
+    std::vector<long> cnt((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i)
+        for (long k = m->row_ptr[i]; k < m->row_ptr[i + 1]; ++k) {
+            const int c = m->col[k];
+            if (c == i || c < 0 || c >= n) continue;
+            cnt[(size_t)std::max(i, c) + 1]++;
+        }
+    lptr.assign((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) lptr[i + 1] = lptr[i] + cnt[i + 1];
+    lidx.assign((size_t)lptr[n], 0);
+    std::vector<long> fill(lptr.begin(), lptr.end() - 1);
+    for (int i = 0; i < n; ++i)
+        for (long k = m->row_ptr[i]; k < m->row_ptr[i + 1]; ++k) {
+            const int c = m->col[k];
+            if (c == i || c < 0 || c >= n) continue;
+            const int hi = std::max(i, c), lo = std::min(i, c);
+            lidx[fill[hi]++] = lo;
+        }
+}
+
+// Greedy colouring in row order (first colour not used by an already coloured neighbour).
+int greedy_colouring(const std::vector<long> &lptr, const std::vector<int> &lidx, int n, std::vector<int> &colour)
+{
+    colour.assign(n, 0);
+    int n_colours = n ? 1 : 0;
+    std::vector<int> mark;
+    for (int i = 0; i < n; ++i) {
+        const long deg = lptr[i + 1] - lptr[i];
+        mark.assign((size_t)deg + 2, 0);
+        for (long k = lptr[i]; k < lptr[i + 1]; ++k) {
+            const int cj = colour[lidx[k]];
+            if (cj <= deg) mark[cj] = 1;
+        }
+        int c = 0;
+        while (mark[c]) ++c;
+        colour[i] = c;
+        n_colours = std::max(n_colours, c + 1);
+    }
+    return n_colours;
+}
+
+// level[i] = 1 + max level of coupled rows j < i: rows of one level are mutually uncoupled and
+// sweeping the levels in order reproduces the reference's index-order sweep exactly.
+int level_schedule(const std::vector<long> &lptr, const std::vector<int> &lidx, int n, std::vector<int> &level)
+{
+    level.assign(n, 0);
+    int n_levels = n ? 1 : 0;
+    for (int i = 0; i < n; ++i) {
+        int lv = 0;
+        for (long k = lptr[i]; k < lptr[i + 1]; ++k) lv = std::max(lv, level[lidx[k]] + 1);
+        level[i] = lv;
+        n_levels = std::max(n_levels, lv + 1);
+    }
+    return n_levels;
+}
+
+template <typename T>
+int upload_vec(DevBuf<T> &d, const std::vector<T> &h, hipStream_t s)
+{
+    CCP_TRY(d.alloc(h.size()));
+    if (!h.empty()) CCP_HIP(hipMemcpyAsync(d.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s));
+    return CCP_OK;
+}
+
+// Build the sliced-ELL image for rows ordered by `group` (stable: ascending row index inside a
+// group).  sort_by_permuted: order a row's entries by their PERMUTED column (what the reference
+// would see on P A P^T); otherwise keep the original storage order.
+int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int n_groups, bool sort_by_permuted)
+{
+    const int n = m->n_rows;
+    std::vector<long> gcount((size_t)n_groups + 1, 0);
+    for (int i = 0; i < n; ++i) gcount[(size_t)group[i] + 1]++;
+    for (int g = 0; g < n_groups; ++g) gcount[g + 1] += gcount[g];
+    std::vector<int> perm(n), inv(n);               // perm[new] = old
+    {
+        std::vector<long> fill(gcount.begin(), gcount.end() - 1);
+        for (int i = 0; i < n; ++i) perm[fill[group[i]]++] = i;
+        for (int r = 0; r < n; ++r) inv[perm[r]] = r;
+    }
+    // columns of a non-square matrix beyond n_rows keep their index (only square systems are
+    // solved; SpMV uses the identity schedule where inv is the identity anyway)
+    auto map_col = [&](int c) { return (c >= 0 && c < n) ? inv[c] : c; };
+
+    std::vector<int> srow0, srows, swidth;
+    std::vector<long> soff;
+    sc.group_slice_ptr.assign((size_t)n_groups + 1, 0);
+    sc.group_block_off.assign((size_t)n_groups + 1, 0);
+    long total = 0;
+    for (int g = 0; g < n_groups; ++g) {
+        for (long r = gcount[g]; r < gcount[g + 1]; r += kWave) {
+            const int rows = (int)std::min<long>(kWave, gcount[g + 1] - r);
+            int width = 0;
+            for (int t = 0; t < rows; ++t) {
+                const int old = perm[r + t];
+                width = std::max(width, (int)(m->row_ptr[old + 1] - m->row_ptr[old]));
+            }
+            srow0.push_back((int)r);
+            srows.push_back(rows);
+            swidth.push_back(width);
+            soff.push_back(total);
+            total += (long)width * kWave;
+        }
+        sc.group_slice_ptr[g + 1] = (int)srow0.size();
+        const int slices = sc.group_slice_ptr[g + 1] - sc.group_slice_ptr[g];
+        sc.group_block_off[g + 1] = sc.group_block_off[g] + (slices + kBlock / kWave - 1) / (kBlock / kWave);
+    }
+    sc.n_slices = (int)srow0.size();
+    sc.n_groups = n_groups;
+    std::vector<int> cols((size_t)std::max<long>(total, 1), -1);
+    std::vector<double> vals((size_t)std::max<long>(total, 1), 0.0);
+    std::vector<std::pair<int, double>> tmp;
+    for (int s = 0; s < sc.n_slices; ++s) {
+        for (int t = 0; t < srows[s]; ++t) {
+            const int old = perm[srow0[s] + t];
+            tmp.clear();
+            for (long k = m->row_ptr[old]; k < m->row_ptr[old + 1]; ++k)
+                tmp.emplace_back(map_col(m->col[k]), m->val[k]);
+            if (sort_by_permuted)
+                std::stable_sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+            for (size_t k = 0; k < tmp.size(); ++k) {
+                cols[(size_t)soff[s] + k * kWave + t] = tmp[k].first;
+                vals[(size_t)soff[s] + k * kWave + t] = tmp[k].second;
+            }
+        }
+    }
+    CCP_TRY(upload_vec(sc.slice_off, soff, m->stream));
+    CCP_TRY(upload_vec(sc.slice_width, swidth, m->stream));
+    CCP_TRY(upload_vec(sc.slice_row0, srow0, m->stream));
+    CCP_TRY(upload_vec(sc.slice_rows, srows, m->stream));
+    CCP_TRY(upload_vec(sc.cols, cols, m->stream));
+    CCP_TRY(upload_vec(sc.vals, vals, m->stream));
+    CCP_TRY(upload_vec(sc.perm, perm, m->stream));
+    CCP_HIP(hipStreamSynchronize(m->stream));      // host vectors die at scope exit
+    sc.built = true;
+    return CCP_OK;
+}
+
+int ensure_natural(ccp_csr *m)
+{
+    if (m->natural.built) return CCP_OK;
+    std::vector<int> group((size_t)m->n_rows, 0);
+    return build_schedule(m, m->natural, group, m->n_rows ? 1 : 0, false);
+}
+
+int ensure_multicolour(ccp_csr *m)
+{
+    if (m->multicolour.built) return CCP_OK;
+    std::vector<long> lptr;
+    std::vector<int> lidx;
+    build_lower(m, lptr, lidx);
+    std::vector<int> colour;
+    int nc;
+    if (!m->user_colour.empty()) {
+        colour = m->user_colour;
+        nc = m->user_n_colours;
+        for (int i = 0; i < m->n_rows; ++i)
+            for (long k = lptr[i]; k < lptr[i + 1]; ++k)
+                if (colour[lidx[k]] == colour[i]) return CCP_ERR_UNSUPPORTED;   // not a proper colouring
+    } else {
+        nc = greedy_colouring(lptr, lidx, m->n_rows, colour);
+    }
+    return build_schedule(m, m->multicolour, colour, nc, true);
+}
+
+int ensure_lexicographic(ccp_csr *m)
+{
+    if (m->lexicographic.built) return CCP_OK;
+    std::vector<long> lptr;
+    std::vector<int> lidx;
+    build_lower(m, lptr, lidx);
+    std::vector<int> level;
+    const int nl = level_schedule(lptr, lidx, m->n_rows, level);
+    return build_schedule(m, m->lexicographic, level, nl, false);
+}
+
+// partial-sum scratch large enough for `blocks` block results of two doubles each
+int ensure_partial(ccp_csr *m, long blocks)
+{
+    const size_t need = 2 * (size_t)std::max<long>(blocks, 1) + 2;
+    if (m->partial.n >= need) return CCP_OK;
+    return m->partial.alloc(need);
+}
+
+unsigned blocks_for(long n) { return (unsigned)std::max<long>(1, std::min<long>(4096, (n + kBlock - 1) / kBlock)); }
+
+}  // namespace
+
+extern "C" {
+
+int ccp_csr_create(int device, ccp_csr **out)
+{
+    if (!out) return CCP_ERR_BAD_ARG;
+    *out = nullptr;
+    CCP_TRY(select_device(device));
+    ccp_csr *m = new (std::nothrow) ccp_csr();
+    if (!m) return CCP_ERR_ALLOC;
+    m->device = device;
+    if (hipEventCreate(&m->ev0) != hipSuccess || hipEventCreate(&m->ev1) != hipSuccess) {
+        ccp_csr_destroy(m);
+        return CCP_ERR_HIP;
+    }
+    *out = m;
+    return CCP_OK;
+}
+
+int ccp_csr_destroy(ccp_csr *m)
+{
+    if (!m) return CCP_OK;
+    (void)hipSetDevice(m->device);
+    if (m->ev0) (void)hipEventDestroy(m->ev0);
+    if (m->ev1) (void)hipEventDestroy(m->ev1);
+    delete m;
+    return CCP_OK;
+}
+
+int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values, const double *values,
+                   const int32_t *col_offset, const int32_t *row_begin, const int32_t *row_num_nze)
+{
+    CCP_TRY(bind(m));
+    if (n_rows < 0 || n_cols < 0 || n_values < 0) return CCP_ERR_BAD_ARG;
+    if (n_rows > 0 && (!row_begin || !row_num_nze)) return CCP_ERR_BAD_ARG;
+    if (n_values > 0 && (!values || !col_offset)) return CCP_ERR_BAD_ARG;
+    try {
+        m->row_ptr.assign((size_t)n_rows + 1, 0);
+        for (int i = 0; i < n_rows; ++i) {
+            const long nz = row_num_nze[i];
+            if (nz < 0 || (nz > 0 && (row_begin[i] < 0 || (long)row_begin[i] + nz > n_values))) return CCP_ERR_BAD_ARG;
+            m->row_ptr[i + 1] = m->row_ptr[i] + nz;
+        }
+        const long nnz = m->row_ptr[n_rows];
+        m->col.resize((size_t)nnz);
+        m->val.resize((size_t)nnz);
+        for (int i = 0; i < n_rows; ++i) {
+            const long nz = row_num_nze[i];
+            if (!nz) continue;
+            std::memcpy(&m->col[m->row_ptr[i]], col_offset + row_begin[i], sizeof(int32_t) * (size_t)nz);
+            std::memcpy(&m->val[m->row_ptr[i]], values + row_begin[i], sizeof(double) * (size_t)nz);
+            for (long k = m->row_ptr[i]; k < m->row_ptr[i + 1]; ++k)
+                if (m->col[k] < 0 || m->col[k] >= n_cols) return CCP_ERR_BAD_ARG;
+        }
+    } catch (const std::bad_alloc &) {
+        return CCP_ERR_ALLOC;
+    }
+    m->n_rows = n_rows;
+    m->n_cols = n_cols;
+    m->natural.reset();
+    m->multicolour.reset();
+    m->lexicographic.reset();
+    m->user_colour.clear();
+    m->user_n_colours = 0;
+    const size_t vec = (size_t)std::max(std::max(n_rows, n_cols), 2);
+    CCP_TRY(m->x.alloc(vec));
+    CCP_TRY(m->b.alloc(vec));
+    CCP_TRY(m->tmp.alloc(vec));
+    CCP_TRY(m->state.alloc(1));
+    m->uploaded = true;
+    return CCP_OK;
+}
+
+int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours)
+{
+    if (!m) return CCP_ERR_BAD_ARG;
+    if (!m->uploaded) return CCP_ERR_STATE;
+    m->multicolour.reset();
+    m->user_colour.clear();
+    m->user_n_colours = 0;
+    if (!colour) return CCP_OK;
+    if (n_colours < 1) return CCP_ERR_BAD_ARG;
+    for (int i = 0; i < m->n_rows; ++i)
+        if (colour[i] < 0 || colour[i] >= n_colours) return CCP_ERR_BAD_ARG;
+    m->user_colour.assign(colour, colour + m->n_rows);
+    m->user_n_colours = n_colours;
+    return CCP_OK;
+}
+
+int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *x_out, double epsilon,
+                         int32_t max_iteration, int32_t check_every, int32_t ordering, ccp_gs_report *report)
+{
+    CCP_TRY(bind(m));
+    if (!m->uploaded) return CCP_ERR_STATE;
+    if (!b || !x_out || check_every < 0) return CCP_ERR_BAD_ARG;
+    if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;   // the reference asserts len(b) == n_cols and sizes x from b
+    if (ordering != CCP_ORDER_LEXICOGRAPHIC && ordering != CCP_ORDER_MULTICOLOUR) return CCP_ERR_BAD_ARG;
+    Schedule &sc = ordering == CCP_ORDER_MULTICOLOUR ? m->multicolour : m->lexicographic;
+    CCP_TRY(ordering == CCP_ORDER_MULTICOLOUR ? ensure_multicolour(m) : ensure_lexicographic(m));
+    const long n = m->n_rows;
+    hipStream_t s = m->stream;
+    CCP_TRY(ensure_partial(m, sc.group_block_off[sc.n_groups]));
+    // stage b (and x0) in natural order, gather into schedule order
+    if (n) {
+        CCP_HIP(hipMemcpyAsync(m->tmp.p, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL((k_permute<true>), dim3(blocks_for(n)), dim3(kBlock), 0, s, m->b.p, m->tmp.p, sc.perm.p, n);
+        CCP_HIP(hipGetLastError());
+        if (x0) {
+            CCP_HIP(hipStreamSynchronize(s));
+            CCP_HIP(hipMemcpyAsync(m->tmp.p, x0, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL((k_permute<true>), dim3(blocks_for(n)), dim3(kBlock), 0, s, m->x.p, m->tmp.p, sc.perm.p, n);
+        } else {
+            hipLaunchKernelGGL(k_fill_n, dim3(blocks_for(n)), dim3(kBlock), 0, s, m->x.p, n, 1.0);   // sparse-matrix.h:352
+        }
+        CCP_HIP(hipGetLastError());
+    }
+    CsrSolveState host{};
+    host.active = 1;
+    host.last_eps = 10.0;                    // sparse-matrix.h:354
+    CCP_HIP(hipMemcpyAsync(m->state.p, &host, sizeof(host), hipMemcpyHostToDevice, s));
+    CCP_HIP(hipStreamSynchronize(s));
+    CCP_HIP(hipEventRecord(m->ev0, s));
+    const SellView view = sc.view();
+    const int *active = reinterpret_cast<const int *>(m->state.p);
+    double *eps_accum = reinterpret_cast<double *>(reinterpret_cast<char *>(m->state.p) + offsetof(CsrSolveState, eps_accum));
+    int issued = 0;
+    bool any_active = (10.0 > epsilon) && max_iteration > 0 && n > 0;
+    while (any_active && issued < max_iteration) {
+        int checks = 0;
+        while (issued < max_iteration && checks < 8) {
+            const int k = issued + 1;
+            const bool check = check_every > 0 && (k % check_every == 0);
+            for (int g = 0; g < sc.n_groups; ++g) {
+                const int s0 = sc.group_slice_ptr[g], s1 = sc.group_slice_ptr[g + 1];
+                if (s1 == s0) continue;
+                const unsigned blocks = (unsigned)(sc.group_block_off[g + 1] - sc.group_block_off[g]);
+                if (check)
+                    hipLaunchKernelGGL((k_sell_gs<true>), dim3(blocks), dim3(kBlock), 0, s, view, s0, s1, m->x.p, m->b.p,
+                                       m->partial.p + sc.group_block_off[g], active);
+                else
+                    hipLaunchKernelGGL((k_sell_gs<false>), dim3(blocks), dim3(kBlock), 0, s, view, s0, s1, m->x.p, m->b.p,
+                                       m->partial.p, active);
+            }
+            CCP_HIP(hipGetLastError());
+            if (check) {
+                hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, m->partial.p, sc.group_block_off[sc.n_groups], 1L, eps_accum, 0);
+                hipLaunchKernelGGL(k_csr_check, dim3(1), dim3(64), 0, s, m->state.p, epsilon, k);
+                CCP_HIP(hipGetLastError());
+                ++checks;
+            }
+            ++issued;
+        }
+        if (check_every > 0) {
+            CCP_HIP(hipMemcpyAsync(&host, m->state.p, sizeof(host), hipMemcpyDeviceToHost, s));
+            CCP_HIP(hipStreamSynchronize(s));
+            any_active = host.active != 0;
+        }
+    }
+    CCP_HIP(hipEventRecord(m->ev1, s));
+    if (n) {
+        hipLaunchKernelGGL((k_permute<false>), dim3(blocks_for(n)), dim3(kBlock), 0, s, m->tmp.p, m->x.p, sc.perm.p, n);
+        CCP_HIP(hipGetLastError());
+        CCP_HIP(hipMemcpyAsync(x_out, m->tmp.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    }
+    CCP_HIP(hipMemcpyAsync(&host, m->state.p, sizeof(host), hipMemcpyDeviceToHost, s));
+    CCP_HIP(hipStreamSynchronize(s));
+    if (report) {
+        float ms = 0.f;
+        CCP_HIP(hipEventElapsedTime(&ms, m->ev0, m->ev1));
+        report->converged = host.converged;
+        report->iterations = host.converged ? host.iterations : issued;
+        report->last_l1_step = host.last_eps;
+        report->seconds = ms * 1e-3;
+    }
+    return CCP_OK;
+}
+
+int ccp_csr_apply_to_vector(ccp_csr *m, const double *in, double *out)
+{
+    CCP_TRY(bind(m));
+    if (!m->uploaded) return CCP_ERR_STATE;
+    if ((m->n_cols && !in) || (m->n_rows && !out)) return CCP_ERR_BAD_ARG;
+    CCP_TRY(ensure_natural(m));
+    hipStream_t s = m->stream;
+    if (m->n_cols) CCP_HIP(hipMemcpyAsync(m->x.p, in, sizeof(double) * m->n_cols, hipMemcpyHostToDevice, s));
+    if (m->n_rows) {
+        const unsigned blocks = (unsigned)((m->natural.n_slices + kBlock / kWave - 1) / (kBlock / kWave));
+        CCP_TRY(ensure_partial(m, blocks));
+        hipLaunchKernelGGL((k_sell_apply<0>), dim3(blocks), dim3(kBlock), 0, s, m->natural.view(), m->natural.n_slices,
+                           m->x.p, m->tmp.p, m->b.p, m->partial.p);
+        CCP_HIP(hipGetLastError());
+        CCP_HIP(hipMemcpyAsync(out, m->tmp.p, sizeof(double) * m->n_rows, hipMemcpyDeviceToHost, s));
+    }
+    CCP_HIP(hipStreamSynchronize(s));
+    return CCP_OK;
+}
+
+int ccp_csr_residual_norm2(ccp_csr *m, const double *b, const double *x, double *rr, double *bb)
+{
+    CCP_TRY(bind(m));
+    if (!m->uploaded) return CCP_ERR_STATE;
+    if (!b || !x || !rr || !bb) return CCP_ERR_BAD_ARG;
+    CCP_TRY(ensure_natural(m));
+    hipStream_t s = m->stream;
+    *rr = 0.0;
+    *bb = 0.0;
+    if (!m->n_rows) return CCP_OK;
+    CCP_HIP(hipMemcpyAsync(m->x.p, x, sizeof(double) * m->n_cols, hipMemcpyHostToDevice, s));
+    CCP_HIP(hipMemcpyAsync(m->b.p, b, sizeof(double) * m->n_rows, hipMemcpyHostToDevice, s));
+    const unsigned blocks = (unsigned)((m->natural.n_slices + kBlock / kWave - 1) / (kBlock / kWave));
+    CCP_TRY(ensure_partial(m, blocks));
+    hipLaunchKernelGGL((k_sell_apply<1>), dim3(blocks), dim3(kBlock), 0, s, m->natural.view(), m->natural.n_slices, m->x.p,
+                       m->tmp.p, m->b.p, m->partial.p);
+    double *res = m->tmp.p;   // two doubles of scratch for the result
+    hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, m->partial.p, (long)blocks, 2L, res, 0);
+    hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, m->partial.p + 1, (long)blocks, 2L, res + 1, 0);
+    CCP_HIP(hipGetLastError());
+    double host[2];
+    CCP_HIP(hipMemcpyAsync(host, res, sizeof(host), hipMemcpyDeviceToHost, s));
+    CCP_HIP(hipStreamSynchronize(s));
+    *rr = host[0];
+    *bb = host[1];
+    return CCP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,515 @@
+// ccp_grid.hip — C ABI of the structured (matrix-free) Poisson grid path.  See include/ccp_gs.h.
+#include "ccp_grid_kernels.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+using namespace ccp;
+
+struct ccp_grid {
+    ccp_grid_desc desc{};
+    Geom geom{};
+    int ghost_top = 0, ghost_bottom = 0;
+    // a side "shrinks" when the local block stops short of the image border there: its
+    // outermost ghost row has no neighbour row, so validity recedes one row per half-sweep
+    bool shrink_top = false, shrink_bottom = false;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevBuf<double> x, b;
+    DevBuf<double> partial;      // per-block partial sums (L1 step / residual / checksums)
+    long partial_region = 0;     // doubles per colour region of `partial` (L1 step)
+    DevBuf<double> small;        // 4*kMaxChannels doubles of reduced results
+    DevBuf<SolveState> state;
+    DevBuf<double> stage;        // natural-order staging rows for host transfers
+    long stage_rows = 0;
+    int half_sweeps_since_refresh = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float last_ms = 0.f;
+    int last_launches = 0;
+    bool timing_pending = false;
+    int cpt = 2;                 // half-columns per thread of the sweep kernel
+    int rows_per_block = 32;
+};
+
+namespace {
+
+int bind(ccp_grid *g)
+{
+    if (!g) return CCP_ERR_BAD_ARG;
+    if (hipSetDevice(g->device) != hipSuccess) return CCP_ERR_NO_DEVICE;
+    return CCP_OK;
+}
+
+long sweep_blocks_x(const ccp_grid *g) { return (g->geom.pitch + (long)kBlock * g->cpt - 1) / ((long)kBlock * g->cpt); }
+
+void choose_tiling(ccp_grid *g)
+{
+    // Aim for >= 4096 workgroups (>> 256 CUs x 8 resident blocks) while keeping the
+    // two-row halo re-read per row tile small.
+    const long bx = sweep_blocks_x(g);
+    long r = (long)g->geom.local_rows * bx * g->desc.channels / 4096;
+    r = std::max<long>(4, std::min<long>(64, r));
+    if (const char *e = getenv("CCP_GS_ROWS_PER_BLOCK")) r = std::max(1, atoi(e));
+    g->rows_per_block = (int)r;
+}
+
+template <bool L1>
+int launch_half_sweep(ccp_grid *g, int c, int l_lo, int l_hi, const int *active)
+{
+    if (l_hi <= l_lo) return CCP_OK;
+    const Geom &geo = g->geom;
+    const int rpb = g->rows_per_block;
+    dim3 grid((unsigned)sweep_blocks_x(g), (unsigned)((l_hi - l_lo + rpb - 1) / rpb), (unsigned)g->desc.channels);
+    dim3 block(kBlock);
+    if (g->cpt == 4)
+        hipLaunchKernelGGL((k_half_sweep<4, L1>), grid, block, 0, g->stream, g->x.p, g->x.p, g->b.p, geo, c,
+                           l_lo, l_hi, rpb, g->partial.p + (long)c * g->partial_region, active);
+    else
+        hipLaunchKernelGGL((k_half_sweep<2, L1>), grid, block, 0, g->stream, g->x.p, g->x.p, g->b.p, geo, c,
+                           l_lo, l_hi, rpb, g->partial.p + (long)c * g->partial_region, active);
+    CCP_HIP(hipGetLastError());
+    g->last_launches++;
+    return CCP_OK;
+}
+
+// Rows a half-sweep may update: everything on a side that is the image border, and on a side
+// with ghosts one row fewer per half-sweep since the last halo refresh.
+void sweep_range(const ccp_grid *g, int &l_lo, int &l_hi)
+{
+    const int s = g->half_sweeps_since_refresh;
+    l_lo = g->shrink_top ? std::min(s + 1, g->ghost_top) : 0;
+    l_hi = g->geom.local_rows - (g->shrink_bottom ? std::min(s + 1, g->ghost_bottom) : 0);
+}
+
+long l1_blocks_per_colour_channel(const ccp_grid *g, int l_lo, int l_hi)
+{
+    const int rpb = g->rows_per_block;
+    return sweep_blocks_x(g) * (long)((l_hi - l_lo + rpb - 1) / rpb);
+}
+
+// blocks_out[c]: L1 block results per channel the colour-c half-sweep wrote.
+int one_iteration(ccp_grid *g, bool l1, const int *active, long *blocks_out)
+{
+    for (int c = 0; c < 2; ++c) {
+        int lo, hi;
+        sweep_range(g, lo, hi);
+        if ((g->shrink_top || g->shrink_bottom) && g->half_sweeps_since_refresh >= g->desc.ghost)
+            return CCP_ERR_STATE;   // ghosts exhausted: refresh the halo first
+        if (l1) {
+            CCP_TRY(launch_half_sweep<true>(g, c, lo, hi, active));
+            if (blocks_out) blocks_out[c] = l1_blocks_per_colour_channel(g, lo, hi);
+        } else {
+            CCP_TRY(launch_half_sweep<false>(g, c, lo, hi, active));
+        }
+        if (g->shrink_top || g->shrink_bottom) g->half_sweeps_since_refresh++;
+    }
+    return CCP_OK;
+}
+
+void begin_timing(ccp_grid *g)
+{
+    g->last_launches = 0;
+    (void)hipEventRecord(g->ev0, g->stream);
+}
+
+void end_timing(ccp_grid *g)
+{
+    (void)hipEventRecord(g->ev1, g->stream);
+    g->timing_pending = true;
+}
+
+// Host <-> device rows in natural order through the staging buffer.
+template <bool TO_DEVICE>
+int transfer_rows(ccp_grid *g, double *dev_base, int channel, double *rows, int first_row, int n_rows)
+{
+    CCP_TRY(bind(g));
+    if (!rows || channel < 0 || channel >= g->desc.channels || n_rows < 0) return CCP_ERR_BAD_ARG;
+    const int img_lo = g->geom.y0, img_hi = g->geom.y0 + g->geom.local_rows;
+    if (first_row < img_lo || first_row + n_rows > img_hi) return CCP_ERR_BAD_ARG;
+    const int W = g->desc.width;
+    int done = 0;
+    while (done < n_rows) {
+        const int chunk = (int)std::min<long>(g->stage_rows, n_rows - done);
+        const int l_first = first_row + done - g->geom.y0;
+        dim3 grid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)chunk);
+        const size_t bytes = (size_t)chunk * W * sizeof(double);
+        double *host = rows + (size_t)done * W;
+        if (TO_DEVICE) {
+            CCP_HIP(hipMemcpyAsync(g->stage.p, host, bytes, hipMemcpyHostToDevice, g->stream));
+            hipLaunchKernelGGL((k_convert<true>), grid, dim3(kBlock), 0, g->stream, dev_base, g->stage.p,
+                               g->geom, channel, l_first, W);
+            CCP_HIP(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL((k_convert<false>), grid, dim3(kBlock), 0, g->stream, dev_base, g->stage.p,
+                               g->geom, channel, l_first, W);
+            CCP_HIP(hipGetLastError());
+            CCP_HIP(hipMemcpyAsync(host, g->stage.p, bytes, hipMemcpyDeviceToHost, g->stream));
+        }
+        CCP_HIP(hipStreamSynchronize(g->stream));
+        done += chunk;
+    }
+    return CCP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
+{
+    if (!d || !out) return CCP_ERR_BAD_ARG;
+    *out = nullptr;
+    if (d->width < 1 || d->height < 1 || d->channels < 1 || d->channels > kMaxChannels) return CCP_ERR_BAD_ARG;
+    if (d->row_begin < 0 || d->row_count < 1 || d->row_begin + d->row_count > d->height || d->ghost < 0)
+        return CCP_ERR_BAD_ARG;
+    if ((long)d->width * d->height > 0x7fffffffL) return CCP_ERR_BAD_ARG;   // int32 indices, as the reference
+    CCP_TRY(select_device(d->device));
+    ccp_grid *g = new (std::nothrow) ccp_grid();
+    if (!g) return CCP_ERR_ALLOC;
+    g->desc = *d;
+    g->device = d->device;
+    g->ghost_top = d->row_begin > 0 ? std::min(d->ghost, d->row_begin) : 0;
+    g->ghost_bottom = (d->row_begin + d->row_count < d->height) ? std::min(d->ghost, d->height - d->row_begin - d->row_count) : 0;
+    Geom &geo = g->geom;
+    geo.W = d->width;
+    geo.H = d->height;
+    geo.y0 = d->row_begin - g->ghost_top;
+    g->shrink_top = geo.y0 > 0;
+    g->shrink_bottom = d->row_begin + d->row_count + g->ghost_bottom < d->height;
+    geo.local_rows = g->ghost_top + d->row_count + g->ghost_bottom;
+    geo.own_lo = g->ghost_top;
+    geo.own_hi = g->ghost_top + d->row_count;
+    geo.pitch = (((long)d->width + 1) / 2 + 15) / 16 * 16;
+    geo.ch_stride = (long)geo.local_rows * 2 * geo.pitch;
+    g->cpt = 2;
+    if (const char *e = getenv("CCP_GS_CPT")) g->cpt = (atoi(e) == 4) ? 4 : 2;
+    choose_tiling(g);
+
+    const size_t elems = (size_t)geo.ch_stride * d->channels;
+    int st = g->x.alloc(elems);
+    if (st == CCP_OK) st = g->b.alloc(elems);
+    // partial sums: the finest launch is one block per (x tile, row, channel*2) with 2 doubles
+    const size_t part = (size_t)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)) * geo.local_rows * d->channels * 2 * 2 + 64;
+    g->partial_region = (long)(part / 2);
+    if (st == CCP_OK) st = g->partial.alloc(part);
+    if (st == CCP_OK) st = g->small.alloc(4 * kMaxChannels);
+    if (st == CCP_OK) st = g->state.alloc(1);
+    g->stage_rows = std::max<long>(1, std::min<long>(geo.local_rows, (8L << 20) / d->width));
+    if (st == CCP_OK) st = g->stage.alloc((size_t)g->stage_rows * d->width);
+    if (st == CCP_OK && (hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess)) st = CCP_ERR_HIP;
+    if (st == CCP_OK && (hipMemset(g->x.p, 0, elems * sizeof(double)) != hipSuccess ||
+                         hipMemset(g->b.p, 0, elems * sizeof(double)) != hipSuccess))
+        st = CCP_ERR_HIP;
+    if (st != CCP_OK) {
+        ccp_grid_destroy(g);
+        return st;
+    }
+    *out = g;
+    return CCP_OK;
+}
+
+int ccp_grid_destroy(ccp_grid *g)
+{
+    if (!g) return CCP_OK;
+    (void)hipSetDevice(g->device);
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
+    if (g->ev1) (void)hipEventDestroy(g->ev1);
+    delete g;
+    return CCP_OK;
+}
+
+int ccp_grid_get_layout(ccp_grid *g, ccp_grid_layout *out)
+{
+    if (!g || !out) return CCP_ERR_BAD_ARG;
+    out->x_dev = g->x.p;
+    out->b_dev = g->b.p;
+    out->pitch = g->geom.pitch;
+    out->local_rows = g->geom.local_rows;
+    out->ghost_top = g->ghost_top;
+    out->ghost_bottom = g->ghost_bottom;
+    out->channels = g->desc.channels;
+    return CCP_OK;
+}
+
+int ccp_grid_set_stream(ccp_grid *g, void *hip_stream)
+{
+    if (!g) return CCP_ERR_BAD_ARG;
+    g->stream = reinterpret_cast<hipStream_t>(hip_stream);
+    return CCP_OK;
+}
+
+int ccp_grid_synchronize(ccp_grid *g)
+{
+    CCP_TRY(bind(g));
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    return CCP_OK;
+}
+
+int ccp_grid_set_b_host(ccp_grid *g, int32_t channel, const double *rows, int32_t first_row, int32_t n_rows)
+{
+    if (!g) return CCP_ERR_BAD_ARG;
+    return transfer_rows<true>(g, g->b.p, channel, const_cast<double *>(rows), first_row, n_rows);
+}
+
+int ccp_grid_set_x_host(ccp_grid *g, int32_t channel, const double *rows, int32_t first_row, int32_t n_rows)
+{
+    if (!g) return CCP_ERR_BAD_ARG;
+    return transfer_rows<true>(g, g->x.p, channel, const_cast<double *>(rows), first_row, n_rows);
+}
+
+int ccp_grid_get_x_host(ccp_grid *g, int32_t channel, double *rows, int32_t first_row, int32_t n_rows)
+{
+    if (!g) return CCP_ERR_BAD_ARG;
+    return transfer_rows<false>(g, g->x.p, channel, rows, first_row, n_rows);
+}
+
+int ccp_grid_get_b_host(ccp_grid *g, int32_t channel, double *rows, int32_t first_row, int32_t n_rows)
+{
+    if (!g) return CCP_ERR_BAD_ARG;
+    return transfer_rows<false>(g, g->b.p, channel, rows, first_row, n_rows);
+}
+
+int ccp_grid_fill_x(ccp_grid *g, double value)
+{
+    CCP_TRY(bind(g));
+    const long n = g->geom.ch_stride * g->desc.channels;
+    hipLaunchKernelGGL(k_fill, dim3(2048), dim3(kBlock), 0, g->stream, g->x.p, n, value);
+    CCP_HIP(hipGetLastError());
+    g->half_sweeps_since_refresh = 0;
+    return CCP_OK;
+}
+
+int ccp_grid_randomize_x(ccp_grid *g, uint64_t seed, double lo, double hi)
+{
+    CCP_TRY(bind(g));
+    dim3 grid((unsigned)((g->geom.pitch + kBlock - 1) / kBlock), (unsigned)g->geom.local_rows, (unsigned)g->desc.channels * 2);
+    hipLaunchKernelGGL(k_randomize, grid, dim3(kBlock), 0, g->stream, g->x.p, g->geom, seed, lo, hi);
+    CCP_HIP(hipGetLastError());
+    g->half_sweeps_since_refresh = 0;
+    return CCP_OK;
+}
+
+int ccp_grid_b_from_x(ccp_grid *g)
+{
+    CCP_TRY(bind(g));
+    if ((g->shrink_top || g->shrink_bottom) && g->half_sweeps_since_refresh >= g->desc.ghost) return CCP_ERR_STATE;
+    const Geom &geo = g->geom;
+    dim3 grid((unsigned)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)), (unsigned)(geo.own_hi - geo.own_lo), (unsigned)g->desc.channels * 2);
+    hipLaunchKernelGGL((k_apply<2, 0>), grid, dim3(kBlock), 0, g->stream, g->x.p, g->b.p, g->b.p, geo, geo.own_lo, g->partial.p);
+    CCP_HIP(hipGetLastError());
+    return CCP_OK;
+}
+
+int ccp_grid_halo_refreshed(ccp_grid *g)
+{
+    if (!g) return CCP_ERR_BAD_ARG;
+    g->half_sweeps_since_refresh = 0;
+    return CCP_OK;
+}
+
+int ccp_grid_sweep(ccp_grid *g, int32_t iterations)
+{
+    CCP_TRY(bind(g));
+    if (iterations < 0) return CCP_ERR_BAD_ARG;
+    begin_timing(g);
+    for (int k = 0; k < iterations; ++k) CCP_TRY(one_iteration(g, false, nullptr, nullptr));
+    end_timing(g);
+    return CCP_OK;
+}
+
+int ccp_grid_sweep_l1(ccp_grid *g, double *l1_per_channel)
+{
+    CCP_TRY(bind(g));
+    if (!l1_per_channel) return CCP_ERR_BAD_ARG;
+    const int C = g->desc.channels;
+    begin_timing(g);
+    long blocks[2] = {0, 0};
+    CCP_TRY(one_iteration(g, true, nullptr, blocks));
+    hipLaunchKernelGGL(k_check, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
+                       g->partial.p + g->partial_region, blocks[1], 0.0, 0, static_cast<SolveState *>(nullptr), g->small.p);
+    CCP_HIP(hipGetLastError());
+    end_timing(g);
+    CCP_HIP(hipMemcpyAsync(l1_per_channel, g->small.p, sizeof(double) * C, hipMemcpyDeviceToHost, g->stream));
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    return CCP_OK;
+}
+
+int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, int32_t check_every, ccp_gs_report *report)
+{
+    CCP_TRY(bind(g));
+    if (g->ghost_top || g->ghost_bottom) return CCP_ERR_STATE;   // row blocks are driven by the caller (halo exchange)
+    if (check_every < 0) return CCP_ERR_BAD_ARG;
+    const int C = g->desc.channels;
+    SolveState host{};
+    for (int ch = 0; ch < C; ++ch) {
+        host.active[ch] = 1;
+        host.last_eps[ch] = 10.0;            // sparse-matrix.h:354
+    }
+    CCP_HIP(hipMemcpyAsync(g->state.p, &host, sizeof(host), hipMemcpyHostToDevice, g->stream));
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    begin_timing(g);
+    int issued = 0;
+    // `while (eps > epsilon && cnt < max_iteration)`: eps starts at 10
+    const bool enter = (10.0 > epsilon);
+    bool any_active = enter && max_iteration > 0;
+    const int batch_checks = 8;             // checked sweeps enqueued between two host polls
+    while (any_active && issued < max_iteration) {
+        int checks = 0;
+        while (issued < max_iteration && checks < batch_checks) {
+            const int k = issued + 1;
+            const bool check = check_every > 0 && (k % check_every == 0);
+            long blocks[2] = {0, 0};
+            CCP_TRY(one_iteration(g, check, reinterpret_cast<const int *>(g->state.p), blocks));
+            if (check) {
+                hipLaunchKernelGGL(k_check, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
+                                   g->partial.p + g->partial_region, blocks[1], epsilon, k, g->state.p,
+                                   static_cast<double *>(nullptr));
+                CCP_HIP(hipGetLastError());
+                ++checks;
+            }
+            ++issued;
+        }
+        if (check_every > 0) {
+            CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));
+            CCP_HIP(hipStreamSynchronize(g->stream));
+            any_active = false;
+            for (int ch = 0; ch < C; ++ch) any_active |= host.active[ch] != 0;
+        }
+    }
+    end_timing(g);
+    CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    float ms = 0.f;
+    CCP_HIP(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+    g->last_ms = ms;
+    g->timing_pending = false;
+    if (report) {
+        for (int ch = 0; ch < C; ++ch) {
+            report[ch].converged = host.converged[ch];
+            report[ch].iterations = host.converged[ch] ? host.iterations[ch] : issued;
+            report[ch].last_l1_step = host.last_eps[ch];
+            report[ch].seconds = ms * 1e-3;
+        }
+    }
+    return CCP_OK;
+}
+
+int ccp_grid_residual_norm2(ccp_grid *g, double *rr_bb)
+{
+    CCP_TRY(bind(g));
+    if (!rr_bb) return CCP_ERR_BAD_ARG;
+    if ((g->shrink_top || g->shrink_bottom) && g->half_sweeps_since_refresh >= g->desc.ghost) return CCP_ERR_STATE;
+    const Geom &geo = g->geom;
+    const int C = g->desc.channels;
+    dim3 grid((unsigned)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)), (unsigned)(geo.own_hi - geo.own_lo), (unsigned)C * 2);
+    hipLaunchKernelGGL((k_apply<2, 1>), grid, dim3(kBlock), 0, g->stream, g->x.p, g->b.p, g->b.p, geo, geo.own_lo, g->partial.p);
+    CCP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_pair_reduce, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, (long)grid.x * grid.y, g->small.p);
+    CCP_HIP(hipGetLastError());
+    double host[2 * kMaxChannels];
+    CCP_HIP(hipMemcpyAsync(host, g->small.p, sizeof(double) * 2 * C, hipMemcpyDeviceToHost, g->stream));
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    for (int ch = 0; ch < C; ++ch) {
+        rr_bb[ch] = host[2 * ch];
+        rr_bb[C + ch] = host[2 * ch + 1];
+    }
+    return CCP_OK;
+}
+
+int ccp_grid_abs_sum(ccp_grid *g, double *per_channel)
+{
+    CCP_TRY(bind(g));
+    if (!per_channel) return CCP_ERR_BAD_ARG;
+    const int C = g->desc.channels;
+    const unsigned blocks = 1024;
+    hipLaunchKernelGGL(k_abs_sum, dim3(blocks, 1, (unsigned)C), dim3(kBlock), 0, g->stream, g->x.p, g->geom, g->partial.p);
+    CCP_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_sum_reduce, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, (long)blocks, g->small.p);
+    CCP_HIP(hipGetLastError());
+    CCP_HIP(hipMemcpyAsync(per_channel, g->small.p, sizeof(double) * C, hipMemcpyDeviceToHost, g->stream));
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    return CCP_OK;
+}
+
+int ccp_grid_assemble_rhs(ccp_grid *g, const float *gx, const float *gy, int64_t row_stride_bytes, const int32_t *constraint)
+{
+    CCP_TRY(bind(g));
+    if (!gx || !gy || !constraint) return CCP_ERR_BAD_ARG;
+    if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;
+    const int W = g->desc.width, H = g->desc.height, C = g->desc.channels;
+    const size_t row_bytes = (size_t)W * C * sizeof(float);
+    if (row_stride_bytes < (int64_t)row_bytes) return CCP_ERR_BAD_ARG;
+    DevBuf<float> dgx, dgy;
+    DevBuf<int> dcons;
+    CCP_TRY(dgx.alloc((size_t)W * H * C));
+    CCP_TRY(dgy.alloc((size_t)W * H * C));
+    CCP_TRY(dcons.alloc(C));
+    // only rows y < H-1 and columns x < W-1 are defined in the reference (PhotoMontage.cpp:416-425);
+    // the kernel never reads the rest, but the copy must not touch it on the host either.
+    const size_t copy_rows = H > 1 ? (size_t)(H - 1) : 0;
+    CCP_HIP(hipMemsetAsync(dgx.p, 0, (size_t)W * H * C * sizeof(float), g->stream));
+    CCP_HIP(hipMemsetAsync(dgy.p, 0, (size_t)W * H * C * sizeof(float), g->stream));
+    if (copy_rows && W > 1) {
+        const size_t width_bytes = (size_t)(W - 1) * C * sizeof(float);
+        CCP_HIP(hipMemcpy2DAsync(dgx.p, row_bytes, gx, (size_t)row_stride_bytes, width_bytes, copy_rows, hipMemcpyHostToDevice, g->stream));
+        CCP_HIP(hipMemcpy2DAsync(dgy.p, row_bytes, gy, (size_t)row_stride_bytes, width_bytes, copy_rows, hipMemcpyHostToDevice, g->stream));
+    }
+    CCP_HIP(hipMemcpyAsync(dcons.p, constraint, sizeof(int) * C, hipMemcpyHostToDevice, g->stream));
+    dim3 grid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, (unsigned)C);
+    hipLaunchKernelGGL(k_assemble_rhs, grid, dim3(kBlock), 0, g->stream, g->b.p, g->geom, dgx.p, dgy.p, C, dcons.p);
+    CCP_HIP(hipGetLastError());
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    return CCP_OK;
+}
+
+int ccp_grid_store_u8(ccp_grid *g, uint8_t *out, int64_t row_stride_bytes)
+{
+    CCP_TRY(bind(g));
+    if (!out) return CCP_ERR_BAD_ARG;
+    if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;
+    const int W = g->desc.width, H = g->desc.height, C = g->desc.channels;
+    if (row_stride_bytes < (int64_t)W * C) return CCP_ERR_BAD_ARG;
+    DevBuf<uint8_t> d;
+    CCP_TRY(d.alloc((size_t)W * H * C));
+    dim3 grid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, (unsigned)C);
+    hipLaunchKernelGGL(k_store_u8, grid, dim3(kBlock), 0, g->stream, g->x.p, g->geom, d.p, C);
+    CCP_HIP(hipGetLastError());
+    CCP_HIP(hipMemcpy2DAsync(out, (size_t)row_stride_bytes, d.p, (size_t)W * C, (size_t)W * C, (size_t)H, hipMemcpyDeviceToHost, g->stream));
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    return CCP_OK;
+}
+
+int ccp_grid_set_x_u8(ccp_grid *g, const uint8_t *image, int64_t row_stride_bytes)
+{
+    CCP_TRY(bind(g));
+    if (!image) return CCP_ERR_BAD_ARG;
+    if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;
+    const int W = g->desc.width, H = g->desc.height, C = g->desc.channels;
+    if (row_stride_bytes < (int64_t)W * C) return CCP_ERR_BAD_ARG;
+    DevBuf<uint8_t> d;
+    CCP_TRY(d.alloc((size_t)W * H * C));
+    CCP_HIP(hipMemcpy2DAsync(d.p, (size_t)W * C, image, (size_t)row_stride_bytes, (size_t)W * C, (size_t)H, hipMemcpyHostToDevice, g->stream));
+    dim3 grid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, (unsigned)C);
+    hipLaunchKernelGGL(k_load_u8, grid, dim3(kBlock), 0, g->stream, g->x.p, g->geom, d.p, C);
+    CCP_HIP(hipGetLastError());
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    return CCP_OK;
+}
+
+int ccp_grid_last_timing(ccp_grid *g, float *milliseconds, int32_t *kernel_launches)
+{
+    CCP_TRY(bind(g));
+    if (g->timing_pending) {
+        CCP_HIP(hipEventSynchronize(g->ev1));
+        float ms = 0.f;
+        CCP_HIP(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+        g->last_ms = ms;
+        g->timing_pending = false;
+    }
+    if (milliseconds) *milliseconds = g->last_ms;
+    if (kernel_launches) *kernel_launches = g->last_launches;
+    return CCP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,211 @@
+/*
+ * ccp_gs.h — C ABI of libccp_gs.so: MI355X (gfx950) Gauss-Seidel / SpMV / Poisson-assembly
+ * path of linwe2012/CourseComputationalPhotography.
+ *
+ * The reference has no FFI; its boundary for this path is the member-function surface of the
+ * header-only template `SparseMatrix<T,IndexType>` plus `PhotoMontage::SolveChannel`
+ * (SURVEY.md §8b).  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference repo root).  The C++ facade `include/ccp/sparse-matrix.h`
+ * keeps the reference's own names and signatures on top of this ABI; INTEGRATION.md shows the
+ * binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns a ccp_status (0 = ok) and never throws;
+ *   - "host" pointers are caller-owned host buffers (never retained);
+ *     "dev" pointers are device addresses on the handle's GPU;
+ *   - one handle per host thread; a handle is bound to one HIP device and one stream;
+ *   - values are IEEE fp64, indices int32 (as the reference: SparseMatrix<double,int>);
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point
+ *     returns CCP_ERR_NO_DEVICE.
+ */
+#ifndef CCP_GS_H
+#define CCP_GS_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CCP_GS_ABI_VERSION 1
+
+typedef enum ccp_status {
+    CCP_OK = 0,
+    CCP_ERR_BAD_ARG = 1,      /* null pointer, negative size, inconsistent arrays            */
+    CCP_ERR_NO_DEVICE = 2,    /* no HIP device / hipSetDevice failed                         */
+    CCP_ERR_HIP = 3,          /* a HIP runtime call or kernel launch failed                  */
+    CCP_ERR_ALLOC = 4,        /* host or device allocation failed                            */
+    CCP_ERR_STATE = 5,        /* call sequence error (e.g. solve before upload)              */
+    CCP_ERR_UNSUPPORTED = 6   /* e.g. colouring that is not a proper colouring of the matrix */
+} ccp_status;
+
+/* Sweep ordering of the Gauss-Seidel solve.
+ *  LEXICOGRAPHIC: the reference's row-index order (sparse-matrix.h:359-374), executed on the
+ *                 GPU by level scheduling; bit-identical to the reference iterates, slow.
+ *  MULTICOLOUR  : rows grouped by colour, colours swept one after another (red-black for the
+ *                 5-point grid).  Identical to the reference gaussSeidel applied to P A P^T
+ *                 with the rows listed colour by colour.  The fast path. */
+typedef enum ccp_ordering {
+    CCP_ORDER_LEXICOGRAPHIC = 0,
+    CCP_ORDER_MULTICOLOUR = 1
+} ccp_ordering;
+
+/* What a solve reports (the reference returns none of this; SURVEY.md §5 "metrics"). */
+typedef struct ccp_gs_report {
+    int32_t iterations;       /* sweeps executed (the reference's `cnt`, sparse-matrix.h:355) */
+    int32_t converged;        /* 1 if the L1-step rule stopped the loop before max_iteration  */
+    double  last_l1_step;     /* sum|x_k - x_{k-1}| of the last CHECKED sweep (`eps`, :376)   */
+    double  seconds;          /* device time of the sweep loop (HIP events), excl. transfers  */
+} ccp_gs_report;
+
+const char *ccp_status_string(int status);
+int ccp_abi_version(void);
+/* Number of visible HIP devices (0 when there is none); never fails. */
+int ccp_device_count(void);
+
+/* ========================================================================================
+ * 1. General slack-CSR matrix  —  replaces SparseMatrix<double,int> storage + solvers
+ *    (project/src/PhotoMontage/sparse-matrix.h:107-121, 670-676).
+ * ====================================================================================== */
+typedef struct ccp_csr ccp_csr;
+
+int ccp_csr_create(int device, ccp_csr **out);
+int ccp_csr_destroy(ccp_csr *m);
+
+/* Hand the five reference arrays to the device.  Replaces the storage hand-off that
+ * initializeFromEigenRowMajor / initializeFromVector end in (sparse-matrix.h:537-620,
+ * 265-319): values_/col_offset_ have n_values entries, row_begin_/row_num_nze_ have n_rows
+ * entries (row_begin is NOT n_rows+1 long); live entries of a row are sorted by column. */
+int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values,
+                   const double *values, const int32_t *col_offset,
+                   const int32_t *row_begin, const int32_t *row_num_nze);
+
+/* Optional colouring for CCP_ORDER_MULTICOLOUR: colour[i] in [0,n_colours), rows of one
+ * colour must not reference each other (checked: CCP_ERR_UNSUPPORTED otherwise).
+ * Without it the library colours the rows itself (greedy, in row order; a 4-connected
+ * raster mask gets its checkerboard). */
+int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours);
+
+/* SparseMatrix::gaussSeidel(b, epsilon, max_iteration) (sparse-matrix.h:350-380).
+ * x0 == NULL starts from all-ones as the reference does (:352); a non-NULL x0 is the `init`
+ * extension mirroring conjugateGradient's 4th argument (:396).  b, x_out: n_cols entries.
+ * check_every: the L1-step stop rule (:356,376) is evaluated every check_every-th sweep
+ * (1 = the reference's behaviour; 0 = never: exactly max_iteration sweeps). */
+int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *x_out,
+                         double epsilon, int32_t max_iteration, int32_t check_every,
+                         int32_t ordering, ccp_gs_report *report);
+
+/* SparseMatrix::applyToVector(in, out) (sparse-matrix.h:382-393). in: n_cols, out: n_rows. */
+int ccp_csr_apply_to_vector(ccp_csr *m, const double *in, double *out);
+
+/* sum (b - A x)^2 and sum b^2 (applyToVector + vecsub + veclen2, sparse-matrix.h:51-55,75-79). */
+int ccp_csr_residual_norm2(ccp_csr *m, const double *b, const double *x, double *rr, double *bb);
+
+/* ========================================================================================
+ * 2. Structured Poisson grid  —  matrix-free form of the system SolveChannel assembles
+ *    (project/src/PhotoMontage/PhotoMontage.cpp:541-597; labs/lab8/.../hw8_pa.cc:911-967).
+ *    The matrix is never stored: degree and neighbours follow from (x,y).
+ *    A grid handle may own only a block of image rows [row_begin, row_begin+row_count) plus
+ *    `ghost` rows on each side that has a neighbour block (row-blocked multi-GPU).
+ * ====================================================================================== */
+typedef struct ccp_grid ccp_grid;
+
+typedef struct ccp_grid_desc {
+    int32_t width;        /* W: unknowns per image row                                       */
+    int32_t height;       /* H: image rows of the WHOLE system                               */
+    int32_t channels;     /* right-hand sides sharing the matrix (3 for a BGR blend)         */
+    int32_t row_begin;    /* first image row this handle owns (0 on a single GPU)            */
+    int32_t row_count;    /* rows owned (H on a single GPU)                                  */
+    int32_t ghost;        /* ghost rows kept above/below where another block exists          */
+    int32_t device;       /* HIP device ordinal                                              */
+    int32_t flags;        /* CCP_GRID_* bits                                                 */
+} ccp_grid_desc;
+
+/* Device layout, for callers that move halos themselves (torch.distributed / RCCL).
+ * Element (channel ch, local row l, colour c, half-column j) of x or b lives at
+ *   base + (((ch*local_rows + l)*2 + c)*pitch + j) * 8 bytes,
+ * local row l = image row (row_begin - ghost_top + l), colour c = (x+y)&1, j = x>>1.
+ * One image row of one channel is therefore 2*pitch contiguous doubles. */
+typedef struct ccp_grid_layout {
+    void   *x_dev;
+    void   *b_dev;
+    int64_t pitch;        /* doubles per colour half-row (>= ceil(W/2), multiple of 16)      */
+    int32_t local_rows;   /* ghost_top + row_count + ghost_bottom                            */
+    int32_t ghost_top;
+    int32_t ghost_bottom;
+    int32_t channels;
+} ccp_grid_layout;
+
+int ccp_grid_create(const ccp_grid_desc *desc, ccp_grid **out);
+int ccp_grid_destroy(ccp_grid *g);
+int ccp_grid_get_layout(ccp_grid *g, ccp_grid_layout *out);
+/* All device work of this handle is enqueued on `hip_stream` (a hipStream_t; NULL = the
+ * null stream). */
+int ccp_grid_set_stream(ccp_grid *g, void *hip_stream);
+int ccp_grid_synchronize(ccp_grid *g);
+
+/* Host hand-off in natural raster order (what the reference's std::vector<double> holds):
+ * `n_rows` image rows starting at image row `first_row`, W doubles each.  Rows may cover the
+ * ghosts.  These calls synchronise the stream. */
+int ccp_grid_set_b_host(ccp_grid *g, int32_t channel, const double *rows, int32_t first_row, int32_t n_rows);
+int ccp_grid_set_x_host(ccp_grid *g, int32_t channel, const double *rows, int32_t first_row, int32_t n_rows);
+int ccp_grid_get_x_host(ccp_grid *g, int32_t channel, double *rows, int32_t first_row, int32_t n_rows);
+int ccp_grid_get_b_host(ccp_grid *g, int32_t channel, double *rows, int32_t first_row, int32_t n_rows);
+/* x := value everywhere (the reference start vector is 1.0, sparse-matrix.h:352). Async. */
+int ccp_grid_fill_x(ccp_grid *g, double value);
+/* b := A x (applyToVector order, sparse-matrix.h:382-393) on the owned rows; needs valid
+ * ghost rows of x when the block has neighbours.  Used to build b = A x_true on device. Async. */
+int ccp_grid_b_from_x(ccp_grid *g);
+/* x := uniform [lo,hi) pseudo-random field depending only on (seed, channel, image x, y):
+ * identical across any row partition.  Fills owned + ghost rows.  Async. */
+int ccp_grid_randomize_x(ccp_grid *g, uint64_t seed, double lo, double hi);
+
+/* `iterations` red-black Gauss-Seidel sweeps (red = colour 0 first) over all local rows that
+ * have their neighbours locally; no convergence check, no host synchronisation. Async.
+ * With ghosts: each sweep invalidates two more ghost rows, so at most ghost/2 iterations may
+ * run between two halo refreshes (enforced: CCP_ERR_STATE). */
+int ccp_grid_sweep(ccp_grid *g, int32_t iterations);
+/* One more sweep that also returns, per channel, sum|x_new - x_old| over the OWNED rows (the
+ * local share of the reference's manhattonDist step, sparse-matrix.h:376) to a host array of
+ * `channels` doubles; row-blocked callers all-reduce it.  Synchronises. */
+int ccp_grid_sweep_l1(ccp_grid *g, double *l1_per_channel);
+/* Tell the handle its ghost rows were just refreshed (by the caller's halo exchange). */
+int ccp_grid_halo_refreshed(ccp_grid *g);
+
+/* SparseMatrix::gaussSeidel loop (sparse-matrix.h:350-380) on the resident system, all
+ * channels at once, each channel with its own stop test exactly as three separate reference
+ * calls would (PhotoMontage.cpp:429-433): a channel that met `eps <= epsilon` is frozen.
+ * report: array of `channels` entries (may be NULL).  Single-block handles only. */
+int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration,
+                          int32_t check_every, ccp_gs_report *report);
+
+/* Per-channel sums over the OWNED rows: rr = sum (b - A x)^2, bb = sum b^2 (2*channels
+ * doubles: rr[0..ch), bb[0..ch)).  Synchronises. */
+int ccp_grid_residual_norm2(ccp_grid *g, double *rr_bb);
+/* Per-channel L1 distance sum|x - other| against a host vector is not needed: the L1 step of
+ * the last checked sweep is in the report.  Sum over owned rows of |x| (checksum helper): */
+int ccp_grid_abs_sum(ccp_grid *g, double *per_channel);
+
+/* Poisson right-hand side on device: ATb for every channel from the gradient fields
+ * (PhotoMontage.cpp:563-572,579-581,592).  gx, gy: host, H x W x channels float32
+ * interleaved, row stride in bytes (cv::Mat CV_32FC3 layout); only y<H-1, x<W-1 are read.
+ * constraint[ch] = the pin value v(0,0).  Single-block handles only. */
+int ccp_grid_assemble_rhs(ccp_grid *g, const float *gx, const float *gy, int64_t row_stride_bytes,
+                          const int32_t *constraint);
+/* Solve epilogue (PhotoMontage.cpp:617-626): out(y,x)[ch] = uchar(max(min(x,255),0)) for all
+ * channels into an interleaved H x W x channels u8 host image. */
+int ccp_grid_store_u8(ccp_grid *g, uint8_t *out, int64_t row_stride_bytes);
+/* Composite initial guess (PhotoMontage.cpp:599-610): x(y,x)[ch] = image(y,x)[ch] from an
+ * interleaved u8 host image (the `fast_init_value` extension for GS). */
+int ccp_grid_set_x_u8(ccp_grid *g, const uint8_t *image, int64_t row_stride_bytes);
+
+/* Device time of the last ccp_grid_sweep / ccp_grid_gauss_seidel in milliseconds and the
+ * number of half-sweep kernel launches it issued (HIP events on the handle's stream). */
+int ccp_grid_last_timing(ccp_grid *g, float *milliseconds, int32_t *kernel_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CCP_GS_H */

@@ -1,0 +1,133 @@
+"""GPU parity of the general slack-CSR path (Gauss-Seidel both orderings, SpMV, residual) —
+through the C ABI, against the reference fixtures and the CPU oracle.  Bit-exact bar."""
+import numpy as np
+import pytest
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from coursecomputationalphotography_amd import capi
+    assert capi.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return capi
+
+
+def dense_to_vector_arrays(orc, dense):
+    """The five slack-CSR arrays the reference's initialize(r,c,list) ends with."""
+    m = orc.from_dense(dense)
+    vals, cols, rb, nnz, _ = m.storage()
+    return m, vals, cols, rb, nnz
+
+
+def test_known_answer_4x4_lexicographic_bit_exact(capi, golden, orc):
+    """The reference's only gaussSeidel test (main6.cc:238-249): every iterate k=1..8, the
+    default-epsilon stop at k=8, expected x ~ (1, 2, -1, 1)."""
+    d = golden("known_answer_4x4.npz")
+    _, vals, cols, rb, nnz = dense_to_vector_arrays(orc, d["A"])
+    m = capi.CsrMatrix().upload(4, 4, vals, cols, rb, nnz)
+    for k in range(1, 9):
+        x, rep = m.gauss_seidel(d["b"], 0.0, k, ordering=capi.ORDER_LEXICOGRAPHIC)
+        assert np.array_equal(x, d["gs_iterates"][k - 1]), k
+        assert rep.iterations == k
+    x, rep = m.gauss_seidel(d["b"], 1e-6, 1000, ordering=capi.ORDER_LEXICOGRAPHIC)
+    assert rep.iterations == 8 and rep.converged == 1
+    assert np.array_equal(x, d["gs_final"])
+    assert np.allclose(x, [1, 2, -1, 1], atol=1e-6)
+    # multicolour converges to the same solution (different iterates)
+    x, rep = m.gauss_seidel(d["b"], 1e-9, 1000, ordering=capi.ORDER_MULTICOLOUR)
+    assert rep.converged == 1 and np.allclose(x, [1, 2, -1, 1], atol=1e-8)
+    m.close()
+
+
+@pytest.mark.parametrize("name", ["poisson_8x8.npz", "poisson_17x13.npz", "poisson_64x64.npz"])
+def test_poisson_csr_both_orderings(capi, golden, name):
+    import oracle
+    from coursecomputationalphotography_amd import synth
+    d = golden(name)
+    W, H = int(d["W"]), int(d["H"])
+    v, c, r = synth.poisson_csr(W, H)
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    for k in (1, 2, 10, 50):
+        x, _ = m.gauss_seidel(d["b"], 0.0, k, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+        assert np.array_equal(x, d[f"x_lex_k{k}"]), (name, "lex", k)
+    m.set_colouring(oracle.grid_colour(W, H), 2)
+    for k in (1, 2, 10, 50):
+        x, _ = m.gauss_seidel(d["b"], 0.0, k, check_every=0, ordering=capi.ORDER_MULTICOLOUR)
+        assert rel_l2(x, d[f"x_rb_k{k}"]) <= TOL
+        assert np.array_equal(x, d[f"x_rb_k{k}"]), (name, "rb", k)
+    # library-chosen greedy colouring of a full grid is the checkerboard too
+    m.set_colouring(None)
+    x, _ = m.gauss_seidel(d["b"], 0.0, 10, check_every=0, ordering=capi.ORDER_MULTICOLOUR)
+    assert np.array_equal(x, d["x_rb_k10"])
+    assert np.array_equal(m.apply_to_vector(d["x_true"]), d["spmv_x_true"])
+    rr, bb = m.residual_norm2(d["b"], d["x_rb_k10"])
+    want = float(np.sum(d["resid_rb_k10"] ** 2))
+    assert abs(rr - want) <= 1e-12 * want and abs(bb - float(np.sum(d["b"] ** 2))) <= 1e-12 * bb
+    m.close()
+
+
+def test_irregular_mask_fixture(capi, golden):
+    d = golden("mask_61x47.npz")
+    m = capi.CsrMatrix().upload_compressed(d["values"], d["cols"], d["row_offset"])
+    assert np.array_equal(m.apply_to_vector(d["x_true"]), d["b"])
+    m.set_colouring(d["colour"], 2)
+    for k in (1, 2, 10, 50):
+        x, _ = m.gauss_seidel(d["b"], 0.0, k, check_every=0, ordering=capi.ORDER_MULTICOLOUR)
+        assert np.array_equal(x, d[f"x_rb_k{k}"]), ("rb", k)
+        x, _ = m.gauss_seidel(d["b"], 0.0, k, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+        assert np.array_equal(x, d[f"x_lex_k{k}"]), ("lex", k)
+    m.close()
+
+
+def test_slack_ingest_fixture(capi, golden, orc):
+    """Matrix ingested with per-row slack / trailing empty rows (sparse-matrix.h:560-619)."""
+    d = golden("slack_ingest_12.npz")
+    n = 12
+    om = orc.from_eigen_row_major(d["values"], d["row_offset"], d["cols"], n, n, d["non_zeros"])
+    vals, cols, rb, nnz, _ = om.storage()
+    m = capi.CsrMatrix().upload(n, n, vals, cols, rb, nnz)
+    assert np.array_equal(m.apply_to_vector(d["xin"]), d["spmv"])
+    x, _ = m.gauss_seidel(d["b"], 0.0, 7, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+    assert np.array_equal(x, d["gs_k7"])
+    m.close()
+
+
+def test_bad_colouring_rejected(capi):
+    from coursecomputationalphotography_amd import synth
+    v, c, r = synth.poisson_csr(6, 5)
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    m.set_colouring(np.zeros(30, dtype=np.int32), 1)
+    with pytest.raises(capi.CcpError) as e:
+        m.gauss_seidel(np.ones(30), 0.0, 1)
+    assert e.value.status == 6
+    m.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_sparse_vs_oracle(capi, orc, seed):
+    """Random diagonally dominant sparse systems, general multi-colouring (greedy)."""
+    from coursecomputationalphotography_amd import synth
+    g = synth.rng(seed)
+    n = 200 + 57 * seed
+    dense = np.where(g.uniform(size=(n, n)) < 0.02, g.uniform(-1, 1, (n, n)), 0.0)
+    dense = dense + dense.T
+    np.fill_diagonal(dense, np.abs(dense).sum(axis=1) + 1.0)
+    dense[5, :] = 0.0                      # an empty row: skipped, x stays at its start value
+    rows, cols = np.nonzero(dense)
+    vals = dense[rows, cols]
+    om = orc.from_vector(rows, cols, vals)
+    v, c, rb, nnz, _ = om.storage()
+    m = capi.CsrMatrix().upload(om.n_rows, om.n_cols, v, c, rb, nnz)
+    b = g.uniform(-10, 10, n)
+    want, it, eps = om.gauss_seidel(b, 1e-9, 500)
+    x, rep = m.gauss_seidel(b, 1e-9, 500, ordering=capi.ORDER_LEXICOGRAPHIC)
+    assert np.array_equal(x, want) and rep.iterations == it
+    assert abs(rep.last_l1_step - eps) <= 1e-9 * max(eps, 1e-300) + 1e-18
+    xm, repm = m.gauss_seidel(b, 1e-9, 500, ordering=capi.ORDER_MULTICOLOUR)
+    assert repm.converged == 1 and rel_l2(xm, want) < 1e-8
+    assert np.array_equal(m.apply_to_vector(b), om.apply_to_vector(b))
+    m.close()
