@@ -104,21 +104,28 @@ def test_stop_rule_and_l1_step(capi, golden, orc, name):
         assert rep.iterations == k and rep.converged == 0
         assert abs(rep.last_l1_step - want) <= 1e-12 * abs(want)
         assert np.array_equal(g.get_x().ravel(), d[f"x_rb_k{k}"])
-    # stop rule: pick epsilon between the oracle's step k=6 and k=7 values
+    # stop rule on a down-scaled system (the reference enters its loop only if epsilon < 10,
+    # sparse-matrix.h:354-356): the oracle says at which sweep sum|dx| first drops to epsilon
     v, c, r = synth.poisson_csr(W, H)
     col = oracle.grid_colour(W, H)
-    x6, _, e6 = orc.multicolour_gauss_seidel(v, c, r, col, d["b"], 0.0, 6)
-    x7, it7, e7 = orc.multicolour_gauss_seidel(v, c, r, col, d["b"], 0.0, 7)
-    eps = 0.5 * (e6 + e7)
-    want, it, e = orc.multicolour_gauss_seidel(v, c, r, col, d["b"], eps, 1000)
-    assert it == 7
+    bs = d["b"] * 1e-3
+    eps = 0.3 if W == 17 else 0.5
+    want, it, e = orc.multicolour_gauss_seidel(v, c, r, col, bs, eps, 1000)
+    assert 1 < it < 1000
+    g.set_b(bs)
     g.fill_x(1.0)
     rep = g.gauss_seidel(eps, 1000, 1)[0]
-    assert rep.iterations == 7 and rep.converged == 1
+    assert rep.iterations == it and rep.converged == 1
+    assert abs(rep.last_l1_step - e) <= 1e-10 * e
     assert np.array_equal(g.get_x().ravel(), want)
+    # epsilon >= 10: the reference loop is never entered, x stays at the start vector
+    g.fill_x(1.0)
+    rep = g.gauss_seidel(10.0, 1000, 1)[0]
+    assert rep.iterations == 0 and np.all(g.get_x() == 1.0)
+    g.set_b(d["b"])
     # check_every = 0: exactly max_iteration sweeps, no stop test
     g.fill_x(1.0)
-    rep = g.gauss_seidel(eps, 10, 0)[0]
+    rep = g.gauss_seidel(0.0, 10, 0)[0]
     assert rep.iterations == 10 and rep.converged == 0
     assert np.array_equal(g.get_x().ravel(), d["x_rb_k10"])
     g.close()
