@@ -1,5 +1,6 @@
 // ccp_grid.hip — C ABI of the structured (matrix-free) Poisson grid path.  See include/ccp_gs.h.
 #include "ccp_grid_kernels.hpp"
+#include "ccp_grid_fused.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -17,6 +18,10 @@ struct ccp_grid {
     int device = 0;
     hipStream_t stream = nullptr;
     DevBuf<double> x, b;
+    DevBuf<double> x_alt;        // ping-pong partner of x for the temporally blocked sweep
+    bool fuse = true;            // use k_fused_sweep for unchecked sweeps
+    int fuse_tmax = kFusedMaxT;  // iterations fused per launch (<= kFusedMaxT)
+    int rows_per_chunk = 128;    // rows a fused wave finalises (plus 4T halo rows)
     DevBuf<double> partial;      // per-block partial sums (L1 step / residual / checksums)
     long partial_region = 0;     // doubles per colour region of `partial` (L1 step)
     DevBuf<double> small;        // 4*kMaxChannels doubles of reduced results
@@ -29,6 +34,7 @@ struct ccp_grid {
     int last_launches = 0;
     bool timing_pending = false;
     int cpt = 2;                 // half-columns per thread of the sweep kernel
+    bool shfl = true;            // horizontal neighbour from the adjacent lane (vs. re-load)
     int rows_per_block = 32;
 };
 
@@ -62,12 +68,16 @@ int launch_half_sweep(ccp_grid *g, int c, int l_lo, int l_hi, const int *active)
     const int rpb = g->rows_per_block;
     dim3 grid((unsigned)sweep_blocks_x(g), (unsigned)((l_hi - l_lo + rpb - 1) / rpb), (unsigned)g->desc.channels);
     dim3 block(kBlock);
-    if (g->cpt == 4)
-        hipLaunchKernelGGL((k_half_sweep<4, L1>), grid, block, 0, g->stream, g->x.p, g->x.p, g->b.p, geo, c,
-                           l_lo, l_hi, rpb, g->partial.p + (long)c * g->partial_region, active);
-    else
-        hipLaunchKernelGGL((k_half_sweep<2, L1>), grid, block, 0, g->stream, g->x.p, g->x.p, g->b.p, geo, c,
-                           l_lo, l_hi, rpb, g->partial.p + (long)c * g->partial_region, active);
+    double *part = g->partial.p + (long)c * g->partial_region;
+#define CCP_LAUNCH_SWEEP(CPT_, SHFL_)                                                                          \
+    hipLaunchKernelGGL((k_half_sweep<CPT_, L1, SHFL_>), grid, block, 0, g->stream, g->x.p, g->x.p, g->b.p, geo, \
+                       c, l_lo, l_hi, rpb, part, active)
+    if (g->cpt == 4) {
+        if (g->shfl) CCP_LAUNCH_SWEEP(4, true); else CCP_LAUNCH_SWEEP(4, false);
+    } else {
+        if (g->shfl) CCP_LAUNCH_SWEEP(2, true); else CCP_LAUNCH_SWEEP(2, false);
+    }
+#undef CCP_LAUNCH_SWEEP
     CCP_HIP(hipGetLastError());
     g->last_launches++;
     return CCP_OK;
@@ -103,6 +113,75 @@ int one_iteration(ccp_grid *g, bool l1, const int *active, long *blocks_out)
             CCP_TRY(launch_half_sweep<false>(g, c, lo, hi, active));
         }
         if (g->shrink_top || g->shrink_bottom) g->half_sweeps_since_refresh++;
+    }
+    return CCP_OK;
+}
+
+template <int T>
+int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi)
+{
+    FusedParams P;
+    P.xin = xin;
+    P.xout = xout;
+    P.b = g->b.p;
+    P.g = g->geom;
+    P.st_lo = st_lo;
+    P.st_hi = st_hi;
+    P.rows_per_chunk = g->rows_per_chunk;
+    const int U = fused_useful_px(T);
+    P.n_strips = (g->geom.W + U - 1) / U;
+    P.partial = g->partial.p;
+    const int waves = kBlock / kWave;
+    dim3 grid((unsigned)((P.n_strips + waves - 1) / waves), (unsigned)((st_hi - st_lo + P.rows_per_chunk - 1) / P.rows_per_chunk),
+              (unsigned)g->desc.channels);
+    hipLaunchKernelGGL((k_fused_sweep<T, false>), grid, dim3(kBlock), 0, g->stream, P);
+    CCP_HIP(hipGetLastError());
+    g->last_launches++;
+    return CCP_OK;
+}
+
+// T fused iterations xin -> xout, with the ghost bookkeeping of 2T half-sweeps.
+int launch_fused(ccp_grid *g, int T, const double *xin, double *xout)
+{
+    const bool shrinking = g->shrink_top || g->shrink_bottom;
+    const int s = g->half_sweeps_since_refresh;
+    if (shrinking && s + 2 * T > g->desc.ghost) return CCP_ERR_STATE;   // ghosts exhausted: refresh first
+    const int st_lo = g->shrink_top ? std::min(s + 2 * T, g->ghost_top) : 0;
+    const int st_hi = g->geom.local_rows - (g->shrink_bottom ? std::min(s + 2 * T, g->ghost_bottom) : 0);
+    if (st_hi > st_lo) {
+        switch (T) {
+        case 1: CCP_TRY(launch_fused_t<1>(g, xin, xout, st_lo, st_hi)); break;
+        case 2: CCP_TRY(launch_fused_t<2>(g, xin, xout, st_lo, st_hi)); break;
+        case 3: CCP_TRY(launch_fused_t<3>(g, xin, xout, st_lo, st_hi)); break;
+        case 4: CCP_TRY(launch_fused_t<4>(g, xin, xout, st_lo, st_hi)); break;
+        default: return CCP_ERR_BAD_ARG;
+        }
+    }
+    if (shrinking) g->half_sweeps_since_refresh += 2 * T;
+    return CCP_OK;
+}
+
+// `iterations` unchecked sweeps: an even number of fused launches (so the result lands back
+// in g->x), a lone leftover iteration through the in-place half-sweep kernels.
+int run_unchecked(ccp_grid *g, int iterations)
+{
+    if (!g->fuse || iterations < 2) {
+        for (int k = 0; k < iterations; ++k) CCP_TRY(one_iteration(g, false, nullptr, nullptr));
+        return CCP_OK;
+    }
+    if (!g->x_alt.p) {
+        const size_t elems = (size_t)g->geom.ch_stride * g->desc.channels;
+        CCP_TRY(g->x_alt.alloc(elems));
+        CCP_HIP(hipMemsetAsync(g->x_alt.p, 0, elems * sizeof(double), g->stream));
+    }
+    const int tmax = g->fuse_tmax;
+    const int launches = 2 * ((iterations + 2 * tmax - 1) / (2 * tmax));
+    const int base_t = iterations / launches, extra = iterations % launches;
+    double *cur = g->x.p, *alt = g->x_alt.p;
+    for (int k = 0; k < launches; ++k) {
+        const int T = base_t + (k < extra ? 1 : 0);
+        CCP_TRY(launch_fused(g, T, cur, alt));
+        std::swap(cur, alt);
     }
     return CCP_OK;
 }
@@ -184,6 +263,10 @@ int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
     geo.ch_stride = (long)geo.local_rows * 2 * geo.pitch;
     g->cpt = 2;
     if (const char *e = getenv("CCP_GS_CPT")) g->cpt = (atoi(e) == 4) ? 4 : 2;
+    if (const char *e = getenv("CCP_GS_SHFL")) g->shfl = atoi(e) != 0;
+    if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
+    if (const char *e = getenv("CCP_GS_TMAX")) g->fuse_tmax = std::max(1, std::min(kFusedMaxT, atoi(e)));
+    if (const char *e = getenv("CCP_GS_CHUNK")) g->rows_per_chunk = std::max(1, atoi(e));
     choose_tiling(g);
 
     const size_t elems = (size_t)geo.ch_stride * d->channels;
@@ -313,7 +396,7 @@ int ccp_grid_sweep(ccp_grid *g, int32_t iterations)
     CCP_TRY(bind(g));
     if (iterations < 0) return CCP_ERR_BAD_ARG;
     begin_timing(g);
-    for (int k = 0; k < iterations; ++k) CCP_TRY(one_iteration(g, false, nullptr, nullptr));
+    CCP_TRY(run_unchecked(g, iterations));
     end_timing(g);
     return CCP_OK;
 }

@@ -125,7 +125,13 @@ __device__ __forceinline__ double apply_row(const Stencil &s, double xi, double 
 // L1: also accumulate sum |x_new - x_old| over the OWNED rows into partial[] (one double per
 // block at [(ch*gridDim.y + by)*gridDim.x + bx]; the host passes a per-colour region) — the
 // reference's manhattonDist(x, prev) (sparse-matrix.h:376), in a deterministic order.
-template <int CPT, bool L1>
+//
+// The one horizontal neighbour outside the thread's own CPT half-columns comes from the
+// adjacent lane's registers (SHFL: __shfl_up/__shfl_down, no memory traffic); only the two edge
+// lanes of a wave fetch it, together with the row's vector load, one row ahead.  (The first
+// version re-loaded it per lane a row later: by then the line had left the 4 MiB L2 and the
+// kernel fetched 1.43x its algorithmic read bytes — profiles/r01_half_sweep_v0_*.)
+template <int CPT, bool L1, bool SHFL>
 __global__ void __launch_bounds__(kBlock)
 k_half_sweep(const double *__restrict__ xr, double *__restrict__ xw, const double *__restrict__ b,
              Geom g, int c, int l_lo, int l_hi, int rows_per_block,
@@ -147,15 +153,35 @@ k_half_sweep(const double *__restrict__ xr, double *__restrict__ xw, const doubl
         if (la >= 1) ld_vec<CPT>(xo + row_off(g, la - 1, o) + j0, up);
         else zero_vec<CPT>(up);
         ld_vec<CPT>(xo + row_off(g, la, o) + j0, mid);
+        const int lane = threadIdx.x & (kWave - 1);
+        // edge value of the wave for the row held in `mid` / `dn` (SHFL only)
+        double edge_mid = 0.0, edge_dn = 0.0;
+        if (SHFL) {
+            const int p0 = (g.y0 + la + c) & 1;
+            const int je = p0 ? j0 + CPT : j0 - 1;
+            if (lane == (p0 ? kWave - 1 : 0) && je >= 0 && je < g.pitch) edge_mid = xo[row_off(g, la, o) + je];
+        }
 #pragma unroll 2
         for (int l = la; l < lb; ++l) {
             if (l + 1 < g.local_rows) ld_vec<CPT>(xo + row_off(g, l + 1, o) + j0, dn);
             else zero_vec<CPT>(dn);
             const int y = g.y0 + l;
             const int p = (y + c) & 1;                 // own pixels sit at image x = 2j + p
-            const int js = p ? j0 + CPT : j0 - 1;      // the one neighbour outside [j0, j0+CPT)
             double side = 0.0;
-            if (js >= 0 && js < g.pitch) side = xo[row_off(g, l, o) + js];
+            if (SHFL) {
+                const int pn = p ^ 1;                  // parity of the next row
+                const int je = pn ? j0 + CPT : j0 - 1;
+                edge_dn = 0.0;
+                if (l + 1 < g.local_rows && lane == (pn ? kWave - 1 : 0) && je >= 0 && je < g.pitch)
+                    edge_dn = xo[row_off(g, l + 1, o) + je];
+                const double from_right = __shfl_down(mid[0], 1, kWave);
+                const double from_left = __shfl_up(mid[CPT - 1], 1, kWave);
+                side = p ? from_right : from_left;
+                if (lane == (p ? kWave - 1 : 0)) side = edge_mid;
+            } else {
+                const int js = p ? j0 + CPT : j0 - 1;  // the one neighbour outside [j0, j0+CPT)
+                if (js >= 0 && js < g.pitch) side = xo[row_off(g, l, o) + js];
+            }
             double bv[CPT], old[CPT], nv[CPT];
             const long own = row_off(g, l, c) + j0;
             ld_vec<CPT>(bc + own, bv);
@@ -196,6 +222,7 @@ k_half_sweep(const double *__restrict__ xr, double *__restrict__ xw, const doubl
                 up[k] = mid[k];
                 mid[k] = dn[k];
             }
+            edge_mid = edge_dn;
         }
     }
     if (L1) {
