@@ -13,7 +13,8 @@ from typing import Optional
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libccp_gs.so")
+# CCP_GS_LIB: developer override to A/B two builds of the library in one session
+LIB_PATH = os.environ.get("CCP_GS_LIB") or os.path.join(_HERE, "lib", "libccp_gs.so")
 
 CCP_OK = 0
 ORDER_LEXICOGRAPHIC = 0

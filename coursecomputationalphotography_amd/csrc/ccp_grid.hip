@@ -134,7 +134,7 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     const int waves = kBlock / kWave;
     dim3 grid((unsigned)((P.n_strips + waves - 1) / waves), (unsigned)((st_hi - st_lo + P.rows_per_chunk - 1) / P.rows_per_chunk),
               (unsigned)g->desc.channels);
-    hipLaunchKernelGGL((k_fused_sweep<T, false>), grid, dim3(kBlock), 0, g->stream, P);
+    hipLaunchKernelGGL((k_fused_sweep<T, false, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
     CCP_HIP(hipGetLastError());
     g->last_launches++;
     return CCP_OK;
@@ -154,6 +154,10 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout)
         case 2: CCP_TRY(launch_fused_t<2>(g, xin, xout, st_lo, st_hi)); break;
         case 3: CCP_TRY(launch_fused_t<3>(g, xin, xout, st_lo, st_hi)); break;
         case 4: CCP_TRY(launch_fused_t<4>(g, xin, xout, st_lo, st_hi)); break;
+        case 5: CCP_TRY(launch_fused_t<5>(g, xin, xout, st_lo, st_hi)); break;
+        case 6: CCP_TRY(launch_fused_t<6>(g, xin, xout, st_lo, st_hi)); break;
+        case 7: CCP_TRY(launch_fused_t<7>(g, xin, xout, st_lo, st_hi)); break;
+        case 8: CCP_TRY(launch_fused_t<8>(g, xin, xout, st_lo, st_hi)); break;
         default: return CCP_ERR_BAD_ARG;
         }
     }

@@ -34,26 +34,37 @@
 
 namespace ccp {
 
-constexpr int kFusedMaxT = 4;
-constexpr int kFusedD = 2;               // rows loaded ahead of the newest row
+constexpr int kFusedMaxT = 8;
+constexpr int kFusedUnroll = 4;          // march steps unrolled per loop trip (shifted window)
+// rows loaded ahead of the newest row: enough bytes in flight per CU at the occupancy the
+// register window of T allows (T<=5: 3 waves/SIMD, T>=6: 2 waves/SIMD)
+#ifndef CCP_FUSED_D_LO
+#define CCP_FUSED_D_LO 2
+#endif
+#ifndef CCP_FUSED_D_HI
+#define CCP_FUSED_D_HI 4
+#endif
+__host__ __device__ constexpr int fused_prefetch(int T) { return T <= 5 ? CCP_FUSED_D_LO : CCP_FUSED_D_HI; }
 constexpr int kStripLanes = kWave;       // half-columns per strip
 
 __host__ __device__ constexpr int fused_halo_px(int T) { return 2 * T; }               // per side
 __host__ __device__ constexpr int fused_useful_px(int T) { return 2 * kStripLanes - 4 * T; }
 
-// lane i <- lane i-1 (lane 0 keeps its own value) / lane i <- lane i+1 (lane 63 keeps its own)
+// lane i <- lane i-1 (lane 0 gets 0) / lane i <- lane i+1 (lane 63 gets 0): the strip-edge lanes
+// have no neighbour inside the wave; their pixels are halo (never stored) or image-edge pixels
+// whose stencil has no such neighbour.
 __device__ __forceinline__ double lane_prev(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138, 0xf, 0xf, false);   // wave_shr:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x138, 0xf, 0xf, true);   // wave_shr:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double lane_next(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130, 0xf, 0xf, false);   // wave_shl:1
-    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x130, 0xf, 0xf, true);   // wave_shl:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 
@@ -68,54 +79,75 @@ struct FusedParams {
     double *__restrict__ partial;   // L1: one double per block
 };
 
+// How the row window maps onto registers.  G march steps are unrolled per loop trip.
+//   G == N (UNR = 0): the window rotates by renaming, slot = (step - distance) mod N, no copies,
+//       but the code grows as N*2T row updates (T=5: 74 KB, T=8: 177 KB — past the instruction
+//       cache: T=8 measured 3.0 ms per pass against 2.0 ms for the shifted form).  Kept for
+//       reference; the library instantiates UNR = kFusedUnroll only.
+//   G == UNR (> 0)  : slot = 2T+1 + step - distance inside a trip, then the whole window is
+//       shifted down by UNR slots ((2T+D+1)*4/UNR register moves per step); code ~ UNR*2T updates.
+template <int T, int UNR>
+struct FusedWindow {
+    static constexpr int HS = 2 * T;
+    static constexpr int D = fused_prefetch(T);
+    static constexpr int NFULL = HS + 2 + D;
+    static constexpr int G = UNR > 0 ? UNR : NFULL;
+    static constexpr int NT = UNR > 0 ? HS + D + UNR + 1 : NFULL;
+    static_assert(G % 2 == 0 && D % 2 == 0, "row parity must be a compile-time constant per unrolled step");
+    // slot of the row at `dist` rows behind the newest row of unrolled step i (dist in [-D, HS+1])
+    __host__ __device__ static constexpr int slot(int i, int dist)
+    {
+        return UNR > 0 ? (HS + 1 + i - dist) : ((i - D - dist) % NFULL + 2 * NFULL) % NFULL;
+    }
+};
+
 // One wave: strip `sx`, rows [ra, rb) of channel data at xin/xout/b (already channel-offset).
-template <int T, bool BORDER, bool L1>
+template <int T, bool BORDER, bool L1, int UNR>
 __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, double *__restrict__ xout,
                                              const double *__restrict__ bb, const Geom &g, int sx,
                                              int ra, int rb)
 {
-    constexpr int HS = 2 * T;
-    constexpr int D = kFusedD;
-    constexpr int N = HS + 2 + D;
-    static_assert(N % 2 == 0, "window must hold an even number of rows (parity bookkeeping)");
-    const int lane = threadIdx.x & (kWave - 1);
+    using Win = FusedWindow<T, UNR>;
+    constexpr int HS = Win::HS, D = Win::D, G = Win::G, NT = Win::NT;
+    const unsigned lane = threadIdx.x & (kWave - 1);
     const int U = fused_useful_px(T);
     const int px0 = sx * U - fused_halo_px(T);          // first pixel column of the strip (even)
-    const int j = px0 / 2 + lane;                       // this lane's half-column (may be < 0)
+    const int jbase = px0 / 2;                          // wave-uniform (sx is): row pointers stay scalar
+    const int j = jbase + (int)lane;                    // this lane's half-column (may be < 0)
     const bool col_ok = (j >= 0) && (j < g.pitch);
     const int ux0 = sx * U, ux1 = ux0 + U;              // pixel columns this strip stores
     const bool col_store = col_ok && (2 * j >= ux0) && (2 * j + 1 < ux1);
 
     const int m0 = max(ra - HS, 0);                     // rows this wave loads: [m0, m1)
     const int m1 = min(rb + HS, g.local_rows);
-    // window slot of row r is (r - base) mod N with (y0 + base) even, so the colour parity of a
-    // slot is a compile-time constant inside the unrolled march
+    // the march starts on an even image row (y0 + base even) and advances G (even) rows per
+    // trip, so the colour parity of every unrolled row update is a compile-time constant
     const int base = m0 - ((g.y0 + m0) & 1);
     const int f_end = rb - 1 + HS;                      // last step: row rb-1 gets half-sweep HS
 
-    double wr[N], wk[N], br[N], bk[N];                  // x red/black, b red/black per window row
+    double wr[NT], wk[NT], br[NT], bk[NT];              // x red/black, b red/black per window row
 #pragma unroll
-    for (int s = 0; s < N; ++s) wr[s] = wk[s] = br[s] = bk[s] = 0.0;
+    for (int s = 0; s < NT; ++s) wr[s] = wk[s] = br[s] = bk[s] = 0.0;
     double acc = 0.0;
 
-    for (int fb = base - D; fb <= f_end; fb += N) {
+    for (int fb = base - D; fb <= f_end; fb += G) {
 #pragma unroll
-        for (int i = 0; i < N; ++i) {
+        for (int i = 0; i < G; ++i) {
             const int f = fb + i;                       // newest row of this step
-            const int u = (i - D + N) % N;              // slot of row f (compile-time after unroll)
             if (f <= f_end) {
                 // ---- load row q = f + D into its slot -----------------------------------------
                 {
                     const int q = f + D;
-                    const int sq = (u + D) % N;
+                    const int sq = Win::slot(i, -D);
                     if (q >= m0 && q < m1) {
                         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
                         if (col_ok) {
-                            const long o0 = row_off(g, q, 0) + j, o1 = row_off(g, q, 1) + j;
-                            a0 = xin[o0];
-                            a1 = xin[o1];
-                            a2 = bb[o0];
-                            a3 = bb[o1];
+                            // uniform row base + lane index
+                            const long o0 = row_off(g, q, 0) + jbase, o1 = row_off(g, q, 1) + jbase;
+                            a0 = (xin + o0)[lane];
+                            a1 = (xin + o1)[lane];
+                            a2 = (bb + o0)[lane];
+                            a3 = (bb + o1)[lane];
                         }
                         wr[sq] = a0; wk[sq] = a1; br[sq] = a2; bk[sq] = a3;
                     }
@@ -124,10 +156,9 @@ __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, dou
 #pragma unroll
                 for (int h = 1; h <= HS; ++h) {
                     const int r = f - h;
-                    const int sr = (u - h + 2 * N) % N;
-                    const int su = (sr - 1 + N) % N, sd = (sr + 1) % N;
+                    const int sr = Win::slot(i, h), su = Win::slot(i, h + 1), sd = Win::slot(i, h - 1);
                     const int c = (h - 1) & 1;                       // 0 = red, 1 = black
-                    const int p = ((u - h + 2 * N) + c) & 1;         // pixel column = 2j + p
+                    const int p = ((i - h + 2 * HS + 2) + c) & 1;    // pixel column = 2j + p
                     if (r >= m0 && r < m1) {
                         // opposite colour: rows r-1, r, r+1
                         const double up = c ? wr[su] : wk[su];
@@ -160,12 +191,18 @@ __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, dou
                 // ---- row f - HS is final: store it -------------------------------------------
                 {
                     const int r = f - HS;
-                    const int sr = (u - HS + 2 * N) % N;
+                    const int sr = Win::slot(i, HS);
                     if (r >= ra && r < rb && col_store) {
-                        xout[row_off(g, r, 0) + j] = wr[sr];
-                        xout[row_off(g, r, 1) + j] = wk[sr];
+                        (xout + (row_off(g, r, 0) + jbase))[lane] = wr[sr];
+                        (xout + (row_off(g, r, 1) + jbase))[lane] = wk[sr];
                     }
                 }
+            }
+        }
+        if (UNR > 0) {
+#pragma unroll
+            for (int s = 0; s + G < NT; ++s) {
+                wr[s] = wr[s + G]; wk[s] = wk[s + G]; br[s] = br[s + G]; bk[s] = bk[s + G];
             }
         }
     }
@@ -173,13 +210,17 @@ __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, dou
 }
 
 // grid = (ceil(n_strips / 4), n_chunks, channels); block = 256 threads = 4 waves = 4 adjacent
-// strips of one chunk.
-template <int T, bool L1>
+// strips of one chunk.  Each wave picks one of two bodies: the branch-free one when all its
+// pixels have four neighbours, the border-aware one when it touches an image edge or the stale
+// edge of a ghost zone.  (Two separate launches were tried: the border launch ran alone at low
+// occupancy and cost +0.25 ms per pass at 16384^2.)
+template <int T, bool L1, int UNR>
 __global__ void __launch_bounds__(kBlock)
 k_fused_sweep(FusedParams P)
 {
     __shared__ double scratch[kBlock / kWave];
-    const int wave = threadIdx.x / kWave;
+    // readfirstlane: tell the compiler the wave index is uniform, so strip/row addressing is SALU
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int sx = blockIdx.x * (kBlock / kWave) + wave;
     const int ch = blockIdx.z;
     const int ra = P.st_lo + blockIdx.y * P.rows_per_chunk;
@@ -196,8 +237,8 @@ k_fused_sweep(FusedParams P)
         const int px1 = px0 + 2 * kStripLanes;                      // exclusive
         const bool border = (px0 <= 0) || (px1 >= g.W - 1) || (ra - HS <= 0) || (rb + HS >= g.local_rows) ||
                             (g.y0 + ra - HS <= 0) || (g.y0 + rb + HS >= g.H - 1);
-        if (border) acc = fused_wave<T, true, L1>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb);
-        else acc = fused_wave<T, false, L1>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb);
+        if (border) acc = fused_wave<T, true, L1, UNR>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb);
+        else acc = fused_wave<T, false, L1, UNR>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb);
     }
     if (L1) {
         const double total = block_sum(acc, scratch);
