@@ -1,0 +1,96 @@
+"""The C++ facade include/ccp/sparse-matrix.h (the reference's SparseMatrix surface on top of the
+C ABI), driven through tests/cpp/facade_driver.cpp — a host-only g++ program that mirrors the
+reference's own test flow (labs/lab3/src/OpenCVHW1/main6.cc:192-253)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+CPP = os.path.join(ROOT, "tests", "cpp")
+EXE = os.path.join(CPP, "facade_driver")
+
+
+@pytest.fixture(scope="module")
+def driver():
+    subprocess.check_call(["make", "-C", CPP], stdout=subprocess.DEVNULL)
+    return EXE
+
+
+def test_host_side_insert_and_ingest_semantics(driver):
+    """Five insert cases of main6.cc:193-231 + 400 seeded inserts against a dense mirror."""
+    out = subprocess.run([driver, "host"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert "host OK" in out.stdout
+
+
+def test_solver_without_device_throws_not_falls_back(driver):
+    from coursecomputationalphotography_amd import capi
+    if capi.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    out = subprocess.run([driver, "known"], capture_output=True, text=True)
+    assert out.returncode == 70 and "no usable HIP device" in out.stderr
+
+
+@pytest.mark.gpu
+def test_known_answer_flow_on_gpu(driver, golden):
+    d = golden("known_answer_4x4.npz")
+    out = subprocess.run([driver, "known"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    lines = out.stdout.strip().splitlines()
+    tok = lines[0].split()
+    x = np.array([float(t) for t in tok[2:6]])
+    assert np.array_equal(x, d["gs_final"]) and int(tok[-1]) == 8      # bit-exact, stops at k=8
+    ax = np.array([float(t) for t in lines[1].split()[1:5]])
+    assert np.array_equal(ax, d["A"] @ d["gs_final"]) or np.allclose(ax, d["b"], atol=1e-6)
+    fast = np.array([float(t) for t in lines[2].split()[1:5]])
+    assert np.allclose(fast, [1, 2, -1, 1], atol=1e-8)
+
+
+def run_gs(driver, tmp_path, values, cols, rowp, b, eps, max_it, ordering, colour=None):
+    n, nnz = len(rowp) - 1, len(values)
+    fin, fout = tmp_path / "in.bin", tmp_path / "out.bin"
+    with open(fin, "wb") as f:
+        f.write(struct.pack("<5i", n, nnz, max_it, ordering, 0 if colour is None else 1))
+        f.write(struct.pack("<d", eps))
+        f.write(np.ascontiguousarray(values, dtype="<f8").tobytes())
+        f.write(np.ascontiguousarray(cols, dtype="<i4").tobytes())
+        f.write(np.ascontiguousarray(rowp, dtype="<i4").tobytes())
+        f.write(np.ascontiguousarray(b, dtype="<f8").tobytes())
+        if colour is not None:
+            f.write(np.ascontiguousarray(colour, dtype="<i4").tobytes())
+    out = subprocess.run([driver, "gs", str(fin), str(fout)], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    raw = open(fout, "rb").read()
+    it = struct.unpack_from("<i", raw, 0)[0]
+    rel = struct.unpack_from("<d", raw, 4)[0]
+    x = np.frombuffer(raw, dtype="<f8", count=n, offset=12)
+    ax = np.frombuffer(raw, dtype="<f8", count=n, offset=12 + 8 * n)
+    return it, rel, x, ax
+
+
+@pytest.mark.gpu
+def test_facade_poisson_both_orderings(driver, golden, orc, tmp_path):
+    import oracle
+    from coursecomputationalphotography_amd import synth
+    d = golden("poisson_17x13.npz")
+    W, H = 17, 13
+    v, c, r = synth.poisson_csr(W, H)
+    it, rel, x, ax = run_gs(driver, tmp_path, v, c, r, d["b"], 0.0, 10, 0)
+    assert it == 10 and np.array_equal(x, d["x_lex_k10"])
+    m = orc.from_csr(v, c, r)
+    assert np.array_equal(ax, m.apply_to_vector(d["x_lex_k10"]))
+    assert abs(rel - m.rel_residual(d["b"], d["x_lex_k10"])) <= 1e-12
+    it, rel, x, ax = run_gs(driver, tmp_path, v, c, r, d["b"], 0.0, 50, 1, oracle.grid_colour(W, H))
+    assert np.array_equal(x, d["x_rb_k50"])
+
+
+@pytest.mark.gpu
+def test_facade_mask_fixture(driver, golden, tmp_path):
+    d = golden("mask_61x47.npz")
+    it, rel, x, ax = run_gs(driver, tmp_path, d["values"], d["cols"], d["row_offset"], d["b"], 0.0, 10, 1, d["colour"])
+    assert np.array_equal(x, d["x_rb_k10"])
+    it, rel, x, ax = run_gs(driver, tmp_path, d["values"], d["cols"], d["row_offset"], d["b"], 0.0, 10, 0)
+    assert np.array_equal(x, d["x_lex_k10"])
