@@ -118,7 +118,7 @@ int one_iteration(ccp_grid *g, bool l1, const int *active, long *blocks_out)
 }
 
 template <int T>
-int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi)
+int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi, const int *active)
 {
     FusedParams P;
     P.xin = xin;
@@ -131,6 +131,7 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     const int U = fused_useful_px(T);
     P.n_strips = (g->geom.W + U - 1) / U;
     P.partial = g->partial.p;
+    P.active = active;
     const int waves = kBlock / kWave;
     dim3 grid((unsigned)((P.n_strips + waves - 1) / waves), (unsigned)((st_hi - st_lo + P.rows_per_chunk - 1) / P.rows_per_chunk),
               (unsigned)g->desc.channels);
@@ -141,7 +142,7 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
 }
 
 // T fused iterations xin -> xout, with the ghost bookkeeping of 2T half-sweeps.
-int launch_fused(ccp_grid *g, int T, const double *xin, double *xout)
+int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int *active)
 {
     const bool shrinking = g->shrink_top || g->shrink_bottom;
     const int s = g->half_sweeps_since_refresh;
@@ -150,14 +151,14 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout)
     const int st_hi = g->geom.local_rows - (g->shrink_bottom ? std::min(s + 2 * T, g->ghost_bottom) : 0);
     if (st_hi > st_lo) {
         switch (T) {
-        case 1: CCP_TRY(launch_fused_t<1>(g, xin, xout, st_lo, st_hi)); break;
-        case 2: CCP_TRY(launch_fused_t<2>(g, xin, xout, st_lo, st_hi)); break;
-        case 3: CCP_TRY(launch_fused_t<3>(g, xin, xout, st_lo, st_hi)); break;
-        case 4: CCP_TRY(launch_fused_t<4>(g, xin, xout, st_lo, st_hi)); break;
-        case 5: CCP_TRY(launch_fused_t<5>(g, xin, xout, st_lo, st_hi)); break;
-        case 6: CCP_TRY(launch_fused_t<6>(g, xin, xout, st_lo, st_hi)); break;
-        case 7: CCP_TRY(launch_fused_t<7>(g, xin, xout, st_lo, st_hi)); break;
-        case 8: CCP_TRY(launch_fused_t<8>(g, xin, xout, st_lo, st_hi)); break;
+        case 1: CCP_TRY(launch_fused_t<1>(g, xin, xout, st_lo, st_hi, active)); break;
+        case 2: CCP_TRY(launch_fused_t<2>(g, xin, xout, st_lo, st_hi, active)); break;
+        case 3: CCP_TRY(launch_fused_t<3>(g, xin, xout, st_lo, st_hi, active)); break;
+        case 4: CCP_TRY(launch_fused_t<4>(g, xin, xout, st_lo, st_hi, active)); break;
+        case 5: CCP_TRY(launch_fused_t<5>(g, xin, xout, st_lo, st_hi, active)); break;
+        case 6: CCP_TRY(launch_fused_t<6>(g, xin, xout, st_lo, st_hi, active)); break;
+        case 7: CCP_TRY(launch_fused_t<7>(g, xin, xout, st_lo, st_hi, active)); break;
+        case 8: CCP_TRY(launch_fused_t<8>(g, xin, xout, st_lo, st_hi, active)); break;
         default: return CCP_ERR_BAD_ARG;
         }
     }
@@ -167,10 +168,10 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout)
 
 // `iterations` unchecked sweeps: an even number of fused launches (so the result lands back
 // in g->x), a lone leftover iteration through the in-place half-sweep kernels.
-int run_unchecked(ccp_grid *g, int iterations)
+int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr)
 {
     if (!g->fuse || iterations < 2) {
-        for (int k = 0; k < iterations; ++k) CCP_TRY(one_iteration(g, false, nullptr, nullptr));
+        for (int k = 0; k < iterations; ++k) CCP_TRY(one_iteration(g, false, active, nullptr));
         return CCP_OK;
     }
     if (!g->x_alt.p) {
@@ -184,7 +185,7 @@ int run_unchecked(ccp_grid *g, int iterations)
     double *cur = g->x.p, *alt = g->x_alt.p;
     for (int k = 0; k < launches; ++k) {
         const int T = base_t + (k < extra ? 1 : 0);
-        CCP_TRY(launch_fused(g, T, cur, alt));
+        CCP_TRY(launch_fused(g, T, cur, alt, active));
         std::swap(cur, alt);
     }
     return CCP_OK;
@@ -440,29 +441,37 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
     // `while (eps > epsilon && cnt < max_iteration)`: eps starts at 10
     const bool enter = (10.0 > epsilon);
     bool any_active = enter && max_iteration > 0;
+    const int *active = reinterpret_cast<const int *>(g->state.p);
+    if (any_active && check_every == 0) {
+        // fixed count, no stop test: the temporally blocked sweep
+        CCP_TRY(run_unchecked(g, max_iteration, nullptr));
+        issued = max_iteration;
+        any_active = false;
+    }
     const int batch_checks = 8;             // checked sweeps enqueued between two host polls
     while (any_active && issued < max_iteration) {
         int checks = 0;
         while (issued < max_iteration && checks < batch_checks) {
-            const int k = issued + 1;
-            const bool check = check_every > 0 && (k % check_every == 0);
-            long blocks[2] = {0, 0};
-            CCP_TRY(one_iteration(g, check, reinterpret_cast<const int *>(g->state.p), blocks));
-            if (check) {
-                hipLaunchKernelGGL(k_check, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
-                                   g->partial.p + g->partial_region, blocks[1], epsilon, k, g->state.p,
-                                   static_cast<double *>(nullptr));
-                CCP_HIP(hipGetLastError());
-                ++checks;
+            // check_every-1 unchecked sweeps (fused), then one sweep that accumulates the L1 step
+            const int plain = std::min(check_every - 1, max_iteration - issued);
+            if (plain > 0) {
+                CCP_TRY(run_unchecked(g, plain, active));
+                issued += plain;
             }
+            if (issued >= max_iteration) break;
+            long blocks[2] = {0, 0};
+            CCP_TRY(one_iteration(g, true, active, blocks));
             ++issued;
+            hipLaunchKernelGGL(k_check, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
+                               g->partial.p + g->partial_region, blocks[1], epsilon, issued, g->state.p,
+                               static_cast<double *>(nullptr));
+            CCP_HIP(hipGetLastError());
+            ++checks;
         }
-        if (check_every > 0) {
-            CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));
-            CCP_HIP(hipStreamSynchronize(g->stream));
-            any_active = false;
-            for (int ch = 0; ch < C; ++ch) any_active |= host.active[ch] != 0;
-        }
+        CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));
+        CCP_HIP(hipStreamSynchronize(g->stream));
+        any_active = false;
+        for (int ch = 0; ch < C; ++ch) any_active |= host.active[ch] != 0;
     }
     end_timing(g);
     CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));

@@ -77,6 +77,7 @@ struct FusedParams {
     int rows_per_chunk;
     int n_strips;
     double *__restrict__ partial;   // L1: one double per block
+    const int *__restrict__ active; // nullable: per-channel "still iterating" flags (device)
 };
 
 // How the row window maps onto registers.  G march steps are unrolled per loop trip.
@@ -226,7 +227,8 @@ k_fused_sweep(FusedParams P)
     const int ra = P.st_lo + blockIdx.y * P.rows_per_chunk;
     const int rb = min(ra + P.rows_per_chunk, P.st_hi);
     double acc = 0.0;
-    if (sx < P.n_strips && ra < rb) {
+    const bool run = (P.active == nullptr) || (P.active[ch] != 0);   // a converged channel is frozen
+    if (run && sx < P.n_strips && ra < rb) {
         const Geom &g = P.g;
         const long off = (long)ch * g.ch_stride;
         constexpr int HS = 2 * T;
