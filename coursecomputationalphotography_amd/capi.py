@@ -60,11 +60,34 @@ class GridLayout(C.Structure):
 _lib: Optional[C.CDLL] = None
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm bundles its own libamdhip64.so.7 (same soname as /opt/rocm's).  Whichever
+    copy is loaded first serves the whole process; if ours pulled in /opt/rocm's first, a later
+    `import torch` would run on a runtime it was not built for and report no GPU.  So when torch
+    is installed but not imported yet, load ITS runtime first (no torch import, no GPU init)."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("CCP_GS_NO_TORCH_HIP"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
+
+
 def load() -> C.CDLL:
     """dlopen libccp_gs.so; raises FileNotFoundError when it has not been built."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(
             f"{LIB_PATH} is missing: build it with `make -C coursecomputationalphotography_amd/csrc` "

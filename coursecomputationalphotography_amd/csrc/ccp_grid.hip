@@ -383,8 +383,12 @@ int ccp_grid_b_from_x(ccp_grid *g)
     CCP_TRY(bind(g));
     if ((g->shrink_top || g->shrink_bottom) && g->half_sweeps_since_refresh >= g->desc.ghost) return CCP_ERR_STATE;
     const Geom &geo = g->geom;
-    dim3 grid((unsigned)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)), (unsigned)(geo.own_hi - geo.own_lo), (unsigned)g->desc.channels * 2);
-    hipLaunchKernelGGL((k_apply<2, 0>), grid, dim3(kBlock), 0, g->stream, g->x.p, g->b.p, g->b.p, geo, geo.own_lo, g->partial.p);
+    // every local row whose neighbour rows are local too: the ghost rows need their b as well
+    // (they are recomputed between halo exchanges); only the outermost ghost row cannot get one
+    const int l_lo = g->shrink_top ? 1 : 0;
+    const int l_hi = geo.local_rows - (g->shrink_bottom ? 1 : 0);
+    dim3 grid((unsigned)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)), (unsigned)(l_hi - l_lo), (unsigned)g->desc.channels * 2);
+    hipLaunchKernelGGL((k_apply<2, 0>), grid, dim3(kBlock), 0, g->stream, g->x.p, g->b.p, g->b.p, geo, l_lo, g->partial.p);
     CCP_HIP(hipGetLastError());
     return CCP_OK;
 }

@@ -155,8 +155,9 @@ int ccp_grid_get_x_host(ccp_grid *g, int32_t channel, double *rows, int32_t firs
 int ccp_grid_get_b_host(ccp_grid *g, int32_t channel, double *rows, int32_t first_row, int32_t n_rows);
 /* x := value everywhere (the reference start vector is 1.0, sparse-matrix.h:352). Async. */
 int ccp_grid_fill_x(ccp_grid *g, double value);
-/* b := A x (applyToVector order, sparse-matrix.h:382-393) on the owned rows; needs valid
- * ghost rows of x when the block has neighbours.  Used to build b = A x_true on device. Async. */
+/* b := A x (applyToVector order, sparse-matrix.h:382-393) on every local row whose neighbour
+ * rows are local too (owned rows and all ghost rows but the outermost one, whose b is never
+ * used); needs valid ghost rows of x.  Used to build b = A x_true on device. Async. */
 int ccp_grid_b_from_x(ccp_grid *g);
 /* x := uniform [lo,hi) pseudo-random field depending only on (seed, channel, image x, y):
  * identical across any row partition.  Fills owned + ghost rows.  Async. */

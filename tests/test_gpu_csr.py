@@ -131,3 +131,18 @@ def test_random_sparse_vs_oracle(capi, orc, seed):
     assert repm.converged == 1 and rel_l2(xm, want) < 1e-8
     assert np.array_equal(m.apply_to_vector(b), om.apply_to_vector(b))
     m.close()
+
+
+def test_config0_512x512_lexicographic_bit_exact(capi, orc):
+    """BASELINE.json configs[0]: 512x512 single-channel Poisson, the reference's own (lexicographic)
+    gaussSeidel — reproduced bit for bit on the GPU by level scheduling (1023 levels)."""
+    from coursecomputationalphotography_amd import synth
+    W = H = 512
+    v, c, r = synth.poisson_csr(W, H)
+    b, _ = synth.poisson_system(W, H, 1234)
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    x, rep = m.gauss_seidel(b, 0.0, 20, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+    want, _, _ = orc.from_csr(v, c, r).gauss_seidel(b, 0.0, 20)
+    assert rep.iterations == 20 and np.array_equal(x, want)
+    assert x[-1] == 1.0
+    m.close()

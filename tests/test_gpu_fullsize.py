@@ -1,0 +1,277 @@
+"""GPU, BASELINE.json full sizes: size-independent properties where the oracle cannot run.
+
+ * the temporally blocked sweep (k_fused_sweep) and the in-place half-sweep kernels are two
+   independent implementations: their results must agree bit for bit (checksum of checksums);
+ * a row-blocked run with ghost exchange equals the single-block run bit for bit;
+ * the solve is affine in (b, x0): GS_k(b1+b2, x1+x2) == GS_k(b1,x1) + GS_k(b2,x2) up to rounding;
+ * x_true is a fixed point: starting from it the residual stays at rounding level;
+ * mid-size systems against the oracle with every fused depth T = 1..8.
+"""
+import os
+import threading
+import queue
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from coursecomputationalphotography_amd import capi
+    assert capi.device_count() >= 1
+    return capi
+
+
+def make(capi, W, H, C=1, seed=1234, **kw):
+    g = capi.Grid(W, H, C, **kw)
+    g.randomize_x(seed, 0.0, 255.0)
+    g.b_from_x()
+    g.fill_x(1.0)
+    return g
+
+
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 5, 6, 7, 8])
+def test_every_fused_depth_matches_oracle(capi, orc, T, monkeypatch):
+    """One launch pair of depth T on a grid with several strips and chunks, odd sizes."""
+    import oracle
+    from coursecomputationalphotography_amd import synth
+    W, H = 391, 301
+    b, _ = synth.poisson_system(W, H, 17)
+    v, c, r = synth.poisson_csr(W, H)
+    monkeypatch.setenv("CCP_GS_TMAX", str(T))
+    monkeypatch.setenv("CCP_GS_CHUNK", "57")
+    g = capi.Grid(W, H, 1)
+    g.set_b(b)
+    g.fill_x(1.0)
+    g.sweep(2 * T)
+    want, _, _ = orc.multicolour_gauss_seidel(v, c, r, oracle.grid_colour(W, H), b, 0.0, 2 * T)
+    assert np.array_equal(g.get_x().ravel(), want)
+    g.close()
+
+
+def test_fused_equals_in_place_kernel_16384(capi, monkeypatch):
+    """configs[2]: 16384x16384 single channel.  40 iterations by each implementation."""
+    W = H = 16384
+    g = make(capi, W, H)
+    g.sweep(40)
+    s_fused = g.abs_sum()[0]
+    rr_f, bb_f = g.residual_norm2()
+    x_rows_f = g.get_x(0, 8000, 8)                 # a band of rows, compared element-wise
+    top_f, bot_f = g.get_x(0, 0, 4), g.get_x(0, H - 4, 4)
+    g.close()
+    monkeypatch.setenv("CCP_GS_FUSE", "0")
+    g = make(capi, W, H)
+    g.sweep(40)
+    assert g.abs_sum()[0] == s_fused
+    rr, bb = g.residual_norm2()
+    assert rr[0] == rr_f[0] and bb[0] == bb_f[0]
+    assert np.array_equal(g.get_x(0, 8000, 8), x_rows_f)
+    assert np.array_equal(g.get_x(0, 0, 4), top_f) and np.array_equal(g.get_x(0, H - 4, 4), bot_f)
+    assert g.get_x(0, H - 1, 1)[0, -1] == 1.0      # the empty row of pixel (W-1,H-1) never moves
+    g.close()
+
+
+def test_three_channel_4096_fused_equals_in_place(capi, monkeypatch):
+    """configs[1]: 4096x4096 three-channel blend."""
+    W = H = 4096
+    g = make(capi, W, H, 3)
+    g.sweep(24)
+    sums = g.abs_sum().copy()
+    rows = [g.get_x(ch, 2000, 4) for ch in range(3)]
+    g.close()
+    monkeypatch.setenv("CCP_GS_FUSE", "0")
+    g = make(capi, W, H, 3)
+    g.sweep(24)
+    assert np.array_equal(g.abs_sum(), sums)
+    for ch in range(3):
+        assert np.array_equal(g.get_x(ch, 2000, 4), rows[ch])
+    assert len(set(sums.tolist())) == 3            # channels differ (per-channel RHS)
+    g.close()
+
+
+def test_affine_in_b_and_x0(capi):
+    from coursecomputationalphotography_amd import synth
+    W, H, k = 1500, 700, 16
+    gen = synth.rng(5)
+    b1, b2 = gen.uniform(-100, 100, (H, W)), gen.uniform(-100, 100, (H, W))
+    x1, x2 = gen.uniform(0, 50, (H, W)), gen.uniform(0, 50, (H, W))
+    outs = []
+    for b, x0 in ((b1, x1), (b2, x2), (b1 + b2, x1 + x2)):
+        g = capi.Grid(W, H, 1)
+        g.set_b(b); g.set_x(x0)
+        g.sweep(k)
+        outs.append(g.get_x())
+        g.close()
+    # pixel (W-1,H-1) is skipped (empty row): it keeps x0, which is additive as well
+    err = np.abs(outs[2] - (outs[0] + outs[1])).max() / np.abs(outs[2]).max()
+    assert err < 1e-13
+
+
+def test_exact_solution_is_a_fixed_point(capi):
+    W = H = 8192
+    g = capi.Grid(W, H, 1)
+    g.randomize_x(99, 0.0, 255.0)
+    g.b_from_x()                                    # b = A x_true, x still holds x_true
+    before = g.abs_sum()[0]
+    g.sweep(16)
+    rr, bb = g.residual_norm2()
+    assert np.sqrt(rr[0] / bb[0]) < 1e-13
+    assert abs(g.abs_sum()[0] - before) <= 1e-12 * before
+    g.close()
+
+
+class ThreadDist:
+    """Single-process stand-in for torch.distributed (one thread per rank) so the real GridBlock
+    device views and RowBlockSolver run on ONE GPU: mailboxes for point-to-point, a barrier
+    reduction for all_reduce.  RCCL itself needs one GPU per rank and is exercised by the driver's
+    multi-GPU bench."""
+
+    class ReduceOp:
+        SUM = "sum"
+
+    class _Req:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def wait(self):
+            self.fn()
+
+    class P2POp:
+        def __init__(self, op, tensor, peer, group=None):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    def __init__(self, world):
+        self.world = world
+        self.box = {(s, d): queue.Queue() for s in range(world) for d in range(world)}
+        self.bar = threading.Barrier(world)
+        self.red = [None] * world
+        self.local = threading.local()
+
+    def bind(self, rank):
+        self.local.rank = rank
+
+    isend, irecv = "isend", "irecv"
+
+    def batch_isend_irecv(self, ops):
+        import torch
+        me = self.local.rank
+        reqs = []
+        for op in ops:
+            if op.op == "isend":
+                self.box[(me, op.peer)].put(op.tensor.clone())
+                reqs.append(self._Req(lambda: None))
+            else:
+                def recv(t=op.tensor, src=op.peer):
+                    t.copy_(self.box[(src, me)].get(timeout=60))
+                reqs.append(self._Req(recv))
+        torch.cuda.synchronize()
+        return reqs
+
+    def get_backend(self, group=None):
+        return "thread"
+
+    def all_reduce(self, t, op=None, group=None):
+        me = self.local.rank
+        self.red[me] = t.clone()
+        self.bar.wait()
+        total = sum(self.red)
+        self.bar.wait()
+        t.copy_(total)
+
+
+@pytest.mark.parametrize("W,H,world,ghost,iters", [(4096, 4096, 3, 16, 40), (1000, 333, 4, 8, 21)])
+def test_row_blocked_gridblocks_equal_single_block(capi, W, H, world, ghost, iters):
+    import torch
+    from coursecomputationalphotography_amd import rowblock
+    whole = make(capi, W, H)
+    whole.sweep(iters)
+    want = whole.get_x()
+    rr_w, bb_w = whole.residual_norm2()
+    whole.close()
+    parts = rowblock.partition_rows(H, world)
+    dist = ThreadDist(world)
+    out, errs = [None] * world, []
+
+    def run(rank):
+        try:
+            dist.bind(rank)
+            rb, rc = parts[rank]
+            blk = rowblock.GridBlock(W, H, 1, rb, rc, ghost, 0)
+            blk.grid.randomize_x(1234, 0.0, 255.0)          # same field on every partition
+            blk.grid.b_from_x()
+            blk.grid.fill_x(1.0)
+            solver = rowblock.RowBlockSolver(blk, rank, world, ghost, dist).set_partition(parts, H)
+            solver.exchange_halos()
+            solver.sweep(iters)
+            res = solver.rel_residual()
+            out[rank] = (blk.grid.get_x_owned(), res)
+            blk.grid.close()
+        except Exception as e:                              # surface thread failures in the test
+            errs.append(e)
+            try:
+                dist.bar.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errs, errs
+    got = np.concatenate([o[0] for o in out])
+    assert np.array_equal(got, want)
+    assert abs(out[0][1][0] - np.sqrt(rr_w[0] / bb_w[0])) <= 1e-12
+
+
+def test_check_every_and_per_channel_freeze(capi, orc):
+    """Three channels with different scales converge at different checked sweeps; each channel's
+    x equals the oracle at its own stop iteration (a frozen channel is not touched again)."""
+    import oracle
+    from coursecomputationalphotography_amd import synth
+    W, H, every = 64, 64, 4
+    v, c, r = synth.poisson_csr(W, H)
+    col = oracle.grid_colour(W, H)
+    base = synth.poisson_system(W, H, 1234)[0]
+    scales = (1e-3, 3e-4, 1e-4)
+    g = capi.Grid(W, H, 3)
+    for ch, s in enumerate(scales):
+        g.set_b(base * s, ch)
+    g.fill_x(1.0)
+    eps = 0.5
+    reps = g.gauss_seidel(eps, 400, every)
+    its = [rep.iterations for rep in reps]
+    assert len(set(its)) > 1, its
+    for ch, s in enumerate(scales):
+        assert reps[ch].converged == 1 and its[ch] % every == 0
+        want, _, e = orc.multicolour_gauss_seidel(v, c, r, col, base * s, 0.0, its[ch])
+        assert np.array_equal(g.get_x(ch).ravel(), want), ch
+        assert e <= eps and abs(reps[ch].last_l1_step - e) <= 1e-10 * e
+        if its[ch] > every:                                  # the previous check had not fired
+            _, _, e_prev = orc.multicolour_gauss_seidel(v, c, r, col, base * s, 0.0, its[ch] - every)
+            assert e_prev > eps
+    g.close()
+
+
+def test_masked_csr_2048_canvas_vs_oracle(capi, orc):
+    """configs[4] shape at a 2048x2048 canvas (same generator, scaled radii): general CSR path,
+    red-black colouring, against the oracle; SpMV bit-exact."""
+    from coursecomputationalphotography_amd import synth
+    mask = synth.disc_mask(2048, 2048, seed=4321)
+    v, c, r, colour, ys, xs = synth.masked_laplacian_csr(mask)
+    n = len(ys)
+    assert n > 500_000
+    xt = synth.x_true(n, 4321)
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    b = m.apply_to_vector(xt)
+    assert np.array_equal(b, synth.csr_apply(v, c, r, xt))
+    m.set_colouring(colour, 2)
+    x, rep = m.gauss_seidel(b, 0.0, 5, check_every=0, ordering=capi.ORDER_MULTICOLOUR)
+    want, _, _ = orc.multicolour_gauss_seidel(v, c, r, colour, b, 0.0, 5)
+    assert np.array_equal(x, want)
+    rr, bb = m.residual_norm2(b, x)
+    om = orc.from_csr(v, c, r)
+    assert abs(np.sqrt(rr / bb) - om.rel_residual(b, x)) <= 1e-12
+    m.close()
