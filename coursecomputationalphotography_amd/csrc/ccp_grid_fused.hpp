@@ -42,7 +42,7 @@ constexpr int kFusedUnroll = 4;          // march steps unrolled per loop trip (
 #define CCP_FUSED_D_LO 2
 #endif
 #ifndef CCP_FUSED_D_HI
-#define CCP_FUSED_D_HI 4
+#define CCP_FUSED_D_HI 2
 #endif
 __host__ __device__ constexpr int fused_prefetch(int T) { return T <= 5 ? CCP_FUSED_D_LO : CCP_FUSED_D_HI; }
 constexpr int kStripLanes = kWave;       // half-columns per strip
@@ -102,6 +102,97 @@ struct FusedWindow {
     }
 };
 
+// Wave-uniform march parameters (SGPRs) and the few per-lane predicates of a strip.
+struct FusedCtx {
+    const double *__restrict__ xin;
+    double *__restrict__ xout;
+    const double *__restrict__ bb;
+    int jbase;          // half-column of lane 0 (may be negative in the first strip)
+    int j;              // this lane's half-column
+    unsigned lane;
+    bool col_ok;        // lane's half-column exists
+    bool col_store;     // lane's pixels belong to the columns this strip stores
+    int ra, rb;         // rows to finalise and store
+    int m0, m1;         // rows loaded
+};
+
+// One march step: newest row f, unrolled position i.  STEADY: every row the step touches is known
+// to be inside [m0, m1) and the finished row inside [ra, rb), so the step is straight-line code
+// (no scalar branches): the s_waitcnt pass can then count the loads in flight instead of
+// draining them, and that is what lets the D-rows-ahead prefetch actually overlap.
+template <int T, bool BORDER, bool L1, int UNR, bool STEADY, int NT>
+__device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], double (&br)[NT], double (&bk)[NT],
+                                           double &acc, const FusedCtx &cx, const Geom &g, int f, int i)
+{
+    using Win = FusedWindow<T, UNR>;
+    constexpr int HS = Win::HS, D = Win::D;
+    // ---- load row q = f + D into its slot ---------------------------------------------------
+    {
+        const int q = f + D;
+        const int sq = Win::slot(i, -D);
+        if (STEADY || (q >= cx.m0 && q < cx.m1)) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            if (!BORDER || cx.col_ok) {
+                // uniform row base + lane index
+                const long o0 = row_off(g, q, 0) + cx.jbase, o1 = row_off(g, q, 1) + cx.jbase;
+                a0 = (cx.xin + o0)[cx.lane];
+                a1 = (cx.xin + o1)[cx.lane];
+                a2 = (cx.bb + o0)[cx.lane];
+                a3 = (cx.bb + o1)[cx.lane];
+            }
+            wr[sq] = a0; wk[sq] = a1; br[sq] = a2; bk[sq] = a3;
+        }
+    }
+    // ---- half-sweep h on row f - h, h = 1..HS ----------------------------------------------
+#pragma unroll
+    for (int h = 1; h <= HS; ++h) {
+        const int r = f - h;
+        const int sr = Win::slot(i, h), su = Win::slot(i, h + 1), sd = Win::slot(i, h - 1);
+        const int c = (h - 1) & 1;                       // 0 = red, 1 = black
+        const int p = ((i - h + 2 * HS + 2) + c) & 1;    // pixel column = 2j + p
+        if (STEADY || (r >= cx.m0 && r < cx.m1)) {
+            // opposite colour: rows r-1, r, r+1
+            const double up = c ? wr[su] : wk[su];
+            const double dn = c ? wr[sd] : wk[sd];
+            const double same = c ? wr[sr] : wk[sr];
+            const double other = p ? lane_next(same) : lane_prev(same);
+            const double left = p ? same : other;
+            const double right = p ? other : same;
+            const double bv = c ? bk[sr] : br[sr];
+            const double old = c ? wk[sr] : wr[sr];
+            double nv = old;
+            if (!BORDER) {
+                nv = (bv + (((up + left) + right) + dn)) * 0.25;
+            } else {
+                const int x = 2 * cx.j + p;
+                if (cx.col_ok && x < g.W) {
+                    const Stencil s = classify(g, x, g.y0 + r, r);
+                    double t;
+                    if (gs_update(s, bv, up, left, right, dn, t)) nv = t;
+                }
+            }
+            if (L1 && h >= HS - 1) {
+                const bool counted = cx.col_store && r >= cx.ra && r < cx.rb && r >= g.own_lo && r < g.own_hi &&
+                                     (!BORDER || (2 * cx.j + p) < g.W);
+                if (counted) acc += fabs(nv - old);
+            }
+            if (c) wk[sr] = nv; else wr[sr] = nv;
+        }
+    }
+    // ---- row f - HS is final: store it -----------------------------------------------------
+    {
+        const int r = f - HS;
+        const int sr = Win::slot(i, HS);
+        if ((STEADY || (r >= cx.ra && r < cx.rb)) && cx.col_store) {
+            (cx.xout + (row_off(g, r, 0) + cx.jbase))[cx.lane] = wr[sr];
+            (cx.xout + (row_off(g, r, 1) + cx.jbase))[cx.lane] = wk[sr];
+        }
+    }
+    // keep the machine scheduler from pulling later steps' loads/updates up across this point:
+    // unconstrained it hoists all G steps' work together and spills the register window
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 // One wave: strip `sx`, rows [ra, rb) of channel data at xin/xout/b (already channel-offset).
 template <int T, bool BORDER, bool L1, int UNR>
 __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, double *__restrict__ xout,
@@ -110,21 +201,25 @@ __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, dou
 {
     using Win = FusedWindow<T, UNR>;
     constexpr int HS = Win::HS, D = Win::D, G = Win::G, NT = Win::NT;
-    const unsigned lane = threadIdx.x & (kWave - 1);
+    FusedCtx cx;
+    cx.xin = xin; cx.xout = xout; cx.bb = bb;
+    cx.lane = threadIdx.x & (kWave - 1);
     const int U = fused_useful_px(T);
     const int px0 = sx * U - fused_halo_px(T);          // first pixel column of the strip (even)
-    const int jbase = px0 / 2;                          // wave-uniform (sx is): row pointers stay scalar
-    const int j = jbase + (int)lane;                    // this lane's half-column (may be < 0)
-    const bool col_ok = (j >= 0) && (j < g.pitch);
+    cx.jbase = px0 / 2;                                 // wave-uniform (sx is): row pointers stay scalar
+    cx.j = cx.jbase + (int)cx.lane;                     // this lane's half-column (may be < 0)
+    cx.col_ok = (cx.j >= 0) && (cx.j < g.pitch);
     const int ux0 = sx * U, ux1 = ux0 + U;              // pixel columns this strip stores
-    const bool col_store = col_ok && (2 * j >= ux0) && (2 * j + 1 < ux1);
-
-    const int m0 = max(ra - HS, 0);                     // rows this wave loads: [m0, m1)
-    const int m1 = min(rb + HS, g.local_rows);
+    cx.col_store = cx.col_ok && (2 * cx.j >= ux0) && (2 * cx.j + 1 < ux1);
+    cx.ra = ra; cx.rb = rb;
+    cx.m0 = max(ra - HS, 0);                            // rows this wave loads: [m0, m1)
+    cx.m1 = min(rb + HS, g.local_rows);
     // the march starts on an even image row (y0 + base even) and advances G (even) rows per
     // trip, so the colour parity of every unrolled row update is a compile-time constant
-    const int base = m0 - ((g.y0 + m0) & 1);
+    const int base = cx.m0 - ((g.y0 + cx.m0) & 1);
     const int f_end = rb - 1 + HS;                      // last step: row rb-1 gets half-sweep HS
+    // steps f in [s_lo, s_hi] touch only existing rows and finish a row inside [ra, rb)
+    const int s_lo = max(ra + HS, cx.m0 + HS + 1), s_hi = min(cx.m1 - 1 - D, rb - 1 + HS);
 
     double wr[NT], wk[NT], br[NT], bk[NT];              // x red/black, b red/black per window row
 #pragma unroll
@@ -132,73 +227,15 @@ __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, dou
     double acc = 0.0;
 
     for (int fb = base - D; fb <= f_end; fb += G) {
+        if (fb >= s_lo && fb + G - 1 <= s_hi) {
 #pragma unroll
-        for (int i = 0; i < G; ++i) {
-            const int f = fb + i;                       // newest row of this step
-            if (f <= f_end) {
-                // ---- load row q = f + D into its slot -----------------------------------------
-                {
-                    const int q = f + D;
-                    const int sq = Win::slot(i, -D);
-                    if (q >= m0 && q < m1) {
-                        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-                        if (col_ok) {
-                            // uniform row base + lane index
-                            const long o0 = row_off(g, q, 0) + jbase, o1 = row_off(g, q, 1) + jbase;
-                            a0 = (xin + o0)[lane];
-                            a1 = (xin + o1)[lane];
-                            a2 = (bb + o0)[lane];
-                            a3 = (bb + o1)[lane];
-                        }
-                        wr[sq] = a0; wk[sq] = a1; br[sq] = a2; bk[sq] = a3;
-                    }
-                }
-                // ---- half-sweep h on row f - h, h = 1..HS ------------------------------------
+            for (int i = 0; i < G; ++i)
+                fused_step<T, BORDER, L1, UNR, true, NT>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+        } else {
 #pragma unroll
-                for (int h = 1; h <= HS; ++h) {
-                    const int r = f - h;
-                    const int sr = Win::slot(i, h), su = Win::slot(i, h + 1), sd = Win::slot(i, h - 1);
-                    const int c = (h - 1) & 1;                       // 0 = red, 1 = black
-                    const int p = ((i - h + 2 * HS + 2) + c) & 1;    // pixel column = 2j + p
-                    if (r >= m0 && r < m1) {
-                        // opposite colour: rows r-1, r, r+1
-                        const double up = c ? wr[su] : wk[su];
-                        const double dn = c ? wr[sd] : wk[sd];
-                        const double same = c ? wr[sr] : wk[sr];
-                        const double other = p ? lane_next(same) : lane_prev(same);
-                        const double left = p ? same : other;
-                        const double right = p ? other : same;
-                        const double bv = c ? bk[sr] : br[sr];
-                        const double old = c ? wk[sr] : wr[sr];
-                        double nv = old;
-                        if (!BORDER) {
-                            nv = (bv + (((up + left) + right) + dn)) * 0.25;
-                        } else {
-                            const int x = 2 * j + p;
-                            if (col_ok && x < g.W) {
-                                const Stencil s = classify(g, x, g.y0 + r, r);
-                                double t;
-                                if (gs_update(s, bv, up, left, right, dn, t)) nv = t;
-                            }
-                        }
-                        if (L1 && h >= HS - 1) {
-                            const bool counted = col_store && r >= ra && r < rb && r >= g.own_lo && r < g.own_hi &&
-                                                 (!BORDER || (2 * j + p) < g.W);
-                            if (counted) acc += fabs(nv - old);
-                        }
-                        if (c) wk[sr] = nv; else wr[sr] = nv;
-                    }
-                }
-                // ---- row f - HS is final: store it -------------------------------------------
-                {
-                    const int r = f - HS;
-                    const int sr = Win::slot(i, HS);
-                    if (r >= ra && r < rb && col_store) {
-                        (xout + (row_off(g, r, 0) + jbase))[lane] = wr[sr];
-                        (xout + (row_off(g, r, 1) + jbase))[lane] = wk[sr];
-                    }
-                }
-            }
+            for (int i = 0; i < G; ++i)
+                if (fb + i <= f_end)
+                    fused_step<T, BORDER, L1, UNR, false, NT>(wr, wk, br, bk, acc, cx, g, fb + i, i);
         }
         if (UNR > 0) {
 #pragma unroll
@@ -215,8 +252,13 @@ __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, dou
 // pixels have four neighbours, the border-aware one when it touches an image edge or the stale
 // edge of a ghost zone.  (Two separate launches were tried: the border launch ran alone at low
 // occupancy and cost +0.25 ms per pass at 16384^2.)
+// Waves per SIMD the register window of depth T is budgeted for (2nd __launch_bounds__ argument:
+// it caps the allocator, so the straight-line steady-state code cannot trade occupancy for
+// load hoisting).
+__host__ __device__ constexpr int fused_waves_per_simd(int T) { return T <= 1 ? 4 : (T <= 3 ? 3 : 2); }
+
 template <int T, bool L1, int UNR>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock, fused_waves_per_simd(T))
 k_fused_sweep(FusedParams P)
 {
     __shared__ double scratch[kBlock / kWave];
