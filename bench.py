@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--iters-per-step", type=int, default=32)
     ap.add_argument("--ghost", type=int, default=32, help="ghost rows per side (N>1); exchange every ghost/2 iterations")
+    ap.add_argument("--no-tune", action="store_true", help="skip ccp_grid_tune (use the built-in defaults)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed iterations-to-1e-5 run")
     ap.add_argument("--converge-cap", type=int, default=6000)
@@ -119,6 +120,11 @@ def main():
         torch.cuda.synchronize()
 
     ips = args.iters_per_step
+    tuned = None
+    if not args.no_tune:
+        # untimed: choose fused depth / chunk rows for this shape (speed only, results identical)
+        tuned = g.tune(min(8, max(1, (ips if world == 1 else solver.iters_per_exchange) // 2)))
+        g.synchronize()
     for _ in range(args.warmup):
         solver.sweep(ips)
     barrier()
@@ -190,6 +196,7 @@ def main():
                                    f"red-black Gauss-Seidel, fixed iteration count" if C == 1 else
                                    f"{W}x{H} {C}-channel Poisson blend, red-black Gauss-Seidel",
                        "iters_per_step": ips, "channels": C,
+                       "tuned": None if tuned is None else {"fused_depth": tuned[0], "rows_per_chunk": tuned[1], "ms_per_iteration": tuned[2]},
                        "partition": "single block" if world == 1 else f"{world} row blocks, ghost {ghost}, halo exchange every {ghost // 2} iterations over RCCL"},
             "roofline_frac_of_value": value * BYTES_PER_UPDATE / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roofline,

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
     "ccp_grid_get_b_host", "ccp_grid_fill_x", "ccp_grid_b_from_x", "ccp_grid_randomize_x",
-    "ccp_grid_sweep", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel",
+    "ccp_grid_sweep", "ccp_grid_tune", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel",
     "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_store_u8",
     "ccp_grid_set_x_u8", "ccp_grid_last_timing",
 )
@@ -115,6 +115,7 @@ def load() -> C.CDLL:
     L.ccp_grid_randomize_x.argtypes = [vp, C.c_uint64, dbl, dbl]
     L.ccp_grid_sweep.argtypes = [vp, i32]
     L.ccp_grid_sweep_l1.argtypes = [vp, vp]
+    L.ccp_grid_tune.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float)]
     L.ccp_grid_halo_refreshed.argtypes = [vp]
     L.ccp_grid_gauss_seidel.argtypes = [vp, dbl, i32, i32, C.POINTER(Report)]
     L.ccp_grid_residual_norm2.argtypes = [vp, vp]
@@ -299,6 +300,12 @@ class Grid:
 
     def sweep(self, iterations):
         check(self.L.ccp_grid_sweep(self.h, iterations), "ccp_grid_sweep")
+
+    def tune(self, max_t: int = 8):
+        """Time the (depth, rows-per-chunk) candidates on this shape; returns (T, rows, ms/iter)."""
+        t, r, ms = C.c_int32(), C.c_int32(), C.c_float()
+        check(self.L.ccp_grid_tune(self.h, max_t, C.byref(t), C.byref(r), C.byref(ms)), "ccp_grid_tune")
+        return t.value, r.value, ms.value
 
     def sweep_l1(self) -> np.ndarray:
         out = np.empty(self.C, dtype=np.float64)

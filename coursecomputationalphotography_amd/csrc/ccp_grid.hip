@@ -3,6 +3,7 @@
 #include "ccp_grid_fused.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <cstring>
 #include <vector>
 
@@ -21,7 +22,11 @@ struct ccp_grid {
     DevBuf<double> x_alt;        // ping-pong partner of x for the temporally blocked sweep
     bool fuse = true;            // use k_fused_sweep for unchecked sweeps
     int fuse_tmax = kFusedMaxT;  // iterations fused per launch (<= kFusedMaxT)
-    int rows_per_chunk = 128;    // rows a fused wave finalises (plus 4T halo rows)
+    int rows_per_chunk = 128;    // rows a fused wave finalises (plus 4T halo rows); default for every T
+    // per-depth launch cost (ms) and chunk rows measured by ccp_grid_tune; index = T
+    float tune_ms[kFusedMaxT + 1] = {0};
+    int tune_rows[kFusedMaxT + 1] = {0};
+    bool tuned = false;
     DevBuf<double> partial;      // per-block partial sums (L1 step / residual / checksums)
     long partial_region = 0;     // doubles per colour region of `partial` (L1 step)
     DevBuf<double> small;        // 4*kMaxChannels doubles of reduced results
@@ -127,7 +132,7 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     P.g = g->geom;
     P.st_lo = st_lo;
     P.st_hi = st_hi;
-    P.rows_per_chunk = g->rows_per_chunk;
+    P.rows_per_chunk = (g->tuned && g->tune_rows[T] > 0) ? g->tune_rows[T] : g->rows_per_chunk;
     const int U = fused_useful_px(T);
     P.n_strips = (g->geom.W + U - 1) / U;
     P.partial = g->partial.p;
@@ -179,12 +184,35 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr)
         CCP_TRY(g->x_alt.alloc(elems));
         CCP_HIP(hipMemsetAsync(g->x_alt.p, 0, elems * sizeof(double), g->stream));
     }
+    // Split `iterations` into an EVEN number of launches of depth <= tmax with the least total
+    // cost: measured per-depth launch times when the handle was tuned, otherwise "fewer, deeper
+    // launches are cheaper".  f[i][p]: best cost for i iterations with launch-count parity p.
     const int tmax = g->fuse_tmax;
-    const int launches = 2 * ((iterations + 2 * tmax - 1) / (2 * tmax));
-    const int base_t = iterations / launches, extra = iterations % launches;
+    auto cost = [&](int T) -> double { return g->tuned && g->tune_ms[T] > 0 ? (double)g->tune_ms[T] : 1.0 + 0.01 * T; };
+    const double inf = 1e300;
+    std::vector<double> f((size_t)(iterations + 1) * 2, inf);
+    std::vector<int> step((size_t)(iterations + 1) * 2, 0);
+    f[0] = 0.0;
+    for (int i = 1; i <= iterations; ++i)
+        for (int p = 0; p < 2; ++p)
+            for (int T = 1; T <= tmax && T <= i; ++T) {
+                const double c = f[(size_t)(i - T) * 2 + (p ^ 1)] + cost(T);
+                if (c < f[(size_t)i * 2 + p]) {
+                    f[(size_t)i * 2 + p] = c;
+                    step[(size_t)i * 2 + p] = T;
+                }
+            }
+    std::vector<int> plan;
+    for (int i = iterations, p = 0; i > 0;) {
+        const int T = step[(size_t)i * 2 + p];
+        if (T == 0) return CCP_ERR_STATE;
+        plan.push_back(T);
+        i -= T;
+        p ^= 1;
+    }
+    std::sort(plan.begin(), plan.end(), std::greater<int>());
     double *cur = g->x.p, *alt = g->x_alt.p;
-    for (int k = 0; k < launches; ++k) {
-        const int T = base_t + (k < extra ? 1 : 0);
+    for (int T : plan) {
         CCP_TRY(launch_fused(g, T, cur, alt, active));
         std::swap(cur, alt);
     }
@@ -407,6 +435,90 @@ int ccp_grid_sweep(ccp_grid *g, int32_t iterations)
     begin_timing(g);
     CCP_TRY(run_unchecked(g, iterations));
     end_timing(g);
+    return CCP_OK;
+}
+
+int ccp_grid_tune(ccp_grid *g, int32_t max_t, int32_t *chosen_t, int32_t *chosen_rows_per_chunk, float *ms_per_iteration)
+{
+    CCP_TRY(bind(g));
+    if (max_t < 1) return CCP_ERR_BAD_ARG;
+    max_t = std::min<int>(max_t, kFusedMaxT);
+    if (!g->x_alt.p) {
+        const size_t elems = (size_t)g->geom.ch_stride * g->desc.channels;
+        CCP_TRY(g->x_alt.alloc(elems));
+        CCP_HIP(hipMemsetAsync(g->x_alt.p, 0, elems * sizeof(double), g->stream));
+    }
+    const int saved_chunk = g->rows_per_chunk, saved_launches = g->last_launches;
+    const bool saved_tuned = g->tuned;
+    g->tuned = false;                                  // candidates below set rows_per_chunk directly
+    float tab_ms[kFusedMaxT + 1] = {0};
+    int tab_rows[kFusedMaxT + 1] = {0};
+    const int rows = g->geom.local_rows;
+    const int chunk_candidates[] = {32, 48, 64, 80, 96, 112, 128, 160, 192, 256};
+    float best = 1e30f;
+    int best_t = 1, best_r = saved_chunk;
+    hipEvent_t e0, e1;
+    CCP_HIP(hipEventCreate(&e0));
+    CCP_HIP(hipEventCreate(&e1));
+    int status = CCP_OK;
+    for (int T = 1; T <= max_t && status == CCP_OK; ++T) {
+        for (int R : chunk_candidates) {
+            if (R > rows && R != chunk_candidates[0]) continue;
+            g->rows_per_chunk = R;
+            auto once = [&]() -> int {
+                switch (T) {
+                case 1: return launch_fused_t<1>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
+                case 2: return launch_fused_t<2>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
+                case 3: return launch_fused_t<3>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
+                case 4: return launch_fused_t<4>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
+                case 5: return launch_fused_t<5>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
+                case 6: return launch_fused_t<6>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
+                case 7: return launch_fused_t<7>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
+                default: return launch_fused_t<8>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
+                }
+            };
+            status = once();                                   // warm (code, TLB)
+            if (status != CCP_OK) break;
+            (void)hipEventRecord(e0, g->stream);
+            status = once();
+            if (status == CCP_OK) status = once();
+            (void)hipEventRecord(e1, g->stream);
+            if (status != CCP_OK) break;
+            if (hipEventSynchronize(e1) != hipSuccess) { status = CCP_ERR_HIP; break; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            const float per_launch = ms / 2.0f;
+            if (getenv("CCP_GS_DEBUG"))
+                fprintf(stderr, "[ccp_gs] tune T=%d rows/chunk=%d: %.4f ms/launch, %.5f ms/iteration\n", T, R, per_launch, per_launch / T);
+            if (tab_ms[T] == 0.f || per_launch < tab_ms[T]) {
+                tab_ms[T] = per_launch;
+                tab_rows[T] = R;
+            }
+            const float per_iter = per_launch / T;
+            if (per_iter < best) {
+                best = per_iter;
+                best_t = T;
+                best_r = R;
+            }
+        }
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    g->last_launches = saved_launches;
+    g->rows_per_chunk = saved_chunk;
+    if (status != CCP_OK) {
+        g->tuned = saved_tuned;
+        return status;
+    }
+    for (int T = 1; T <= kFusedMaxT; ++T) {
+        g->tune_ms[T] = tab_ms[T];
+        g->tune_rows[T] = tab_rows[T];
+    }
+    g->tuned = true;
+    g->fuse_tmax = max_t;
+    if (chosen_t) *chosen_t = best_t;
+    if (chosen_rows_per_chunk) *chosen_rows_per_chunk = best_r;
+    if (ms_per_iteration) *ms_per_iteration = best;
     return CCP_OK;
 }
 

@@ -168,6 +168,12 @@ int ccp_grid_randomize_x(ccp_grid *g, uint64_t seed, double lo, double hi);
  * With ghosts: each sweep invalidates two more ghost rows, so at most ghost/2 iterations may
  * run between two halo refreshes (enforced: CCP_ERR_STATE). */
 int ccp_grid_sweep(ccp_grid *g, int32_t iterations);
+/* Pick the temporal-blocking depth (iterations fused per kernel pass, <= max_t) and the rows a
+ * wave finalises per pass by timing the candidates on this handle's actual shape (a few dozen
+ * launches into the scratch buffer; x, b and the ghost bookkeeping are left untouched).  Results
+ * never depend on the choice — only speed does.  Outputs may be NULL.  Synchronises. */
+int ccp_grid_tune(ccp_grid *g, int32_t max_t, int32_t *chosen_t, int32_t *chosen_rows_per_chunk,
+                  float *ms_per_iteration);
 /* One more sweep that also returns, per channel, sum|x_new - x_old| over the OWNED rows (the
  * local share of the reference's manhattonDist step, sparse-matrix.h:376) to a host array of
  * `channels` doubles; row-blocked callers all-reduce it.  Synchronises. */
