@@ -29,7 +29,7 @@ ABI_SYMBOLS = (
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
     "ccp_grid_get_b_host", "ccp_grid_fill_x", "ccp_grid_b_from_x", "ccp_grid_randomize_x",
     "ccp_grid_sweep", "ccp_grid_tune", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel",
-    "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_store_u8",
+    "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_assemble_from_images", "ccp_grid_store_u8",
     "ccp_grid_set_x_u8", "ccp_grid_last_timing",
 )
 
@@ -121,6 +121,7 @@ def load() -> C.CDLL:
     L.ccp_grid_residual_norm2.argtypes = [vp, vp]
     L.ccp_grid_abs_sum.argtypes = [vp, vp]
     L.ccp_grid_assemble_rhs.argtypes = [vp, vp, vp, i64, vp]
+    L.ccp_grid_assemble_from_images.argtypes = [vp, vp, i32, i64, vp, i64, i32]
     L.ccp_grid_store_u8.argtypes = [vp, vp, i64]
     L.ccp_grid_set_x_u8.argtypes = [vp, vp, i64]
     L.ccp_grid_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
@@ -335,6 +336,14 @@ class Grid:
         gy = np.ascontiguousarray(gy, dtype=np.float32)
         cons = _i32(constraint)
         check(self.L.ccp_grid_assemble_rhs(self.h, _ptr(gx), _ptr(gy), gx.strides[0], _ptr(cons)), "ccp_grid_assemble_rhs")
+
+    def assemble_from_images(self, images, label: np.ndarray, init_x: bool = False):
+        imgs = [np.ascontiguousarray(i, dtype=np.uint8) for i in images]
+        label = np.ascontiguousarray(label, dtype=np.uint8)
+        ptrs = (C.c_void_p * len(imgs))(*[i.ctypes.data for i in imgs])
+        check(self.L.ccp_grid_assemble_from_images(self.h, ptrs, len(imgs), imgs[0].strides[0], _ptr(label),
+                                                   label.strides[0], 1 if init_x else 0),
+              "ccp_grid_assemble_from_images")
 
     def store_u8(self) -> np.ndarray:
         out = np.zeros((self.H, self.W, self.C), dtype=np.uint8)

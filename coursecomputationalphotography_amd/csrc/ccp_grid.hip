@@ -675,6 +675,41 @@ int ccp_grid_assemble_rhs(ccp_grid *g, const float *gx, const float *gy, int64_t
     return CCP_OK;
 }
 
+int ccp_grid_assemble_from_images(ccp_grid *g, const uint8_t *const *images, int32_t n_images,
+                                  int64_t image_stride_bytes, const uint8_t *label, int64_t label_stride_bytes,
+                                  int32_t init_x_from_composite)
+{
+    CCP_TRY(bind(g));
+    if (!images || !label || n_images < 1 || n_images > 256) return CCP_ERR_BAD_ARG;
+    if (g->desc.channels != 3) return CCP_ERR_UNSUPPORTED;                   // BGR images
+    if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;
+    const int W = g->desc.width, H = g->desc.height;
+    if (image_stride_bytes < (int64_t)W * 3 || label_stride_bytes < W) return CCP_ERR_BAD_ARG;
+    for (int k = 0; k < n_images; ++k)
+        if (!images[k]) return CCP_ERR_BAD_ARG;
+    // labels must select existing images (the reference indexes Images[label] unchecked)
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            if (label[(size_t)y * label_stride_bytes + x] >= n_images) return CCP_ERR_BAD_ARG;
+    DevBuf<uint8_t> dimg, dlab;
+    const size_t plane = (size_t)W * H * 3;
+    CCP_TRY(dimg.alloc(plane * n_images));
+    CCP_TRY(dlab.alloc((size_t)W * H));
+    for (int k = 0; k < n_images; ++k)
+        CCP_HIP(hipMemcpy2DAsync(dimg.p + plane * k, (size_t)W * 3, images[k], (size_t)image_stride_bytes, (size_t)W * 3,
+                                 (size_t)H, hipMemcpyHostToDevice, g->stream));
+    CCP_HIP(hipMemcpy2DAsync(dlab.p, (size_t)W, label, (size_t)label_stride_bytes, (size_t)W, (size_t)H,
+                             hipMemcpyHostToDevice, g->stream));
+    dim3 grid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, 3);
+    if (init_x_from_composite)
+        hipLaunchKernelGGL((k_assemble_from_images<true>), grid, dim3(kBlock), 0, g->stream, g->b.p, g->x.p, g->geom, dimg.p, dlab.p);
+    else
+        hipLaunchKernelGGL((k_assemble_from_images<false>), grid, dim3(kBlock), 0, g->stream, g->b.p, g->x.p, g->geom, dimg.p, dlab.p);
+    CCP_HIP(hipGetLastError());
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    return CCP_OK;
+}
+
 int ccp_grid_store_u8(ccp_grid *g, uint8_t *out, int64_t row_stride_bytes)
 {
     CCP_TRY(bind(g));

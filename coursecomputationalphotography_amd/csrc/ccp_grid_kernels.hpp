@@ -456,6 +456,45 @@ k_assemble_rhs(double *__restrict__ b, Geom g, const float *__restrict__ gx,
     b[(long)ch * g.ch_stride + row_off(g, l, (x + y) & 1) + (x >> 1)] = acc;
 }
 
+// Gradient field + right-hand side in one pass, straight from the source images and the label
+// map (BuildSolveGradientFusion, PhotoMontage.cpp:419-433): the forward differences of
+// GradientAt (:399-408: integer subtraction of the label-selected image, then float) feed the
+// same ATb accumulation as k_assemble_rhs, with the pin value Images[0](0,0)[ch] (:428).
+// INIT: also write the composite image as the start vector (PhotoMontage.cpp:599-610).
+// images: K stacked H x W x 3 u8 images, label: H x W u8.  grid = (ceil(W/kBlock), H, 3).
+template <bool INIT>
+__global__ void __launch_bounds__(kBlock)
+k_assemble_from_images(double *__restrict__ b, double *__restrict__ x, Geom g,
+                       const uint8_t *__restrict__ images, const uint8_t *__restrict__ label)
+{
+    const int xi = blockIdx.x * kBlock + threadIdx.x;
+    const int y = blockIdx.y;
+    const int ch = blockIdx.z;
+    if (xi >= g.W) return;
+    const long plane = (long)g.W * g.H * 3;
+    auto pix = [&](int k, int yy, int xx) -> int { return (int)images[(long)k * plane + ((long)yy * g.W + xx) * 3 + ch]; };
+    auto lab = [&](int yy, int xx) -> int { return (int)label[(long)yy * g.W + xx]; };
+    double acc = 0.0;
+    if (y >= 1 && xi < g.W - 1) {                       // gy(y-1, x) of the cell above
+        const int k = lab(y - 1, xi);
+        acc += 1.0 * (double)(float)(pix(k, y, xi) - pix(k, y - 1, xi));
+    }
+    if (xi >= 1 && y < g.H - 1) {                       // gx(y, x-1) of the cell to the left
+        const int k = lab(y, xi - 1);
+        acc += 1.0 * (double)(float)(pix(k, y, xi) - pix(k, y, xi - 1));
+    }
+    if (xi < g.W - 1 && y < g.H - 1) {                  // -gx(y,x) - gy(y,x) of this cell
+        const int k = lab(y, xi);
+        const int here = pix(k, y, xi);
+        acc += -1.0 * (double)(float)(pix(k, y, xi + 1) - here);
+        acc += -1.0 * (double)(float)(pix(k, y + 1, xi) - here);
+    }
+    if ((xi | y) == 0) acc += 1.0 * (double)pix(0, 0, 0);
+    const long at = (long)ch * g.ch_stride + row_off(g, y - g.y0, (xi + y) & 1) + (xi >> 1);
+    b[at] = acc;
+    if (INIT) x[at] = (double)pix(lab(y, xi), y, xi);
+}
+
 // Solve epilogue: out(y,x)[ch] = uchar(max(min(sol,255),0)) (PhotoMontage.cpp:617-626).
 __global__ void __launch_bounds__(kBlock)
 k_store_u8(const double *__restrict__ x, Geom g, uint8_t *__restrict__ out, int C)

@@ -201,6 +201,14 @@ int ccp_grid_abs_sum(ccp_grid *g, double *per_channel);
  * constraint[ch] = the pin value v(0,0).  Single-block handles only. */
 int ccp_grid_assemble_rhs(ccp_grid *g, const float *gx, const float *gy, int64_t row_stride_bytes,
                           const int32_t *constraint);
+/* The whole front half of BuildSolveGradientFusion on device (PhotoMontage.cpp:399-433): the
+ * gradient field of the label-selected images (GradientAt) and from it ATb of all three
+ * channels, pin = Images[0](0,0)[ch]; optionally the composite image as the start vector
+ * (PhotoMontage.cpp:599-610).  images[k]: H x W x 3 u8 interleaved (cv::Mat CV_8UC3), label:
+ * H x W u8 (CV_8UC1), strides in bytes.  3-channel single-block handles only. */
+int ccp_grid_assemble_from_images(ccp_grid *g, const uint8_t *const *images, int32_t n_images,
+                                  int64_t image_stride_bytes, const uint8_t *label,
+                                  int64_t label_stride_bytes, int32_t init_x_from_composite);
 /* Solve epilogue (PhotoMontage.cpp:617-626): out(y,x)[ch] = uchar(max(min(x,255),0)) for all
  * channels into an interleaved H x W x channels u8 host image. */
 int ccp_grid_store_u8(ccp_grid *g, uint8_t *out, int64_t row_stride_bytes);
