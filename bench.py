@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--iters-per-step", type=int, default=32)
     ap.add_argument("--ghost", type=int, default=32, help="ghost rows per side (N>1); exchange every ghost/2 iterations")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (default); gloo stages halos through the host (several ranks on one GPU, testing only)")
+    ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (testing with --backend gloo)")
     ap.add_argument("--no-tune", action="store_true", help="skip ccp_grid_tune (use the built-in defaults)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed iterations-to-1e-5 run")
@@ -92,9 +95,14 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Gauss-Seidel path has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
 
     from coursecomputationalphotography_amd import rowblock
 
@@ -138,7 +146,7 @@ def main():
     ms, n_launch = g.last_timing()
     kernel_ms, launches = ms, n_launch
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+    t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -184,6 +192,8 @@ def main():
         extra["iters_to_1e-5"] = done if rel <= 1e-5 else None
         extra["rel_residual_trace"] = trace[-4:]
         extra["rel_residual_final"] = rel
+        # the reference's own stop quantity, sum|x_k - x_{k-1}| (sparse-matrix.h:376), one more sweep
+        extra["l1_step_after"] = [done + 1, float(solver.sweep_l1().max())]
 
     if rank == 0:
         out = {
@@ -197,7 +207,7 @@ def main():
                                    f"{W}x{H} {C}-channel Poisson blend, red-black Gauss-Seidel",
                        "iters_per_step": ips, "channels": C,
                        "tuned": None if tuned is None else {"fused_depth": tuned[0], "rows_per_chunk": tuned[1], "ms_per_iteration": tuned[2]},
-                       "partition": "single block" if world == 1 else f"{world} row blocks, ghost {ghost}, halo exchange every {ghost // 2} iterations over RCCL"},
+                       "partition": "single block" if world == 1 else f"{world} row blocks, ghost {ghost}, halo exchange every {ghost // 2} iterations over " + ("RCCL" if args.backend == "nccl" else "gloo (host-staged, test only)")},
             "roofline_frac_of_value": value * BYTES_PER_UPDATE / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roofline,
         }

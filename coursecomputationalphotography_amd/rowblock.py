@@ -86,23 +86,33 @@ class RowBlockSolver:
         """Send the outermost owned rows to the neighbours' ghost rows (both directions)."""
         blk, dist = self.block, self.dist
         if self.world > 1:
-            ops, keep = [], []
             x = blk.x_rows
             C = x.shape[0]
             gt, gb = blk.ghost_top, blk.ghost_bottom
             own_lo, own_hi = gt, gt + blk.row_count
+            sends, recvs = [], []                       # (tensor view, peer)
             for ch in range(C):
                 if self.rank > 0:          # upper neighbour: my top owned rows <-> my top ghosts
                     n_send = self._peer_ghost_bottom(self.rank - 1)
-                    ops.append(dist.P2POp(dist.isend, x[ch, own_lo:own_lo + n_send], self.rank - 1, self.group))
-                    ops.append(dist.P2POp(dist.irecv, x[ch, 0:gt], self.rank - 1, self.group))
+                    sends.append((x[ch, own_lo:own_lo + n_send], self.rank - 1))
+                    recvs.append((x[ch, 0:gt], self.rank - 1))
                 if self.rank < self.world - 1:
                     n_send = self._peer_ghost_top(self.rank + 1)
-                    ops.append(dist.P2POp(dist.isend, x[ch, own_hi - n_send:own_hi], self.rank + 1, self.group))
-                    ops.append(dist.P2POp(dist.irecv, x[ch, own_hi:own_hi + gb], self.rank + 1, self.group))
+                    sends.append((x[ch, own_hi - n_send:own_hi], self.rank + 1))
+                    recvs.append((x[ch, own_hi:own_hi + gb], self.rank + 1))
+            # gloo cannot move device memory: stage through host copies (CPU tests of the GPU
+            # path with several ranks on one card; RCCL sends the device rows directly)
+            staged = x.is_cuda and dist.get_backend(self.group) == "gloo"
+            out = [(t.cpu() if staged else t, p) for t, p in sends]
+            inn = [((t.new_empty(t.shape, device="cpu") if staged else t), p) for t, p in recvs]
+            ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in out]
+            ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in inn]
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
+            if staged:
+                for (dst, _), (src, _) in zip(recvs, inn):
+                    dst.copy_(src)
         blk.halo_refreshed()
         self.since_exchange = 0
 
