@@ -24,11 +24,11 @@ ORDER_MULTICOLOUR = 1
 ABI_SYMBOLS = (
     "ccp_status_string", "ccp_abi_version", "ccp_device_count",
     "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_set_colouring",
-    "ccp_csr_gauss_seidel", "ccp_csr_apply_to_vector", "ccp_csr_residual_norm2",
+    "ccp_csr_gauss_seidel", "ccp_csr_conjugate_gradient", "ccp_csr_apply_to_vector", "ccp_csr_residual_norm2",
     "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
     "ccp_grid_get_b_host", "ccp_grid_fill_x", "ccp_grid_b_from_x", "ccp_grid_randomize_x",
-    "ccp_grid_sweep", "ccp_grid_tune", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel",
+    "ccp_grid_sweep", "ccp_grid_tune", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_conjugate_gradient",
     "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_assemble_from_images", "ccp_grid_store_u8",
     "ccp_grid_set_x_u8", "ccp_grid_last_timing",
 )
@@ -101,6 +101,8 @@ def load() -> C.CDLL:
     L.ccp_csr_upload.argtypes = [vp, i32, i32, i64, vp, vp, vp, vp]
     L.ccp_csr_set_colouring.argtypes = [vp, vp, i32]
     L.ccp_csr_gauss_seidel.argtypes = [vp, vp, vp, vp, dbl, i32, i32, i32, C.POINTER(Report)]
+    L.ccp_csr_conjugate_gradient.argtypes = [vp, vp, vp, vp, dbl, i32, C.POINTER(Report)]
+    L.ccp_grid_conjugate_gradient.argtypes = [vp, dbl, i32, C.POINTER(Report)]
     L.ccp_csr_apply_to_vector.argtypes = [vp, vp, vp]
     L.ccp_csr_residual_norm2.argtypes = [vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl)]
     L.ccp_grid_create.argtypes = [C.POINTER(GridDesc), C.POINTER(vp)]
@@ -211,6 +213,15 @@ class CsrMatrix:
                                           check_every, ordering, C.byref(rep)), "ccp_csr_gauss_seidel")
         return x, rep
 
+    def conjugate_gradient(self, b, epsilon=1e-16, max_iteration=1000, init=None):
+        b = _f64(b)
+        ia = None if init is None else _f64(init)
+        x = np.empty(self.n_cols, dtype=np.float64)
+        rep = Report()
+        check(self.L.ccp_csr_conjugate_gradient(self.h, _ptr(b), _ptr(ia), _ptr(x), epsilon, max_iteration,
+                                                C.byref(rep)), "ccp_csr_conjugate_gradient")
+        return x, rep
+
     def apply_to_vector(self, v):
         v = _f64(v)
         out = np.empty(self.n_rows, dtype=np.float64)
@@ -319,6 +330,11 @@ class Grid:
     def gauss_seidel(self, epsilon=1e-6, max_iteration=1000, check_every=1):
         reps = (Report * self.C)()
         check(self.L.ccp_grid_gauss_seidel(self.h, epsilon, max_iteration, check_every, reps), "ccp_grid_gauss_seidel")
+        return list(reps)
+
+    def conjugate_gradient(self, epsilon=1e-16, max_iteration=1000):
+        reps = (Report * self.C)()
+        check(self.L.ccp_grid_conjugate_gradient(self.h, epsilon, max_iteration, reps), "ccp_grid_conjugate_gradient")
         return list(reps)
 
     def residual_norm2(self):

@@ -2,6 +2,7 @@
 // See include/ccp_gs.h.  Host side: schedule construction (colouring / level scheduling) and the
 // sliced-ELL re-tiling; device side: ccp_csr_kernels.hpp.
 #include "ccp_csr_kernels.hpp"
+#include "ccp_cg.hpp"
 
 #include <algorithm>
 #include <cstring>
@@ -54,6 +55,8 @@ struct ccp_csr {
     Schedule multicolour;    // colour-major, columns sorted by permuted index (reference on P A P^T)
     Schedule lexicographic;  // level-major, original storage order kept inside a row
     DevBuf<double> x, b, tmp, partial;
+    DevBuf<double> cg_p, cg_ap;            // conjugate-gradient work vectors (allocated on first use)
+    DevBuf<CgState> cg_state;
     DevBuf<CsrSolveState> state;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
 };
@@ -431,6 +434,42 @@ int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *
         report->last_l1_step = host.last_eps;
         report->seconds = ms * 1e-3;
     }
+    return CCP_OK;
+}
+
+int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, double *x_out, double epsilon,
+                               int32_t max_iteration, ccp_gs_report *report)
+{
+    CCP_TRY(bind(m));
+    if (!m->uploaded) return CCP_ERR_STATE;
+    if (!b || !x_out) return CCP_ERR_BAD_ARG;
+    if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;
+    CCP_TRY(ensure_natural(m));
+    const long n = m->n_rows;
+    hipStream_t s = m->stream;
+    if (!m->cg_p.p || m->cg_p.n < (size_t)std::max<long>(n, 2)) {
+        CCP_TRY(m->cg_p.alloc((size_t)std::max<long>(n, 2)));
+        CCP_TRY(m->cg_ap.alloc((size_t)std::max<long>(n, 2)));
+        CCP_TRY(m->cg_state.alloc(1));
+    }
+    const unsigned spmv_blocks = (unsigned)((m->natural.n_slices + kBlock / kWave - 1) / (kBlock / kWave));
+    CCP_TRY(ensure_partial(m, std::max<long>(2048, spmv_blocks)));
+    if (n) {
+        CCP_HIP(hipMemcpyAsync(m->b.p, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        if (init) CCP_HIP(hipMemcpyAsync(m->x.p, init, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        else CCP_HIP(hipMemsetAsync(m->x.p, 0, sizeof(double) * n, s));                 // sparse-matrix.h:397
+    }
+    const SellView view = m->natural.view();
+    const int n_slices = m->natural.n_slices;
+    auto spmv = [&](const double *in, double *out) -> int {
+        if (n_slices == 0) return CCP_OK;
+        hipLaunchKernelGGL((k_sell_apply<0>), dim3(spmv_blocks), dim3(kBlock), 0, s, view, n_slices, in, out, in, m->partial.p);
+        return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
+    };
+    CCP_TRY(cg_solve(spmv, m->b.p, m->x.p, m->tmp.p, m->cg_p.p, m->cg_ap.p, n, epsilon, max_iteration, m->cg_state.p,
+                     m->partial.p, s, m->ev0, m->ev1, report));
+    if (n) CCP_HIP(hipMemcpyAsync(x_out, m->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    CCP_HIP(hipStreamSynchronize(s));
     return CCP_OK;
 }
 

@@ -1,6 +1,7 @@
 // ccp_grid.hip — C ABI of the structured (matrix-free) Poisson grid path.  See include/ccp_gs.h.
 #include "ccp_grid_kernels.hpp"
 #include "ccp_grid_fused.hpp"
+#include "ccp_cg.hpp"
 
 #include <algorithm>
 #include <functional>
@@ -19,6 +20,8 @@ struct ccp_grid {
     int device = 0;
     hipStream_t stream = nullptr;
     DevBuf<double> x, b;
+    DevBuf<double> cg_r, cg_p, cg_ap;   // conjugate-gradient work vectors, one channel each
+    DevBuf<CgState> cg_state;
     DevBuf<double> x_alt;        // ping-pong partner of x for the temporally blocked sweep
     bool fuse = true;            // use k_fused_sweep for unchecked sweeps
     int fuse_tmax = kFusedMaxT;  // iterations fused per launch (<= kFusedMaxT)
@@ -603,6 +606,34 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
             report[ch].last_l1_step = host.last_eps[ch];
             report[ch].seconds = ms * 1e-3;
         }
+    }
+    return CCP_OK;
+}
+
+int ccp_grid_conjugate_gradient(ccp_grid *g, double epsilon, int32_t max_iteration, ccp_gs_report *report)
+{
+    CCP_TRY(bind(g));
+    if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;
+    const Geom &geo = g->geom;
+    const long n = geo.ch_stride;                       // one channel incl. pads (pads stay 0 in b, r, p, Ap)
+    if (!g->cg_r.p) {
+        CCP_TRY(g->cg_r.alloc((size_t)n));
+        CCP_TRY(g->cg_p.alloc((size_t)n));
+        CCP_TRY(g->cg_ap.alloc((size_t)n));
+        CCP_TRY(g->cg_state.alloc(1));
+    }
+    hipStream_t s = g->stream;
+    dim3 grid((unsigned)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)), (unsigned)geo.local_rows, 2);
+    for (int ch = 0; ch < g->desc.channels; ++ch) {
+        CCP_HIP(hipMemsetAsync(g->cg_r.p, 0, sizeof(double) * n, s));
+        CCP_HIP(hipMemsetAsync(g->cg_ap.p, 0, sizeof(double) * n, s));
+        // matrix-free A*v on one channel: the kernel sees channel 0 of the offset pointers
+        auto spmv = [&](const double *in, double *out) -> int {
+            hipLaunchKernelGGL((k_apply<2, 0>), grid, dim3(kBlock), 0, s, in, out, out, geo, 0, g->partial.p);
+            return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
+        };
+        CCP_TRY(cg_solve(spmv, g->b.p + (long)ch * n, g->x.p + (long)ch * n, g->cg_r.p, g->cg_p.p, g->cg_ap.p, n, epsilon,
+                         max_iteration, g->cg_state.p, g->partial.p, s, g->ev0, g->ev1, report ? report + ch : nullptr));
     }
     return CCP_OK;
 }

@@ -18,7 +18,8 @@
 //   * the host-side storage is written from scratch: same five arrays, same slack semantics
 //     (explicit zeros and removed entries become free slots), different code.
 //
-// Not on the hot path and therefore not provided here: conjugateGradient* (SURVEY.md §8f.1).
+// conjugateGradient (the solver the blend call sites use today) is provided too; its iterates
+// match the reference to rounding (tree-ordered reductions).  conjugateGradientEigen / Paper are not.
 #pragma once
 
 #include <algorithm>
@@ -295,6 +296,20 @@ public:
         ccp::throw_on(ccp_csr_gauss_seidel(dev_, b.data(), initialize.empty() ? nullptr : initialize.data(), x.data(),
                                            epsilon, max_iteration, 1, static_cast<int>(ordering), &rep),
                       "ccp_csr_gauss_seidel");
+        last_report_ = rep;
+        return x;
+    }
+
+    // Reference: sparse-matrix.h:396-434 (x0 = 0 unless `initialize` is given).
+    std::vector<double> conjugateGradient(const std::vector<double> &b, double epsilon = 1e-16, int max_iteration = 1000,
+                                          const std::vector<double> &initialize = std::vector<double>())
+    {
+        sync_device();
+        std::vector<double> x(b.size(), 0.0);
+        ccp_gs_report rep{};
+        ccp::throw_on(ccp_csr_conjugate_gradient(dev_, b.data(), initialize.empty() ? nullptr : initialize.data(), x.data(),
+                                                 epsilon, max_iteration, &rep),
+                      "ccp_csr_conjugate_gradient");
         last_report_ = rep;
         return x;
     }

@@ -97,6 +97,14 @@ int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *
                          double epsilon, int32_t max_iteration, int32_t check_every,
                          int32_t ordering, ccp_gs_report *report);
 
+/* SparseMatrix::conjugateGradient(b, epsilon, max_iteration, initialize) (sparse-matrix.h:396-434)
+ * — the solver the blend call sites use today (PhotoMontage.cpp:613, hw8_pa.cc:972).
+ * init == NULL starts from 0 (:397).  Stops when sqrt(r'r) < epsilon (:425) or after
+ * max_iteration iterations.  report->last_l1_step carries sqrt(r'r) of the last update.
+ * Reductions are deterministic but tree-ordered: iterates match the reference to rounding. */
+int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, double *x_out,
+                               double epsilon, int32_t max_iteration, ccp_gs_report *report);
+
 /* SparseMatrix::applyToVector(in, out) (sparse-matrix.h:382-393). in: n_cols, out: n_rows. */
 int ccp_csr_apply_to_vector(ccp_csr *m, const double *in, double *out);
 
@@ -187,6 +195,12 @@ int ccp_grid_halo_refreshed(ccp_grid *g);
  * report: array of `channels` entries (may be NULL).  Single-block handles only. */
 int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration,
                           int32_t check_every, ccp_gs_report *report);
+
+/* conjugateGradient (sparse-matrix.h:396-434) on the resident system, matrix-free, channel by
+ * channel; the resident x is the initial guess (ccp_grid_fill_x(g, 0) for the reference default,
+ * ccp_grid_set_x_u8 for the composite start of PhotoMontage.cpp:599-610).  report: `channels`
+ * entries (may be NULL).  Single-block handles only. */
+int ccp_grid_conjugate_gradient(ccp_grid *g, double epsilon, int32_t max_iteration, ccp_gs_report *report);
 
 /* Per-channel sums over the OWNED rows: rr = sum (b - A x)^2, bb = sum b^2 (2*channels
  * doubles: rr[0..ch), bb[0..ch)).  Synchronises. */

@@ -111,6 +111,16 @@ class OracleMatrix:
             raise MemoryError("orc_gauss_seidel failed")
         return x, it.value, eps.value
 
+    def conjugate_gradient(self, b, epsilon: float = 1e-16, max_iteration: int = 1000, init=None):
+        b = _f64(b)
+        x = np.empty(self.n_cols, dtype=np.float64)
+        it = C.c_int(0)
+        ia = None if init is None else _f64(init)
+        rc = self._lib.orc_conjugate_gradient(C.byref(self._m), b, _opt(ia), epsilon, max_iteration, x, C.byref(it))
+        if rc != 0:
+            raise MemoryError("orc_conjugate_gradient failed")
+        return x, it.value
+
     def apply_to_vector(self, v) -> np.ndarray:
         v = _f64(v)
         out = np.zeros(self.n_rows, dtype=np.float64)
@@ -136,6 +146,7 @@ class Oracle:
         L.orc_at.restype = C.c_double
         L.orc_gauss_seidel.argtypes = [MP, _f64p, C.c_void_p, C.c_double, C.c_int, _f64p,
                                        C.POINTER(C.c_int), C.POINTER(C.c_double)]
+        L.orc_conjugate_gradient.argtypes = [MP, _f64p, C.c_void_p, C.c_double, C.c_int, _f64p, C.POINTER(C.c_int)]
         L.orc_apply_to_vector.argtypes = [MP, _f64p, _f64p]
         L.orc_apply_to_vector.restype = None
         L.orc_rel_residual.argtypes = [MP, _f64p, _f64p]

@@ -227,6 +227,39 @@ void orc_apply_to_vector(const orc_matrix *m, const double *in, double *out)
     }
 }
 
+/* sparse-matrix.h:396-434 */
+int orc_conjugate_gradient(const orc_matrix *m, const double *b, const double *init,
+                           double epsilon, int max_iteration, double *x, int *iters_done)
+{
+    const int64_t n = m->n_cols;
+    double *r = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+    double *r1 = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+    double *p = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+    double *ap = (double *)malloc(sizeof(double) * (size_t)(n ? n : 1));
+    if (!r || !r1 || !p || !ap) { free(r); free(r1); free(p); free(ap); return -1; }
+    for (int64_t i = 0; i < n; ++i) x[i] = init ? init[i] : 0.0;        /* :397,401-403 */
+    orc_apply_to_vector(m, x, r);                                       /* :406 r = A x   */
+    orc_vecsub(b, r, r, n);                                             /* :407 r = b - r */
+    memcpy(p, r, sizeof(double) * (size_t)n);                           /* :410 */
+    int cnt = 0;
+    while (cnt < max_iteration) {
+        const double rlen = orc_veclen2(r, n);                          /* :418 */
+        orc_apply_to_vector(m, p, ap);                                  /* :419 */
+        const double alpha = rlen / orc_dot_prod(p, ap, n);             /* :420 */
+        orc_vecadd_scaled(x, p, alpha, x, n);                           /* :421 */
+        orc_vecadd_scaled(r, ap, -alpha, r1, n);                        /* :422 */
+        const double r1len = orc_veclen2(r1, n);                        /* :423 */
+        if (sqrt(r1len) < epsilon) break;                               /* :425 */
+        const double beta = r1len / rlen;                               /* :426 */
+        orc_vecadd_scaled(r1, p, beta, p, n);                           /* :427 */
+        double *t = r1; r1 = r; r = t;                                  /* :429 swap */
+        ++cnt;
+    }
+    free(r); free(r1); free(p); free(ap);
+    if (iters_done) *iters_done = cnt;
+    return 0;
+}
+
 double orc_rel_residual(const orc_matrix *m, const double *b, const double *x)
 {
     const int64_t n = m->n_rows;

@@ -63,6 +63,12 @@ int orc_gauss_seidel(const orc_matrix *m, const double *b, const double *x0,
                      double epsilon, int max_iteration,
                      double *x, int *iters_done, double *last_eps);
 
+/* sparse-matrix.h:396-434 (conjugateGradient with optional initial guess; the solver the blend
+ * call sites use today, PhotoMontage.cpp:613 / hw8_pa.cc:972).  init == NULL starts from 0.
+ * Outputs x (n_cols entries) and the number of completed iterations (`cnt`). */
+int orc_conjugate_gradient(const orc_matrix *m, const double *b, const double *init,
+                           double epsilon, int max_iteration, double *x, int *iters_done);
+
 /* sparse-matrix.h:382-393 (applyToVector). */
 void orc_apply_to_vector(const orc_matrix *m, const double *in, double *out);
 

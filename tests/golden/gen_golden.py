@@ -223,10 +223,28 @@ def gen_assembly(O):
     save("assembly.npz", **arrays)
 
 
+def gen_cg(R):
+    """conjugateGradient with / without initial guess (sparse-matrix.h:396-434) on Poisson 17x13
+    and on the irregular mask."""
+    W, H = 17, 13
+    v, c, r = synth.poisson_csr(W, H)
+    b, xt = synth.poisson_system(W, H, 1234)
+    init = synth.x_true(W * H, 7)
+    arrays = dict(W=np.int32(W), H=np.int32(H), b=b, init=init, x_true=xt)
+    for k in (1, 5, 25):
+        arrays[f"x_cg_k{k}"] = R.cg_csr(v, c, r, b, 1e-10, k)
+        arrays[f"x_cg_init_k{k}"] = R.cg_csr(v, c, r, b, 1e-10, k, init)
+    arrays["x_cg_converged"] = R.cg_csr(v, c, r, b, 1e-8, 5000)
+    save("cg_17x13.npz", **arrays)
+
+
 def main():
     oracle.build()
     R = oracle.Ref()
     O = oracle.Oracle()
+    if len(sys.argv) > 1 and sys.argv[1] == "cg":
+        gen_cg(R)
+        return
     gen_known_answer(R)
     gen_insert_scenario(R)
     for (W, H) in ((8, 8), (17, 13), (64, 64)):
@@ -234,6 +252,7 @@ def main():
     gen_mask(R, O)
     gen_slack_ingest(R)
     gen_assembly(O)
+    gen_cg(R)
 
 
 if __name__ == "__main__":

@@ -146,3 +146,54 @@ def test_config0_512x512_lexicographic_bit_exact(capi, orc):
     assert rep.iterations == 20 and np.array_equal(x, want)
     assert x[-1] == 1.0
     m.close()
+
+
+@pytest.mark.parametrize("name", ["poisson_8x8.npz", "poisson_17x13.npz", "poisson_64x64.npz"])
+def test_conjugate_gradient_vs_oracle(capi, orc, golden, name):
+    """conjugateGradient with and without the composite-style initial guess (sparse-matrix.h:396-434,
+    call site PhotoMontage.cpp:613).  Tree-ordered reductions: tolerance 1e-9 relative L2 while
+    the iteration is far from the rounding floor (north-star bar: 1e-5)."""
+    from coursecomputationalphotography_amd import synth
+    d = golden(name)
+    W, H = int(d["W"]), int(d["H"])
+    v, c, r = synth.poisson_csr(W, H)
+    om = orc.from_csr(v, c, r)
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    init = synth.x_true(W * H, 7)
+    for k in (1, 5, 25):
+        for ini in (None, init):
+            want, it = om.conjugate_gradient(d["b"], 1e-10, k, ini)
+            x, rep = m.conjugate_gradient(d["b"], 1e-10, k, ini)
+            assert rep.iterations == it == k
+            assert rel_l2(x, want) <= 1e-9, (k, rel_l2(x, want))
+    # run to convergence: same stop iteration (+-1) and the true solution (pixel n-1 is free: empty row)
+    want, it = om.conjugate_gradient(d["b"], 1e-8, 5000)
+    x, rep = m.conjugate_gradient(d["b"], 1e-8, 5000)
+    assert rep.converged == 1 and abs(rep.iterations - it) <= 2
+    assert np.abs(x[:-1] - d["x_true"][:-1]).max() < 1e-6
+    m.close()
+
+
+def test_known_answer_cg(capi, orc, golden):
+    d = golden("known_answer_4x4.npz")
+    _, vals, cols, rb, nnz = dense_to_vector_arrays(orc, d["A"])
+    m = capi.CsrMatrix().upload(4, 4, vals, cols, rb, nnz)
+    x, rep = m.conjugate_gradient(d["b"], 1e-16, 1000)          # main6.cc:251 (lab3 defaults differ only in eps)
+    assert np.allclose(x, d["cg_final"], atol=1e-12) and np.allclose(x, [1, 2, -1, 1], atol=1e-12)
+    m.close()
+
+
+def test_conjugate_gradient_reference_fixture(capi, golden):
+    """GPU conjugateGradient against the compiled reference's iterates (fixture)."""
+    from coursecomputationalphotography_amd import synth
+    d = golden("cg_17x13.npz")
+    v, c, r = synth.poisson_csr(17, 13)
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    for k in (1, 5, 25):
+        x, _ = m.conjugate_gradient(d["b"], 1e-10, k)
+        assert rel_l2(x, d[f"x_cg_k{k}"]) <= 1e-9
+        x, _ = m.conjugate_gradient(d["b"], 1e-10, k, d["init"])
+        assert rel_l2(x, d[f"x_cg_init_k{k}"]) <= 1e-9
+    x, rep = m.conjugate_gradient(d["b"], 1e-8, 5000)
+    assert rep.converged == 1 and rel_l2(x[:-1], d["x_cg_converged"][:-1]) <= 1e-7
+    m.close()
