@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "ccp/sparse-matrix.h"
+#include "ccp/photomontage.h"
 
 using Dense = std::vector<std::vector<double>>;
 
@@ -133,6 +134,55 @@ static int solve_file(const char *in, const char *out)
     return 0;
 }
 
+// blend <in.bin> <out.bin>: header {W, H, K, iterations, fast_init}, K images HxWx3 u8, label HxW u8.
+// Route 1: ccp::BuildSolveGradientFusion (everything on device).  Route 2: the reference's own
+// structure — GradientAt loop on the host (PhotoMontage.cpp:419-425) then ccp::SolveChannel per
+// channel (:429-433).  Both must give the same image; route 1 is written to out.bin.
+static int blend_file(const char *in, const char *out)
+{
+    FILE *f = std::fopen(in, "rb");
+    if (!f) return 20;
+    int hdr[5];
+    if (std::fread(hdr, sizeof(int), 5, f) != 5) return 21;
+    const int W = hdr[0], H = hdr[1], K = hdr[2], iters = hdr[3], fast = hdr[4];
+    std::vector<std::vector<uint8_t>> imgs(K, std::vector<uint8_t>((size_t)W * H * 3));
+    for (auto &im : imgs)
+        if (std::fread(im.data(), 1, im.size(), f) != im.size()) return 22;
+    std::vector<uint8_t> label((size_t)W * H);
+    if (std::fread(label.data(), 1, label.size(), f) != label.size()) return 23;
+    std::fclose(f);
+    std::vector<ccp::ImageView> views;
+    for (auto &im : imgs) views.push_back(ccp::ImageView{im.data(), H, W, 3, (size_t)W * 3});
+    ccp::ImageView lab{label.data(), H, W, 1, (size_t)W};
+    std::vector<uint8_t> res1((size_t)W * H * 3, 0), res2((size_t)W * H * 3, 0);
+    ccp::ImageView r1{res1.data(), H, W, 3, (size_t)W * 3}, r2{res2.data(), H, W, 3, (size_t)W * 3};
+    ccp::BuildSolveGradientFusion(views, lab, r1, iters, fast != 0);
+    // route 2
+    std::vector<float> gx((size_t)W * H * 3, 0.f), gy((size_t)W * H * 3, 0.f);
+    std::vector<uint8_t> composite((size_t)W * H * 3);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const uint8_t *im = imgs[label[(size_t)y * W + x]].data();
+            for (int c = 0; c < 3; ++c) {
+                composite[((size_t)y * W + x) * 3 + c] = im[((size_t)y * W + x) * 3 + c];
+                if (y < H - 1 && x < W - 1) {
+                    gx[((size_t)y * W + x) * 3 + c] = (float)((int)im[((size_t)y * W + x + 1) * 3 + c] - (int)im[((size_t)y * W + x) * 3 + c]);
+                    gy[((size_t)y * W + x) * 3 + c] = (float)((int)im[((size_t)(y + 1) * W + x) * 3 + c] - (int)im[((size_t)y * W + x) * 3 + c]);
+                }
+            }
+        }
+    ccp::ImageView vgx{gx.data(), H, W, 3, (size_t)W * 3 * sizeof(float)}, vgy{gy.data(), H, W, 3, (size_t)W * 3 * sizeof(float)};
+    ccp::ImageView comp{composite.data(), H, W, 3, (size_t)W * 3};
+    for (int c = 0; c < 3; ++c)
+        ccp::SolveChannel(c, imgs[0][c], vgx, vgy, r2, iters, fast ? &comp : nullptr);
+    if (res1 != res2) { std::fprintf(stderr, "SolveChannel route differs from BuildSolveGradientFusion\n"); return 24; }
+    FILE *o = std::fopen(out, "wb");
+    if (!o) return 25;
+    std::fwrite(res1.data(), 1, res1.size(), o);
+    std::fclose(o);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     try {
@@ -140,6 +190,7 @@ int main(int argc, char **argv)
         if (mode == "host") return host_checks();
         if (mode == "known") return known_answer();
         if (mode == "gs" && argc == 4) return solve_file(argv[2], argv[3]);
+        if (mode == "blend" && argc == 4) return blend_file(argv[2], argv[3]);
         std::fprintf(stderr, "usage: facade_driver host|known|gs in out\n");
         return 64;
     } catch (const std::exception &e) {
