@@ -59,6 +59,10 @@ struct ccp_csr {
     DevBuf<CgState> cg_state;
     DevBuf<CsrSolveState> state;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // structured-matrix detection: -1 unknown, 0 not the SolveChannel Poisson matrix, else W
+    int poisson_w = -1, poisson_h = 0;
+    ccp_grid *grid = nullptr;              // matrix-free twin used when the matrix is that Poisson matrix
+    bool allow_structured = true;
 };
 
 namespace {
@@ -211,6 +215,54 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
     return CCP_OK;
 }
 
+// Is this exactly the matrix SolveChannel assembles (closed form) for some W x H?
+// Row 0 of that matrix is [3 @0, -1 @1, -1 @W], which fixes W; then every row is compared.
+void detect_poisson(ccp_csr *m)
+{
+    if (m->poisson_w >= 0) return;
+    m->poisson_w = 0;
+    const int n = m->n_rows;
+    if (n < 4 || m->n_cols != n) return;
+    if (m->row_ptr[1] - m->row_ptr[0] != 3) return;
+    const int W = m->col[m->row_ptr[0] + 2];
+    if (W < 2 || n % W != 0) return;
+    const int H = n / W;
+    if (H < 2) return;
+    auto cell = [&](int x, int y) { return x >= 0 && y >= 0 && x < W - 1 && y < H - 1; };
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const int i = y * W + x;
+            const bool up = cell(x, y - 1), left = cell(x - 1, y), here = cell(x, y);
+            const int diag = (int)up + (int)left + 2 * (int)here + (i == 0 ? 1 : 0);
+            long k = m->row_ptr[i];
+            const long end = m->row_ptr[i + 1];
+            auto next_is = [&](int c, double v) {
+                if (k >= end || m->col[k] != c || m->val[k] != v) return false;
+                ++k;
+                return true;
+            };
+            if (up && !next_is(i - W, -1.0)) return;
+            if (left && !next_is(i - 1, -1.0)) return;
+            if (diag && !next_is(i, (double)diag)) return;
+            if (here && (!next_is(i + 1, -1.0) || !next_is(i + W, -1.0))) return;
+            if (k != end) return;
+        }
+    m->poisson_w = W;
+    m->poisson_h = H;
+}
+
+// The user colouring (if any) must be the grid's red-black colouring with pixel 0 red, because
+// that is the sweep order the matrix-free kernels implement.
+bool colouring_is_checkerboard(const ccp_csr *m)
+{
+    if (m->user_colour.empty()) return true;          // greedy colouring of the full grid IS the checkerboard
+    if (m->user_n_colours != 2) return false;
+    const int W = m->poisson_w;
+    for (int i = 0; i < m->n_rows; ++i)
+        if (m->user_colour[i] != (((i % W) + (i / W)) & 1)) return false;
+    return true;
+}
+
 int ensure_natural(ccp_csr *m)
 {
     if (m->natural.built) return CCP_OK;
@@ -285,6 +337,7 @@ int ccp_csr_destroy(ccp_csr *m)
     (void)hipSetDevice(m->device);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
+    if (m->grid) ccp_grid_destroy(m->grid);
     delete m;
     return CCP_OK;
 }
@@ -324,6 +377,11 @@ int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values,
     m->lexicographic.reset();
     m->user_colour.clear();
     m->user_n_colours = 0;
+    m->poisson_w = -1;
+    m->poisson_h = 0;
+    if (m->grid) ccp_grid_destroy(m->grid);
+    m->grid = nullptr;
+    if (const char *e = getenv("CCP_GS_STRUCTURED")) m->allow_structured = atoi(e) != 0;
     const size_t vec = (size_t)std::max(std::max(n_rows, n_cols), 2);
     CCP_TRY(m->x.alloc(vec));
     CCP_TRY(m->b.alloc(vec));
@@ -357,6 +415,24 @@ int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *
     if (!b || !x_out || check_every < 0) return CCP_ERR_BAD_ARG;
     if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;   // the reference asserts len(b) == n_cols and sizes x from b
     if (ordering != CCP_ORDER_LEXICOGRAPHIC && ordering != CCP_ORDER_MULTICOLOUR) return CCP_ERR_BAD_ARG;
+    if (ordering == CCP_ORDER_MULTICOLOUR && m->allow_structured) {
+        // The matrix SolveChannel builds (via Eigen, ConvertFromEigen) is recognised and solved
+        // matrix-free by the grid kernels: same sweep order, same arithmetic, same bits as the
+        // sliced-ELL path, ~20x its speed (temporally blocked sweep).
+        detect_poisson(m);
+        if (m->poisson_w > 0 && colouring_is_checkerboard(m)) {
+            if (!m->grid) {
+                ccp_grid_desc d{m->poisson_w, m->poisson_h, 1, 0, m->poisson_h, 0, m->device, 0};
+                CCP_TRY(ccp_grid_create(&d, &m->grid));
+            }
+            CCP_TRY(ccp_grid_set_stream(m->grid, m->stream));
+            CCP_TRY(ccp_grid_set_b_host(m->grid, 0, b, 0, m->poisson_h));
+            if (x0) CCP_TRY(ccp_grid_set_x_host(m->grid, 0, x0, 0, m->poisson_h));
+            else CCP_TRY(ccp_grid_fill_x(m->grid, 1.0));                       // sparse-matrix.h:352
+            CCP_TRY(ccp_grid_gauss_seidel(m->grid, epsilon, max_iteration, check_every, report));
+            return ccp_grid_get_x_host(m->grid, 0, x_out, 0, m->poisson_h);
+        }
+    }
     Schedule &sc = ordering == CCP_ORDER_MULTICOLOUR ? m->multicolour : m->lexicographic;
     CCP_TRY(ordering == CCP_ORDER_MULTICOLOUR ? ensure_multicolour(m) : ensure_lexicographic(m));
     const long n = m->n_rows;

@@ -92,7 +92,10 @@ int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours);
  * x0 == NULL starts from all-ones as the reference does (:352); a non-NULL x0 is the `init`
  * extension mirroring conjugateGradient's 4th argument (:396).  b, x_out: n_cols entries.
  * check_every: the L1-step stop rule (:356,376) is evaluated every check_every-th sweep
- * (1 = the reference's behaviour; 0 = never: exactly max_iteration sweeps). */
+ * (1 = the reference's behaviour; 0 = never: exactly max_iteration sweeps).
+ * With CCP_ORDER_MULTICOLOUR a matrix that is exactly the W x H Poisson matrix SolveChannel
+ * assembles (PhotoMontage.cpp:541-597) — and whose colouring, if given, is (x+y)&1 — is recognised
+ * at the first solve and swept by the matrix-free grid kernels: identical bits, far faster. */
 int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *x_out,
                          double epsilon, int32_t max_iteration, int32_t check_every,
                          int32_t ordering, ccp_gs_report *report);
