@@ -45,7 +45,7 @@ def parse():
     ap.add_argument("--height", type=int, default=16384)
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--iters-per-step", type=int, default=32)
-    ap.add_argument("--ghost", type=int, default=32, help="ghost rows per side (N>1); exchange every ghost/2 iterations")
+    ap.add_argument("--ghost", type=int, default=64, help="ghost rows per side (N>1); exchange every ghost/2 iterations")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo stages halos through the host (several ranks on one GPU, testing only)")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (testing with --backend gloo)")
