@@ -117,9 +117,9 @@ struct FusedCtx {
 };
 
 // One march step: newest row f, unrolled position i.  STEADY: every row the step touches is known
-// to be inside [m0, m1) and the finished row inside [ra, rb), so the step is straight-line code
-// (no scalar branches): the s_waitcnt pass can then count the loads in flight instead of
-// draining them, and that is what lets the D-rows-ahead prefetch actually overlap.
+// to be inside [m0, m1), so loads and row updates are straight-line code (the only scalar branch
+// left guards the store of the finished row): the s_waitcnt pass can then count the loads in
+// flight instead of draining them, and that is what lets the D-rows-ahead prefetch overlap.
 template <int T, bool BORDER, bool L1, int UNR, bool STEADY, int NT>
 __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], double (&br)[NT], double (&bk)[NT],
                                            double &acc, const FusedCtx &cx, const Geom &g, int f, int i)
@@ -183,7 +183,7 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
     {
         const int r = f - HS;
         const int sr = Win::slot(i, HS);
-        if ((STEADY || (r >= cx.ra && r < cx.rb)) && cx.col_store) {
+        if (r >= cx.ra && r < cx.rb && cx.col_store) {
             (cx.xout + (row_off(g, r, 0) + cx.jbase))[cx.lane] = wr[sr];
             (cx.xout + (row_off(g, r, 1) + cx.jbase))[cx.lane] = wk[sr];
         }
@@ -218,8 +218,8 @@ __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, dou
     // trip, so the colour parity of every unrolled row update is a compile-time constant
     const int base = cx.m0 - ((g.y0 + cx.m0) & 1);
     const int f_end = rb - 1 + HS;                      // last step: row rb-1 gets half-sweep HS
-    // steps f in [s_lo, s_hi] touch only existing rows and finish a row inside [ra, rb)
-    const int s_lo = max(ra + HS, cx.m0 + HS + 1), s_hi = min(cx.m1 - 1 - D, rb - 1 + HS);
+    // steps f in [s_lo, s_hi] touch only existing rows: r = f-h >= m0 for h <= HS+1, f+D < m1
+    const int s_lo = cx.m0 + HS + 1, s_hi = cx.m1 - 1 - D;
 
     double wr[NT], wk[NT], br[NT], bk[NT];              // x red/black, b red/black per window row
 #pragma unroll
