@@ -133,10 +133,12 @@ k_cg_direction(double *__restrict__ p, const double *__restrict__ r, long n, con
         p[i] = r[i] + beta * p[i];
 }
 
-// The loop.  `spmv(in, out)` enqueues out := A in on `stream` (all device pointers).
+// The loop.  `spmv(in, out)` enqueues out := A in on `stream` (all device pointers);
+// `spmv_dot(in, out)` does the same and leaves block partials of in'(A in) in `partial`,
+// returning how many (0 = not fused: a separate dot pass runs).
 // x: initial guess on entry, solution on exit.  r, p, ap: scratch vectors of n doubles.
-template <typename Spmv>
-int cg_solve(Spmv &&spmv, const double *b, double *x, double *r, double *p, double *ap, long n, double epsilon,
+template <typename Spmv, typename SpmvDot>
+int cg_solve(Spmv &&spmv, SpmvDot &&spmv_dot, const double *b, double *x, double *r, double *p, double *ap, long n, double epsilon,
              int max_iteration, CgState *st_dev, double *partial, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
              ccp_gs_report *report)
 {
@@ -154,9 +156,13 @@ int cg_solve(Spmv &&spmv, const double *b, double *x, double *r, double *p, doub
     while (active && issued < max_iteration) {
         const int batch = std::min(16, max_iteration - issued);
         for (int k = 0; k < batch; ++k) {
-            CCP_TRY(spmv(p, ap));                                            // Ap = A p     (:419)
-            hipLaunchKernelGGL(k_cg_dot, dim3(blocks), dim3(kBlock), 0, stream, p, ap, n, partial, st_dev);
-            hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kBlock), 0, stream, partial, blocks, st_dev);
+            int dot_blocks = 0;
+            CCP_TRY(spmv_dot(p, ap, &dot_blocks));                           // Ap = A p (:419) [+ p'Ap partials]
+            if (dot_blocks == 0) {
+                hipLaunchKernelGGL(k_cg_dot, dim3(blocks), dim3(kBlock), 0, stream, p, ap, n, partial, st_dev);
+                dot_blocks = blocks;
+            }
+            hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kBlock), 0, stream, partial, dot_blocks, st_dev);
             hipLaunchKernelGGL(k_cg_update, dim3(blocks), dim3(kBlock), 0, stream, x, p, r, ap, n, partial, st_dev);
             hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(kBlock), 0, stream, partial, blocks, epsilon, st_dev);
             hipLaunchKernelGGL(k_cg_direction, dim3(blocks), dim3(kBlock), 0, stream, p, r, n, st_dev);

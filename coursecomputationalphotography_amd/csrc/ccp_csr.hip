@@ -542,7 +542,14 @@ int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, 
         hipLaunchKernelGGL((k_sell_apply<0>), dim3(spmv_blocks), dim3(kBlock), 0, s, view, n_slices, in, out, in, m->partial.p);
         return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
     };
-    CCP_TRY(cg_solve(spmv, m->b.p, m->x.p, m->tmp.p, m->cg_p.p, m->cg_ap.p, n, epsilon, max_iteration, m->cg_state.p,
+    auto spmv_dot = [&](const double *in, double *out, int *n_partials) -> int {
+        *n_partials = 0;
+        if (n_slices == 0) return CCP_OK;
+        hipLaunchKernelGGL((k_sell_apply<2>), dim3(spmv_blocks), dim3(kBlock), 0, s, view, n_slices, in, out, in, m->partial.p);
+        *n_partials = (int)spmv_blocks;
+        return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
+    };
+    CCP_TRY(cg_solve(spmv, spmv_dot, m->b.p, m->x.p, m->tmp.p, m->cg_p.p, m->cg_ap.p, n, epsilon, max_iteration, m->cg_state.p,
                      m->partial.p, s, m->ev0, m->ev1, report));
     if (n) CCP_HIP(hipMemcpyAsync(x_out, m->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
     CCP_HIP(hipStreamSynchronize(s));

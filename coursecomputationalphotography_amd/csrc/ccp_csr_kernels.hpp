@@ -64,7 +64,8 @@ k_sell_gs(SellView m, int s_first, int s_last, double *__restrict__ x, const dou
 }
 
 // out[row] = sum values*in[col] in storage order (applyToVector, sparse-matrix.h:382-393).
-// MODE 0: store; MODE 1: partial sums of (b - Ax)^2 and b^2.
+// MODE 0: store; MODE 1: partial sums of (b - Ax)^2 and b^2; MODE 2: store and one partial sum of
+// in'(A in) per block (p'Ap of conjugateGradient fused into the SpMV).
 template <int MODE>
 __global__ void __launch_bounds__(kBlock)
 k_sell_apply(SellView m, int n_slices, const double *__restrict__ in, double *__restrict__ out,
@@ -86,6 +87,9 @@ k_sell_apply(SellView m, int n_slices, const double *__restrict__ in, double *__
         }
         if (MODE == 0) {
             out[row] = sum;
+        } else if (MODE == 2) {
+            out[row] = sum;
+            rr = in[row] * sum;
         } else {
             const double bv = b[row];
             const double r = bv - sum;
@@ -100,6 +104,10 @@ k_sell_apply(SellView m, int n_slices, const double *__restrict__ in, double *__
             partial[2 * (long)blockIdx.x] = t0;
             partial[2 * (long)blockIdx.x + 1] = t1;
         }
+    }
+    if (MODE == 2) {
+        const double t0 = block_sum(rr, scratch);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t0;
     }
 }
 

@@ -632,7 +632,12 @@ int ccp_grid_conjugate_gradient(ccp_grid *g, double epsilon, int32_t max_iterati
             hipLaunchKernelGGL((k_apply<2, 0>), grid, dim3(kBlock), 0, s, in, out, out, geo, 0, g->partial.p);
             return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
         };
-        CCP_TRY(cg_solve(spmv, g->b.p + (long)ch * n, g->x.p + (long)ch * n, g->cg_r.p, g->cg_p.p, g->cg_ap.p, n, epsilon,
+        auto spmv_dot = [&](const double *in, double *out, int *n_partials) -> int {
+            hipLaunchKernelGGL((k_apply<2, 2>), grid, dim3(kBlock), 0, s, in, out, out, geo, 0, g->partial.p);
+            *n_partials = (int)(grid.x * grid.y * grid.z);
+            return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
+        };
+        CCP_TRY(cg_solve(spmv, spmv_dot, g->b.p + (long)ch * n, g->x.p + (long)ch * n, g->cg_r.p, g->cg_p.p, g->cg_ap.p, n, epsilon,
                          max_iteration, g->cg_state.p, g->partial.p, s, g->ev0, g->ev1, report ? report + ch : nullptr));
     }
     return CCP_OK;

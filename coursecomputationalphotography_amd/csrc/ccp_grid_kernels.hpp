@@ -269,6 +269,8 @@ k_check(const double *__restrict__ partial0, long blocks0, const double *__restr
 // ---------------------------------------------------------------------------------------------
 // SpMV-shaped kernels on the same layout.  One thread per CPT half-columns of one (row, colour).
 // MODE 0: b := A x (applyToVector).  MODE 1: partial sums of (b - A x)^2 and b^2 (residual).
+// MODE 2: b := A x and one partial sum of x'(A x) per block (the p'Ap of conjugateGradient,
+// sparse-matrix.h:419-420, fused into the SpMV pass).
 // grid = (ceil(pitch/(kBlock*CPT)), rows, channels*2); rows l in [l_lo, l_hi).
 template <int CPT, int MODE>
 __global__ void __launch_bounds__(kBlock)
@@ -307,6 +309,9 @@ k_apply(const double *__restrict__ x, double *__restrict__ bw, const double *__r
                 const double ax = apply_row(s, own[k], up[k], left, right, dn[k]);
                 if (MODE == 0) {
                     bw[at + k] = ax;
+                } else if (MODE == 2) {
+                    bw[at + k] = ax;
+                    rr += own[k] * ax;
                 } else {
                     const double bv = br[at + k];
                     const double r = bv - ax;          // vecsub(b, Ax) (sparse-matrix.h:75-79)
@@ -324,6 +329,11 @@ k_apply(const double *__restrict__ x, double *__restrict__ bw, const double *__r
             partial[2 * blk] = t0;
             partial[2 * blk + 1] = t1;
         }
+    }
+    if (MODE == 2) {
+        const double t0 = block_sum(rr, scratch);
+        if (threadIdx.x == 0)
+            partial[((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = t0;
     }
 }
 
