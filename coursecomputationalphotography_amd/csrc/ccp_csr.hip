@@ -22,6 +22,8 @@ struct Schedule {
     int n_slices = 0;
     DevBuf<long> slice_off;
     DevBuf<int> slice_width, slice_row0, slice_rows, cols, perm;
+    DevBuf<int> group_ptr_dev;           // group_slice_ptr on the device (one-workgroup solver)
+    int max_group_slices = 0;
     DevBuf<double> vals;
     void reset()
     {
@@ -30,7 +32,8 @@ struct Schedule {
         group_slice_ptr.clear();
         group_block_off.clear();
         slice_off.release(); slice_width.release(); slice_row0.release(); slice_rows.release();
-        cols.release(); perm.release(); vals.release();
+        cols.release(); perm.release(); vals.release(); group_ptr_dev.release();
+        max_group_slices = 0;
     }
     SellView view() const
     {
@@ -63,6 +66,7 @@ struct ccp_csr {
     int poisson_w = -1, poisson_h = 0;
     ccp_grid *grid = nullptr;              // matrix-free twin used when the matrix is that Poisson matrix
     bool allow_structured = true;
+    bool allow_one_block = true;           // CCP_GS_ONE_BLOCK=0: always one launch per group
 };
 
 namespace {
@@ -210,6 +214,10 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
     CCP_TRY(upload_vec(sc.cols, cols, m->stream));
     CCP_TRY(upload_vec(sc.vals, vals, m->stream));
     CCP_TRY(upload_vec(sc.perm, perm, m->stream));
+    CCP_TRY(upload_vec(sc.group_ptr_dev, sc.group_slice_ptr, m->stream));
+    sc.max_group_slices = 0;
+    for (int g = 0; g < n_groups; ++g)
+        sc.max_group_slices = std::max(sc.max_group_slices, sc.group_slice_ptr[g + 1] - sc.group_slice_ptr[g]);
     CCP_HIP(hipStreamSynchronize(m->stream));      // host vectors die at scope exit
     sc.built = true;
     return CCP_OK;
@@ -382,6 +390,7 @@ int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values,
     if (m->grid) ccp_grid_destroy(m->grid);
     m->grid = nullptr;
     if (const char *e = getenv("CCP_GS_STRUCTURED")) m->allow_structured = atoi(e) != 0;
+    if (const char *e = getenv("CCP_GS_ONE_BLOCK")) m->allow_one_block = atoi(e) != 0;
     const size_t vec = (size_t)std::max(std::max(n_rows, n_cols), 2);
     CCP_TRY(m->x.alloc(vec));
     CCP_TRY(m->b.alloc(vec));
@@ -463,6 +472,16 @@ int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *
     double *eps_accum = reinterpret_cast<double *>(reinterpret_cast<char *>(m->state.p) + offsetof(CsrSolveState, eps_accum));
     int issued = 0;
     bool any_active = (10.0 > epsilon) && max_iteration > 0 && n > 0;
+    // narrow groups (<= 1024 rows: level schedules of grids up to ~1000 px wide, small matrices): the
+    // whole solve in one workgroup; wider groups keep one launch per group (one CU cannot feed them)
+    const bool one_block = m->allow_one_block && sc.n_groups > 0 && sc.max_group_slices <= 16;
+    if (any_active && one_block) {
+        hipLaunchKernelGGL(k_sell_gs_one_block, dim3(1), dim3(kSerialBlock), 0, s, view, sc.group_ptr_dev.p, sc.n_groups, m->x.p,
+                           m->b.p, m->state.p, epsilon, max_iteration, check_every);
+        CCP_HIP(hipGetLastError());
+        issued = max_iteration;
+        any_active = false;
+    }
     while (any_active && issued < max_iteration) {
         int checks = 0;
         while (issued < max_iteration && checks < 8) {

@@ -15,6 +15,15 @@
 
 namespace ccp {
 
+struct CsrSolveState {
+    int active;
+    int converged;
+    int iterations;
+    int pad;
+    double eps_accum;     // running sum of the current checked sweep
+    double last_eps;
+};
+
 struct SellView {
     const long *__restrict__ slice_off;    // [n_slices] first entry of the slice
     const int *__restrict__ slice_width;   // [n_slices] entries per row in the slice
@@ -62,6 +71,18 @@ k_sell_gs(SellView m, int s_first, int s_last, double *__restrict__ x, const dou
         if (threadIdx.x == 0) partial[blockIdx.x] = t;
     }
 }
+
+// Whole solve in ONE workgroup: all groups (levels / colours) of all sweeps, __syncthreads()
+// between groups, stop rule evaluated in the kernel.  For schedules whose groups are narrow —
+// the level schedule of the lexicographic order has W+H-1 levels of <= min(W,H) rows on a grid —
+// one launch per group costs ~5 us each (4.8 ms per 512x512 sweep); here a group costs a barrier.
+// Visibility: all waves of a workgroup share the CU's L1 and __syncthreads() is a workgroup-scope
+// release/acquire, so rows written in one group are seen by the next.
+constexpr int kSerialBlock = 1024;
+__global__ void __launch_bounds__(kSerialBlock)
+k_sell_gs_one_block(SellView m, const int *__restrict__ group_slice_ptr, int n_groups, double *__restrict__ x,
+                    const double *__restrict__ b, CsrSolveState *__restrict__ st, double epsilon, int max_iteration,
+                    int check_every);
 
 // out[row] = sum values*in[col] in storage order (applyToVector, sparse-matrix.h:382-393).
 // MODE 0: store; MODE 1: partial sums of (b - Ax)^2 and b^2; MODE 2: store and one partial sum of
@@ -138,15 +159,6 @@ k_reduce_to(const double *__restrict__ partial, long count, long stride, double 
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + t : t;
 }
 
-struct CsrSolveState {
-    int active;
-    int converged;
-    int iterations;
-    int pad;
-    double eps_accum;     // running sum of the current checked sweep
-    double last_eps;
-};
-
 __global__ void k_csr_check(CsrSolveState *__restrict__ st, double epsilon, int sweep_index)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0 && st->active) {
@@ -158,6 +170,139 @@ __global__ void k_csr_check(CsrSolveState *__restrict__ st, double epsilon, int 
             st->iterations = sweep_index;
         }
     }
+}
+
+// What a lane needs for one row that does NOT depend on x: fetched for the NEXT group while the
+// current one is still being swept, so after the barrier only the x gathers are on the
+// critical path (one dependent memory latency per group instead of three).
+constexpr int kPrefetchWidth = 8;
+struct RowAhead {
+    int row;            // -1: lane idle in this slice
+    int width;          // entries per row in the slice; > kPrefetchWidth: cols/vals not prefetched
+    long off;
+    double bval;
+    int c[kPrefetchWidth];
+    double v[kPrefetchWidth];
+};
+
+__device__ __forceinline__ void fetch_row_ahead(const SellView &m, const double *__restrict__ b, int s, int lane, RowAhead &ra)
+{
+    ra.row = -1;
+    ra.width = 0;
+    if (lane < m.slice_rows[s]) {
+        ra.row = m.slice_row0[s] + lane;
+        ra.off = m.slice_off[s] + lane;
+        ra.width = m.slice_width[s];
+        ra.bval = b[ra.row];
+        if (ra.width <= kPrefetchWidth) {
+#pragma unroll
+            for (int e = 0; e < kPrefetchWidth; ++e) {
+                const bool on = e < ra.width;
+                ra.c[e] = on ? m.cols[ra.off + (long)e * kWave] : -1;
+                ra.v[e] = on ? m.vals[ra.off + (long)e * kWave] : 0.0;
+            }
+        }
+    }
+}
+
+__global__ void __launch_bounds__(kSerialBlock)
+k_sell_gs_one_block(SellView m, const int *__restrict__ group_slice_ptr, int n_groups, double *__restrict__ x,
+                    const double *__restrict__ b, CsrSolveState *__restrict__ st, double epsilon, int max_iteration,
+                    int check_every)
+{
+    __shared__ double scratch[kSerialBlock / kWave];
+    __shared__ int s_go;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x / kWave;
+    constexpr int kWaves = kSerialBlock / kWave;
+    int done = 0;
+    // one row update; the x gathers are the only loads left when `ra` was prefetched
+    auto update = [&](const RowAhead &ra, bool check, double &acc) {
+        if (ra.row < 0) return;
+        double a_ii = 0.0, sigma = 0.0;
+        if (ra.width <= kPrefetchWidth) {
+#pragma unroll
+            for (int e = 0; e < kPrefetchWidth; ++e) {
+                if (ra.c[e] == ra.row) a_ii = ra.v[e];
+                else if (ra.c[e] >= 0) sigma += ra.v[e] * x[ra.c[e]];
+            }
+        } else {
+            for (int e = 0; e < ra.width; ++e) {
+                const int c = m.cols[ra.off + (long)e * kWave];
+                const double v = m.vals[ra.off + (long)e * kWave];
+                if (c == ra.row) a_ii = v;
+                else if (c >= 0) sigma += v * x[c];
+            }
+        }
+        if (a_ii != 0.0) {
+            const double nv = (ra.bval - sigma) / a_ii;
+            if (check) acc += fabs(nv - x[ra.row]);
+            x[ra.row] = nv;
+        }
+    };
+    RowAhead ahead;
+    ahead.row = -1;
+    ahead.width = 0;
+    int ahead_slice = -1;
+    {
+        const int s = group_slice_ptr[0] + wave;
+        if (n_groups > 0 && s < group_slice_ptr[1]) {
+            fetch_row_ahead(m, b, s, lane, ahead);
+            ahead_slice = s;
+        }
+    }
+    for (int k = 1; k <= max_iteration; ++k) {
+        const bool check = check_every > 0 && (k % check_every) == 0;
+        double acc = 0.0;
+        for (int g = 0; g < n_groups; ++g) {
+            const int s0 = group_slice_ptr[g], s1 = group_slice_ptr[g + 1];
+            RowAhead cur = ahead;
+            const int cur_slice = ahead_slice;
+            // prefetch this wave's first slice of the next group (next sweep's first group at the end)
+            {
+                const int gn = (g + 1 < n_groups) ? g + 1 : 0;
+                const int s = group_slice_ptr[gn] + wave;
+                ahead.row = -1;
+                ahead_slice = -1;
+                if (s < group_slice_ptr[gn + 1]) {
+                    fetch_row_ahead(m, b, s, lane, ahead);
+                    ahead_slice = s;
+                }
+            }
+            for (int s = s0 + wave; s < s1; s += kWaves) {
+                if (s == cur_slice) {
+                    update(cur, check, acc);
+                } else {
+                    RowAhead now;
+                    fetch_row_ahead(m, b, s, lane, now);
+                    update(now, check, acc);
+                }
+            }
+            __syncthreads();
+        }
+        done = k;
+        if (check) {
+            double v = wave_sum(acc);
+            if (lane == 0) scratch[wave] = v;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                double eps = 0.0;
+                for (int w = 0; w < kWaves; ++w) eps += scratch[w];
+                st->last_eps = eps;
+                int go = 1;
+                if (!(eps > epsilon)) {            // `while (eps > epsilon && ...)`, sparse-matrix.h:356
+                    st->active = 0;
+                    st->converged = 1;
+                    st->iterations = k;
+                    go = 0;
+                }
+                s_go = go;
+            }
+            __syncthreads();
+            if (!s_go) break;
+        }
+    }
+    if (threadIdx.x == 0 && st->active) st->iterations = done;
 }
 
 }  // namespace ccp
