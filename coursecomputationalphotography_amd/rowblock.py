@@ -78,6 +78,7 @@ class RowBlockSolver:
         self.block, self.rank, self.world, self.ghost, self.dist, self.group = block, rank, world, ghost, dist, group
         self.iters_per_exchange = ghost // 2
         self.since_exchange = 0
+        self._views = None
         if world > 1 and block.row_count < ghost:
             raise ValueError(f"row block of {block.row_count} rows is thinner than the ghost depth {ghost}")
 
@@ -87,19 +88,22 @@ class RowBlockSolver:
         blk, dist = self.block, self.dist
         if self.world > 1:
             x = blk.x_rows
-            C = x.shape[0]
-            gt, gb = blk.ghost_top, blk.ghost_bottom
-            own_lo, own_hi = gt, gt + blk.row_count
-            sends, recvs = [], []                       # (tensor view, peer)
-            for ch in range(C):
-                if self.rank > 0:          # upper neighbour: my top owned rows <-> my top ghosts
-                    n_send = self._peer_ghost_bottom(self.rank - 1)
-                    sends.append((x[ch, own_lo:own_lo + n_send], self.rank - 1))
-                    recvs.append((x[ch, 0:gt], self.rank - 1))
-                if self.rank < self.world - 1:
-                    n_send = self._peer_ghost_top(self.rank + 1)
-                    sends.append((x[ch, own_hi - n_send:own_hi], self.rank + 1))
-                    recvs.append((x[ch, own_hi:own_hi + gb], self.rank + 1))
+            if self._views is None:                     # the row views never change: build them once
+                C = x.shape[0]
+                gt, gb = blk.ghost_top, blk.ghost_bottom
+                own_lo, own_hi = gt, gt + blk.row_count
+                sends, recvs = [], []                   # (tensor view, peer)
+                for ch in range(C):
+                    if self.rank > 0:      # upper neighbour: my top owned rows <-> my top ghosts
+                        n_send = self._peer_ghost_bottom(self.rank - 1)
+                        sends.append((x[ch, own_lo:own_lo + n_send], self.rank - 1))
+                        recvs.append((x[ch, 0:gt], self.rank - 1))
+                    if self.rank < self.world - 1:
+                        n_send = self._peer_ghost_top(self.rank + 1)
+                        sends.append((x[ch, own_hi - n_send:own_hi], self.rank + 1))
+                        recvs.append((x[ch, own_hi:own_hi + gb], self.rank + 1))
+                self._views = (sends, recvs)
+            sends, recvs = self._views
             # gloo cannot move device memory: stage through host copies (CPU tests of the GPU
             # path with several ranks on one card; RCCL sends the device rows directly)
             staged = x.is_cuda and dist.get_backend(self.group) == "gloo"
