@@ -238,3 +238,42 @@ def test_poisson_matrix_is_recognised_and_swept_matrix_free(capi, orc, monkeypat
     x3, _ = m.gauss_seidel(b, 0.0, 5, check_every=0)
     assert np.array_equal(x3, want3)
     m.close()
+
+
+def test_edge_shapes(capi, orc):
+    """Degenerate inputs: 1x1 system, all-empty matrix, rectangular SpMV, zero iterations."""
+    m = capi.CsrMatrix().upload(1, 1, [5.0], [0], [0], [1])
+    x, rep = m.gauss_seidel([10.0], 1e-12, 50, ordering=capi.ORDER_LEXICOGRAPHIC)
+    assert x.tolist() == [2.0] and rep.converged == 1 and rep.iterations == 2     # 2nd sweep: step 0 <= eps
+    x, rep = m.gauss_seidel([10.0], 1e-12, 50, ordering=capi.ORDER_MULTICOLOUR)
+    assert x.tolist() == [2.0]
+    x, rep = m.gauss_seidel([10.0], 0.0, 0)                                        # max_iteration 0: start vector
+    assert x.tolist() == [1.0] and rep.iterations == 0
+    m.close()
+    # every row empty: a_ii == 0 everywhere -> all rows skipped, x stays 1.0, eps = 0 after one sweep
+    m = capi.CsrMatrix().upload(3, 3, [0.0], [0], [0, 0, 0], [0, 0, 0])
+    x, rep = m.gauss_seidel([1.0, 2.0, 3.0], 1e-6, 10, ordering=capi.ORDER_LEXICOGRAPHIC)
+    assert x.tolist() == [1.0, 1.0, 1.0] and rep.iterations == 1 and rep.converged == 1
+    assert m.apply_to_vector([4.0, 5.0, 6.0]).tolist() == [0.0, 0.0, 0.0]
+    m.close()
+    # rectangular matrix: applyToVector only (the reference's gaussSeidel needs a square one)
+    dense = np.array([[1.0, 0, 2, 0, 0], [0, 0, 0, 0, 3], [0, 4, 0, 0, 0]])
+    rows, cols = np.nonzero(dense)
+    om = orc.from_vector(rows, cols, dense[rows, cols])
+    v, c, rb, nnz, _ = om.storage()
+    m = capi.CsrMatrix().upload(3, 5, v, c, rb, nnz)
+    vin = np.array([1.0, 2, 3, 4, 5])
+    assert np.array_equal(m.apply_to_vector(vin), dense @ vin)
+    with pytest.raises(capi.CcpError) as e:
+        m.gauss_seidel(np.ones(5), 0.0, 1)
+    assert e.value.status == 6
+    m.close()
+    # bad arrays are rejected, not dereferenced
+    m = capi.CsrMatrix()
+    with pytest.raises(capi.CcpError) as e:
+        m.upload(2, 2, [1.0, 1.0], [0, 7], [0, 1], [1, 1])        # column 7 of a 2-column matrix
+    assert e.value.status == 1
+    with pytest.raises(capi.CcpError) as e:
+        m.gauss_seidel([1.0, 1.0], 0.0, 1)                          # nothing uploaded
+    assert e.value.status == 5
+    m.close()
