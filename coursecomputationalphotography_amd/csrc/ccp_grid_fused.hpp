@@ -266,7 +266,12 @@ k_fused_sweep(FusedParams P)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int sx = blockIdx.x * (kBlock / kWave) + wave;
     const int ch = blockIdx.z;
-    const int ra = P.st_lo + blockIdx.y * P.rows_per_chunk;
+    // Workgroups are dispatched in index order.  The waves of the first and the last chunk take
+    // the border-aware body, which runs ~2.6x longer at T=8: give the last chunk index 1 instead
+    // of the highest one so both start at the beginning and never form the tail of the launch.
+    int chunk = blockIdx.y;
+    if (gridDim.y > 2) chunk = blockIdx.y == 1 ? (int)gridDim.y - 1 : (blockIdx.y > 1 ? (int)blockIdx.y - 1 : 0);
+    const int ra = P.st_lo + chunk * P.rows_per_chunk;
     const int rb = min(ra + P.rows_per_chunk, P.st_hi);
     double acc = 0.0;
     const bool run = (P.active == nullptr) || (P.active[ch] != 0);   // a converged channel is frozen

@@ -13,6 +13,17 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "timeout: per-test time limit (pytest-timeout)")
+
+
+def pytest_collection_modifyitems(config, items):
+    """A GPU test that stops making progress must fail, not hang the box: give every GPU test a
+    time limit when pytest-timeout is available (it is in this image)."""
+    if not config.pluginmanager.hasplugin("timeout"):
+        return
+    for item in items:
+        if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
+            item.add_marker(pytest.mark.timeout(240))
 
 
 @pytest.fixture(scope="session")

@@ -215,12 +215,13 @@ def test_row_blocked_gridblocks_equal_single_block(capi, W, H, world, ghost, ite
             except Exception:
                 pass
 
-    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    threads = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
     for t in threads:
         t.start()
     for t in threads:
-        t.join(timeout=300)
+        t.join(timeout=120)
     assert not errs, errs
+    assert all(not t.is_alive() for t in threads), "a rank thread is stuck"
     got = np.concatenate([o[0] for o in out])
     assert np.array_equal(got, want)
     assert abs(out[0][1][0] - np.sqrt(rr_w[0] / bb_w[0])) <= 1e-12
