@@ -126,7 +126,8 @@ int one_iteration(ccp_grid *g, bool l1, const int *active, long *blocks_out)
 }
 
 template <int T>
-int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi, const int *active)
+int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi, const int *active,
+                   bool l1 = false, long *l1_blocks = nullptr)
 {
     FusedParams P;
     P.xin = xin;
@@ -143,14 +144,20 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     const int waves = kBlock / kWave;
     dim3 grid((unsigned)((P.n_strips + waves - 1) / waves), (unsigned)((st_hi - st_lo + P.rows_per_chunk - 1) / P.rows_per_chunk),
               (unsigned)g->desc.channels);
-    hipLaunchKernelGGL((k_fused_sweep<T, false, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
+    if (l1) {   // also accumulate sum|x_new - x_old| of the launch's LAST iteration (one double per block)
+        hipLaunchKernelGGL((k_fused_sweep<T, true, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
+        if (l1_blocks) *l1_blocks = (long)grid.x * grid.y;
+    } else {
+        hipLaunchKernelGGL((k_fused_sweep<T, false, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
+    }
     CCP_HIP(hipGetLastError());
     g->last_launches++;
     return CCP_OK;
 }
 
 // T fused iterations xin -> xout, with the ghost bookkeeping of 2T half-sweeps.
-int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int *active)
+int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int *active, bool l1 = false,
+                 long *l1_blocks = nullptr)
 {
     const bool shrinking = g->shrink_top || g->shrink_bottom;
     const int s = g->half_sweeps_since_refresh;
@@ -159,14 +166,14 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int 
     const int st_hi = g->geom.local_rows - (g->shrink_bottom ? std::min(s + 2 * T, g->ghost_bottom) : 0);
     if (st_hi > st_lo) {
         switch (T) {
-        case 1: CCP_TRY(launch_fused_t<1>(g, xin, xout, st_lo, st_hi, active)); break;
-        case 2: CCP_TRY(launch_fused_t<2>(g, xin, xout, st_lo, st_hi, active)); break;
-        case 3: CCP_TRY(launch_fused_t<3>(g, xin, xout, st_lo, st_hi, active)); break;
-        case 4: CCP_TRY(launch_fused_t<4>(g, xin, xout, st_lo, st_hi, active)); break;
-        case 5: CCP_TRY(launch_fused_t<5>(g, xin, xout, st_lo, st_hi, active)); break;
-        case 6: CCP_TRY(launch_fused_t<6>(g, xin, xout, st_lo, st_hi, active)); break;
-        case 7: CCP_TRY(launch_fused_t<7>(g, xin, xout, st_lo, st_hi, active)); break;
-        case 8: CCP_TRY(launch_fused_t<8>(g, xin, xout, st_lo, st_hi, active)); break;
+        case 1: CCP_TRY(launch_fused_t<1>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
+        case 2: CCP_TRY(launch_fused_t<2>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
+        case 3: CCP_TRY(launch_fused_t<3>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
+        case 4: CCP_TRY(launch_fused_t<4>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
+        case 5: CCP_TRY(launch_fused_t<5>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
+        case 6: CCP_TRY(launch_fused_t<6>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
+        case 7: CCP_TRY(launch_fused_t<7>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
+        case 8: CCP_TRY(launch_fused_t<8>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
         default: return CCP_ERR_BAD_ARG;
         }
     }
@@ -176,9 +183,12 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int 
 
 // `iterations` unchecked sweeps: an even number of fused launches (so the result lands back
 // in g->x), a lone leftover iteration through the in-place half-sweep kernels.
-int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr)
+// l1_last: the last launch also accumulates the L1 step of the final iteration (fused check).
+int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool l1_last = false,
+                  long *l1_blocks = nullptr)
 {
     if (!g->fuse || iterations < 2) {
+        if (l1_last) return CCP_ERR_STATE;
         for (int k = 0; k < iterations; ++k) CCP_TRY(one_iteration(g, false, active, nullptr));
         return CCP_OK;
     }
@@ -215,8 +225,9 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr)
     }
     std::sort(plan.begin(), plan.end(), std::greater<int>());
     double *cur = g->x.p, *alt = g->x_alt.p;
-    for (int T : plan) {
-        CCP_TRY(launch_fused(g, T, cur, alt, active));
+    for (size_t k = 0; k < plan.size(); ++k) {
+        const bool last = k + 1 == plan.size();
+        CCP_TRY(launch_fused(g, plan[k], cur, alt, active, l1_last && last, l1_blocks));
         std::swap(cur, alt);
     }
     return CCP_OK;
@@ -571,6 +582,18 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
     while (any_active && issued < max_iteration) {
         int checks = 0;
         while (issued < max_iteration && checks < batch_checks) {
+            if (g->fuse && check_every >= 2 && max_iteration - issued >= check_every) {
+                // a whole check period in fused launches; the last one accumulates the L1 step of
+                // the period's final sweep, so checking costs no extra pass over the grid
+                long blocks = 0;
+                CCP_TRY(run_unchecked(g, check_every, active, true, &blocks));
+                issued += check_every;
+                hipLaunchKernelGGL(k_check, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks,
+                                   g->partial.p, 0L, epsilon, issued, g->state.p, static_cast<double *>(nullptr));
+                CCP_HIP(hipGetLastError());
+                ++checks;
+                continue;
+            }
             // check_every-1 unchecked sweeps (fused), then one sweep that accumulates the L1 step
             const int plain = std::min(check_every - 1, max_iteration - issued);
             if (plain > 0) {

@@ -299,3 +299,27 @@ def test_tuned_planner_any_iteration_count(capi, orc):
         want, _, _ = orc.multicolour_gauss_seidel(v, c, r, col, b, 0.0, k)
         assert np.array_equal(g.get_x().ravel(), want), k
     g.close()
+
+
+@pytest.mark.parametrize("every", [2, 5, 8, 16])
+def test_fused_convergence_check(capi, orc, every):
+    """check_every >= 2: the whole period runs in fused launches and the last one accumulates the
+    L1 step; stop iteration, step value and x must equal the oracle's at that iteration."""
+    import oracle
+    from coursecomputationalphotography_amd import synth
+    W, H = 391, 301                       # several strips and chunks, odd sizes
+    v, c, r = synth.poisson_csr(W, H)
+    col = oracle.grid_colour(W, H)
+    b = synth.poisson_system(W, H, 23)[0] * 1e-4
+    g = capi.Grid(W, H, 1)
+    g.set_b(b)
+    g.fill_x(1.0)
+    eps = 3.0
+    rep = g.gauss_seidel(eps, 400, every)[0]
+    assert rep.converged == 1 and rep.iterations % every == 0 and rep.iterations > every
+    want, _, e = orc.multicolour_gauss_seidel(v, c, r, col, b, 0.0, rep.iterations)
+    assert np.array_equal(g.get_x().ravel(), want)
+    assert e <= eps and abs(rep.last_l1_step - e) <= 1e-10 * e
+    _, _, e_prev = orc.multicolour_gauss_seidel(v, c, r, col, b, 0.0, rep.iterations - every)
+    assert e_prev > eps
+    g.close()
