@@ -34,6 +34,7 @@ struct ccp_grid {
     long partial_region = 0;     // doubles per colour region of `partial` (L1 step)
     DevBuf<double> small;        // 4*kMaxChannels doubles of reduced results
     DevBuf<SolveState> state;
+    DevBuf<int> redo_mask;       // per-channel flags for re-running one channel of a checked pass
     DevBuf<double> stage;        // natural-order staging rows for host transfers
     long stage_rows = 0;
     int half_sweeps_since_refresh = 0;
@@ -126,8 +127,9 @@ int one_iteration(ccp_grid *g, bool l1, const int *active, long *blocks_out)
 }
 
 template <int T>
+// l1: 0 none, 1 step of the last sweep, 2 step of every sweep of the pass
 int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi, const int *active,
-                   bool l1 = false, long *l1_blocks = nullptr)
+                   int l1 = 0, long *l1_blocks = nullptr)
 {
     FusedParams P;
     P.xin = xin;
@@ -144,19 +146,22 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     const int waves = kBlock / kWave;
     dim3 grid((unsigned)((P.n_strips + waves - 1) / waves), (unsigned)((st_hi - st_lo + P.rows_per_chunk - 1) / P.rows_per_chunk),
               (unsigned)g->desc.channels);
-    if (l1) {   // also accumulate sum|x_new - x_old| of the launch's LAST iteration (one double per block)
-        hipLaunchKernelGGL((k_fused_sweep<T, true, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
-        if (l1_blocks) *l1_blocks = (long)grid.x * grid.y;
-    } else {
-        hipLaunchKernelGGL((k_fused_sweep<T, false, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
-    }
+    if (l1_blocks) *l1_blocks = (long)grid.x * grid.y;
+    if (l1 == 2 && T <= kFusedMaxCheckedT)
+        hipLaunchKernelGGL((k_fused_sweep<(T <= kFusedMaxCheckedT ? T : 1), 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
+    else if (l1 == 1)   // sum|x_new - x_old| of the launch's LAST sweep, one double per block
+        hipLaunchKernelGGL((k_fused_sweep<T, 1, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
+    else if (l1 == 0)
+        hipLaunchKernelGGL((k_fused_sweep<T, 0, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
+    else
+        return CCP_ERR_BAD_ARG;
     CCP_HIP(hipGetLastError());
     g->last_launches++;
     return CCP_OK;
 }
 
 // T fused iterations xin -> xout, with the ghost bookkeeping of 2T half-sweeps.
-int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int *active, bool l1 = false,
+int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int *active, int l1 = 0,
                  long *l1_blocks = nullptr)
 {
     const bool shrinking = g->shrink_top || g->shrink_bottom;
@@ -227,7 +232,7 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool
     double *cur = g->x.p, *alt = g->x_alt.p;
     for (size_t k = 0; k < plan.size(); ++k) {
         const bool last = k + 1 == plan.size();
-        CCP_TRY(launch_fused(g, plan[k], cur, alt, active, l1_last && last, l1_blocks));
+        CCP_TRY(launch_fused(g, plan[k], cur, alt, active, (l1_last && last) ? 1 : 0, l1_blocks));
         std::swap(cur, alt);
     }
     return CCP_OK;
@@ -576,6 +581,66 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
         // fixed count, no stop test: the temporally blocked sweep
         CCP_TRY(run_unchecked(g, max_iteration, nullptr));
         issued = max_iteration;
+        any_active = false;
+    }
+    if (any_active && check_every == 1 && g->fuse) {
+        // The reference tests its stop rule after EVERY sweep.  A temporally blocked pass knows the
+        // previous level of every pixel it updates, so it reports the step of each of its T sweeps
+        // (L1 = 2) at no extra traffic; k_check_multi finds the first sweep that meets the rule.  If
+        // that sweep is inside the pass, the channel is re-run from the pass's input buffer (still
+        // intact: passes ping-pong) for exactly the missing sweeps — once per solve.
+        const size_t elems = (size_t)g->geom.ch_stride * C;
+        if (!g->x_alt.p) {
+            CCP_TRY(g->x_alt.alloc(elems));
+            CCP_HIP(hipMemsetAsync(g->x_alt.p, 0, elems * sizeof(double), g->stream));
+        }
+        if (!g->redo_mask.p) CCP_TRY(g->redo_mask.alloc(kMaxChannels));
+        const size_t plane = (size_t)g->geom.ch_stride * sizeof(double);
+        double *cur = g->x.p, *alt = g->x_alt.p;
+        int was_active[kMaxChannels];
+        for (int ch = 0; ch < C; ++ch) was_active[ch] = 1;
+        int k0 = 0;
+        while (any_active && k0 < max_iteration) {
+            const int T = std::min(kFusedMaxCheckedT, max_iteration - k0);
+            long blocks = 0;
+            CCP_TRY(launch_fused(g, T, cur, alt, active, 2, &blocks));
+            hipLaunchKernelGGL(k_check_multi, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks, T, k0 + 1,
+                               epsilon, g->state.p);
+            CCP_HIP(hipGetLastError());
+            CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));
+            CCP_HIP(hipStreamSynchronize(g->stream));
+            any_active = false;
+            for (int ch = 0; ch < C; ++ch) {
+                any_active |= host.active[ch] != 0;
+                if (!was_active[ch] || host.active[ch]) continue;
+                was_active[ch] = 0;                                   // stopped inside this pass
+                const int m = host.iterations[ch] - k0;               // sweeps of the pass it wanted: 1..T
+                double *have = alt;                                   // where the channel's x_k is
+                if (m < T) {
+                    int mask[kMaxChannels] = {0};
+                    mask[ch] = 1;
+                    CCP_HIP(hipMemcpyAsync(g->redo_mask.p, mask, sizeof(mask), hipMemcpyHostToDevice, g->stream));
+                    double *p = cur, *q = alt;
+                    for (int left = m; left > 0;) {
+                        const int t = std::min(left, kFusedMaxT);
+                        CCP_TRY(launch_fused(g, t, p, q, g->redo_mask.p));
+                        std::swap(p, q);
+                        left -= t;
+                    }
+                    CCP_HIP(hipStreamSynchronize(g->stream));          // `mask` lives on this stack frame
+                    have = p;
+                }
+                // a frozen channel is never touched again: keep its result in BOTH buffers
+                double *other = (have == cur) ? alt : cur;
+                CCP_HIP(hipMemcpyAsync(other + (size_t)ch * g->geom.ch_stride, have + (size_t)ch * g->geom.ch_stride, plane,
+                                       hipMemcpyDeviceToDevice, g->stream));
+            }
+            k0 += T;
+            std::swap(cur, alt);
+        }
+        if (cur != g->x.p)
+            CCP_HIP(hipMemcpyAsync(g->x.p, cur, elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+        issued = k0;
         any_active = false;
     }
     const int batch_checks = 8;             // checked sweeps enqueued between two host polls

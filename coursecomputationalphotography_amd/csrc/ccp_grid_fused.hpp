@@ -35,6 +35,7 @@
 namespace ccp {
 
 constexpr int kFusedMaxT = 8;
+constexpr int kFusedMaxCheckedT = 5;     // deepest pass that also reports the step of each of its sweeps (+2T VGPRs)
 constexpr int kFusedUnroll = 4;          // march steps unrolled per loop trip (shifted window)
 // rows loaded ahead of the newest row: enough bytes in flight per CU at the occupancy the
 // register window of T allows (T<=5: 3 waves/SIMD, T>=6: 2 waves/SIMD)
@@ -76,7 +77,7 @@ struct FusedParams {
     int st_lo, st_hi;          // local rows to finalise and store
     int rows_per_chunk;
     int n_strips;
-    double *__restrict__ partial;   // L1: one double per block
+    double *__restrict__ partial;   // L1 = 1: one double per block; L1 = 2: T doubles per block (per iteration)
     const int *__restrict__ active; // nullable: per-channel "still iterating" flags (device)
 };
 
@@ -120,9 +121,12 @@ struct FusedCtx {
 // to be inside [m0, m1), so loads and row updates are straight-line code (the only scalar branch
 // left guards the store of the finished row): the s_waitcnt pass can then count the loads in
 // flight instead of draining them, and that is what lets the D-rows-ahead prefetch overlap.
-template <int T, bool BORDER, bool L1, int UNR, bool STEADY, int NT>
+// L1: 0 = no step norm; 1 = accumulate sum|x_new - x_old| of the pass's LAST iteration in acc[0];
+// 2 = of EVERY iteration t = 1..T in acc[t-1] (old is the previous level of the same colour, which
+// the window still holds — the reference's per-sweep manhattonDist at no extra memory traffic).
+template <int T, bool BORDER, int L1, int UNR, bool STEADY, int NT, int AN>
 __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], double (&br)[NT], double (&bk)[NT],
-                                           double &acc, const FusedCtx &cx, const Geom &g, int f, int i)
+                                           double (&acc)[AN], const FusedCtx &cx, const Geom &g, int f, int i)
 {
     using Win = FusedWindow<T, UNR>;
     constexpr int HS = Win::HS, D = Win::D;
@@ -171,10 +175,10 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
                     if (gs_update(s, bv, up, left, right, dn, t)) nv = t;
                 }
             }
-            if (L1 && h >= HS - 1) {
+            if ((L1 == 1 && h >= HS - 1) || L1 == 2) {
                 const bool counted = cx.col_store && r >= cx.ra && r < cx.rb && r >= g.own_lo && r < g.own_hi &&
                                      (!BORDER || (2 * cx.j + p) < g.W);
-                if (counted) acc += fabs(nv - old);
+                if (counted) acc[L1 == 2 ? (h - 1) / 2 : 0] += fabs(nv - old);
             }
             if (c) wk[sr] = nv; else wr[sr] = nv;
         }
@@ -194,10 +198,10 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
 }
 
 // One wave: strip `sx`, rows [ra, rb) of channel data at xin/xout/b (already channel-offset).
-template <int T, bool BORDER, bool L1, int UNR>
-__device__ __forceinline__ double fused_wave(const double *__restrict__ xin, double *__restrict__ xout,
-                                             const double *__restrict__ bb, const Geom &g, int sx,
-                                             int ra, int rb)
+template <int T, bool BORDER, int L1, int UNR, int AN>
+__device__ __forceinline__ void fused_wave(const double *__restrict__ xin, double *__restrict__ xout,
+                                           const double *__restrict__ bb, const Geom &g, int sx,
+                                           int ra, int rb, double (&acc)[AN])
 {
     using Win = FusedWindow<T, UNR>;
     constexpr int HS = Win::HS, D = Win::D, G = Win::G, NT = Win::NT;
@@ -224,18 +228,17 @@ __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, dou
     double wr[NT], wk[NT], br[NT], bk[NT];              // x red/black, b red/black per window row
 #pragma unroll
     for (int s = 0; s < NT; ++s) wr[s] = wk[s] = br[s] = bk[s] = 0.0;
-    double acc = 0.0;
 
     for (int fb = base - D; fb <= f_end; fb += G) {
         if (fb >= s_lo && fb + G - 1 <= s_hi) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
-                fused_step<T, BORDER, L1, UNR, true, NT>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+                fused_step<T, BORDER, L1, UNR, true, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
         } else {
 #pragma unroll
             for (int i = 0; i < G; ++i)
                 if (fb + i <= f_end)
-                    fused_step<T, BORDER, L1, UNR, false, NT>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+                    fused_step<T, BORDER, L1, UNR, false, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
         }
         if (UNR > 0) {
 #pragma unroll
@@ -244,7 +247,6 @@ __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, dou
             }
         }
     }
-    return acc;
 }
 
 // grid = (ceil(n_strips / 4), n_chunks, channels); block = 256 threads = 4 waves = 4 adjacent
@@ -255,10 +257,10 @@ __device__ __forceinline__ double fused_wave(const double *__restrict__ xin, dou
 // Waves per SIMD the register window of depth T is budgeted for (2nd __launch_bounds__ argument:
 // it caps the allocator, so the straight-line steady-state code cannot trade occupancy for
 // load hoisting).
-__host__ __device__ constexpr int fused_waves_per_simd(int T) { return T <= 1 ? 4 : (T <= 3 ? 3 : 2); }
+__host__ __device__ constexpr int fused_waves_per_simd(int T, int L1 = 0) { return T <= 1 ? 4 : (T <= (L1 == 2 ? 2 : 3) ? 3 : 2); }
 
-template <int T, bool L1, int UNR>
-__global__ void __launch_bounds__(kBlock, fused_waves_per_simd(T))
+template <int T, int L1, int UNR>
+__global__ void __launch_bounds__(kBlock, fused_waves_per_simd(T, L1))
 k_fused_sweep(FusedParams P)
 {
     __shared__ double scratch[kBlock / kWave];
@@ -273,7 +275,10 @@ k_fused_sweep(FusedParams P)
     if (gridDim.y > 2) chunk = blockIdx.y == 1 ? (int)gridDim.y - 1 : (blockIdx.y > 1 ? (int)blockIdx.y - 1 : 0);
     const int ra = P.st_lo + chunk * P.rows_per_chunk;
     const int rb = min(ra + P.rows_per_chunk, P.st_hi);
-    double acc = 0.0;
+    constexpr int AN = L1 == 2 ? T : 1;
+    double acc[AN];
+#pragma unroll
+    for (int t = 0; t < AN; ++t) acc[t] = 0.0;
     const bool run = (P.active == nullptr) || (P.active[ch] != 0);   // a converged channel is frozen
     if (run && sx < P.n_strips && ra < rb) {
         const Geom &g = P.g;
@@ -286,13 +291,17 @@ k_fused_sweep(FusedParams P)
         const int px1 = px0 + 2 * kStripLanes;                      // exclusive
         const bool border = (px0 <= 0) || (px1 >= g.W - 1) || (ra - HS <= 0) || (rb + HS >= g.local_rows) ||
                             (g.y0 + ra - HS <= 0) || (g.y0 + rb + HS >= g.H - 1);
-        if (border) acc = fused_wave<T, true, L1, UNR>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb);
-        else acc = fused_wave<T, false, L1, UNR>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb);
+        if (border) fused_wave<T, true, L1, UNR, AN>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc);
+        else fused_wave<T, false, L1, UNR, AN>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc);
     }
-    if (L1) {
-        const double total = block_sum(acc, scratch);
-        if (threadIdx.x == 0)
-            P.partial[((long)ch * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total;
+    if (L1 != 0) {
+        // partial[((t*channels + ch)*gridDim.y + by)*gridDim.x + bx], t = 0 for L1 = 1
+#pragma unroll
+        for (int t = 0; t < AN; ++t) {
+            const double total = block_sum(acc[t], scratch);
+            if (threadIdx.x == 0)
+                P.partial[(((long)t * gridDim.z + ch) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total;
+        }
     }
 }
 

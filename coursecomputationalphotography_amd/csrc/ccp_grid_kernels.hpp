@@ -266,6 +266,33 @@ k_check(const double *__restrict__ partial0, long blocks0, const double *__restr
     }
 }
 
+// The same rule for a temporally blocked pass that reported the step of EACH of its T sweeps
+// (partial[(t*channels + ch)*blocks + i]): the first sweep whose step is not above epsilon stops
+// the channel, exactly where the reference loop would have stopped.  grid = channels.
+__global__ void __launch_bounds__(kBlock)
+k_check_multi(const double *__restrict__ partial, long blocks, int T, int first_sweep_index, double epsilon,
+              SolveState *__restrict__ st)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int ch = blockIdx.x;
+    const int channels = gridDim.x;
+    for (int t = 0; t < T; ++t) {
+        double acc = 0.0;
+        const double *__restrict__ p = partial + ((long)t * channels + ch) * blocks;
+        for (long i = threadIdx.x; i < blocks; i += kBlock) acc += p[i];
+        const double eps = block_sum(acc, scratch);
+        if (threadIdx.x == 0 && st->active[ch]) {
+            st->last_eps[ch] = eps;
+            if (!(eps > epsilon)) {
+                st->active[ch] = 0;
+                st->converged[ch] = 1;
+                st->iterations[ch] = first_sweep_index + t;
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // SpMV-shaped kernels on the same layout.  One thread per CPT half-columns of one (row, colour).
 // MODE 0: b := A x (applyToVector).  MODE 1: partial sums of (b - A x)^2 and b^2 (residual).

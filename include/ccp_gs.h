@@ -196,9 +196,10 @@ int ccp_grid_halo_refreshed(ccp_grid *g);
  * channels at once, each channel with its own stop test exactly as three separate reference
  * calls would (PhotoMontage.cpp:429-433): a channel that met `eps <= epsilon` is frozen.
  * report: array of `channels` entries (may be NULL).  Single-block handles only.
- * check_every: 1 = test after every sweep as the reference does (in-place kernels); k >= 2 = test
- * after every k-th sweep at no extra cost (the temporally blocked pass accumulates the step of its
- * last sweep); 0 = no test, exactly max_iteration sweeps (fastest). */
+ * check_every: 1 = test after every sweep, exactly as the reference does — still temporally
+ * blocked: a pass reports the step of each of its sweeps and a channel that met the rule inside a
+ * pass is re-run to precisely that sweep; k >= 2 = test after every k-th sweep; 0 = no test,
+ * exactly max_iteration sweeps (fastest). */
 int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration,
                           int32_t check_every, ccp_gs_report *report);
 
