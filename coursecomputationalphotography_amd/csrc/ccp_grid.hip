@@ -19,6 +19,8 @@ struct ccp_grid {
     bool shrink_top = false, shrink_bottom = false;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;     // border tiles of a fused pass run here, beside the ordinary ones
+    hipEvent_t ev_main = nullptr, ev_side = nullptr;
     DevBuf<double> x, b;
     DevBuf<double> cg_r, cg_p, cg_ap;   // conjugate-gradient work vectors, one channel each
     DevBuf<CgState> cg_state;
@@ -30,6 +32,8 @@ struct ccp_grid {
     float tune_ms[kFusedMaxT + 1] = {0};
     int tune_rows[kFusedMaxT + 1] = {0};
     bool tuned = false;
+    bool all_border = false;     // debug (CCP_GS_ALL_BORDER): every tile of a pass goes through k_fused_border
+    bool force_border = false;   // debug (CCP_GS_FORCE_BORDER): and every trip there takes the border body
     DevBuf<double> partial;      // per-block partial sums (L1 step / residual / checksums)
     long partial_region = 0;     // doubles per colour region of `partial` (L1 step)
     DevBuf<double> small;        // 4*kMaxChannels doubles of reduced results
@@ -126,8 +130,35 @@ int one_iteration(ccp_grid *g, bool l1, const int *active, long *blocks_out)
     return CCP_OK;
 }
 
+// Which tiles of a pass can touch a pixel with a missing neighbour (same predicates the kernels
+// used to evaluate per wave): leading / trailing chunks by rows, leading / trailing strips by columns.
+void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P)
+{
+    const Geom &geo = g->geom;
+    const int HS = 2 * T, R = P.rows_per_chunk;
+    P.n_chunks = (P.st_hi - P.st_lo + R - 1) / R;
+    auto top = [&](int c) { const int ra = P.st_lo + c * R; return (ra - HS <= 0) || (geo.y0 + ra - HS <= 0); };
+    auto bot = [&](int c) { const int rb = std::min(P.st_lo + (c + 1) * R, P.st_hi); return (rb + HS >= geo.local_rows) || (geo.y0 + rb + HS >= geo.H - 1); };
+    P.nb_top = 0;
+    while (P.nb_top < P.n_chunks && top(P.nb_top)) ++P.nb_top;
+    P.nb_bot = 0;
+    while (P.nb_top + P.nb_bot < P.n_chunks && bot(P.n_chunks - 1 - P.nb_bot)) ++P.nb_bot;
+    const int U = fused_useful_px(T);
+    auto left = [&](int s) { return s * U - fused_halo_px(T) <= 0; };
+    auto right = [&](int s) { return s * U - fused_halo_px(T) + 2 * kStripLanes >= geo.W - 1; };
+    P.ns_left = 0;
+    while (P.ns_left < P.n_strips && left(P.ns_left)) ++P.ns_left;
+    P.ns_right = 0;
+    while (P.ns_left + P.ns_right < P.n_strips && right(P.n_strips - 1 - P.ns_right)) ++P.ns_right;
+    if (g->all_border) {                 // debug: every tile through the border launch
+        P.nb_top = P.n_chunks;
+        P.nb_bot = 0;
+    }
+}
+
+// One pass of depth T.  l1: 0 none, 1 step of the last sweep, 2 step of every sweep of the pass;
+// l1_blocks[0/1]: block results per (sweep, channel) of the ordinary / the border launch.
 template <int T>
-// l1: 0 none, 1 step of the last sweep, 2 step of every sweep of the pass
 int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi, const int *active,
                    int l1 = 0, long *l1_blocks = nullptr)
 {
@@ -142,19 +173,41 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     const int U = fused_useful_px(T);
     P.n_strips = (g->geom.W + U - 1) / U;
     P.partial = g->partial.p;
+    P.partial_border = g->partial.p + g->partial_region;
     P.active = active;
+    fused_tile_counts(g, T, P);
     const int waves = kBlock / kWave;
-    dim3 grid((unsigned)((P.n_strips + waves - 1) / waves), (unsigned)((st_hi - st_lo + P.rows_per_chunk - 1) / P.rows_per_chunk),
-              (unsigned)g->desc.channels);
-    if (l1_blocks) *l1_blocks = (long)grid.x * grid.y;
-    if (l1 == 2 && T <= kFusedMaxCheckedT)
-        hipLaunchKernelGGL((k_fused_sweep<(T <= kFusedMaxCheckedT ? T : 1), 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
-    else if (l1 == 1)   // sum|x_new - x_old| of the launch's LAST sweep, one double per block
-        hipLaunchKernelGGL((k_fused_sweep<T, 1, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
-    else if (l1 == 0)
-        hipLaunchKernelGGL((k_fused_sweep<T, 0, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
-    else
-        return CCP_ERR_BAD_ARG;
+    const int edge_chunks = std::min(P.nb_top + P.nb_bot, P.n_chunks);
+    const int edge_strips = std::min(P.ns_left + P.ns_right, P.n_strips);
+    const long n_border = (long)edge_chunks * P.n_strips + (long)(P.n_chunks - edge_chunks) * edge_strips;
+    const bool any_plain = edge_chunks < P.n_chunks && edge_strips < P.n_strips;
+    dim3 grid((unsigned)((P.n_strips + waves - 1) / waves), (unsigned)P.n_chunks, (unsigned)g->desc.channels);
+    dim3 bgrid((unsigned)((n_border + waves - 1) / waves), 1, (unsigned)g->desc.channels);
+    if (l1_blocks) {
+        l1_blocks[0] = any_plain ? (long)grid.x * grid.y : 0;
+        l1_blocks[1] = n_border ? (long)bgrid.x : 0;
+    }
+    if (l1 == 2 && T > kFusedMaxCheckedT) return CCP_ERR_BAD_ARG;
+    constexpr int TC = T <= kFusedMaxCheckedT ? T : 1;       // per-sweep sums exist up to kFusedMaxCheckedT
+    // The border launch sees everything queued on the main stream so far, runs beside the ordinary
+    // tiles, and whatever comes next on the main stream waits for it.
+    if (n_border) {
+        CCP_HIP(hipEventRecord(g->ev_main, g->stream));
+        CCP_HIP(hipStreamWaitEvent(g->stream2, g->ev_main, 0));
+    }
+    if (any_plain) {
+        if (l1 == 2) hipLaunchKernelGGL((k_fused_sweep<TC, 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
+        else if (l1 == 1) hipLaunchKernelGGL((k_fused_sweep<T, 1, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
+        else hipLaunchKernelGGL((k_fused_sweep<T, 0, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
+    }
+    if (n_border) {
+        const int fb = g->force_border ? 1 : 0;
+        if (l1 == 2) hipLaunchKernelGGL((k_fused_border<TC, 2, kFusedUnroll>), bgrid, dim3(kBlock), 0, g->stream2, P, fb);
+        else if (l1 == 1) hipLaunchKernelGGL((k_fused_border<T, 1, kFusedUnroll>), bgrid, dim3(kBlock), 0, g->stream2, P, fb);
+        else hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll>), bgrid, dim3(kBlock), 0, g->stream2, P, fb);
+        CCP_HIP(hipEventRecord(g->ev_side, g->stream2));
+        CCP_HIP(hipStreamWaitEvent(g->stream, g->ev_side, 0));
+    }
     CCP_HIP(hipGetLastError());
     g->last_launches++;
     return CCP_OK;
@@ -318,6 +371,8 @@ int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
     if (const char *e = getenv("CCP_GS_SHFL")) g->shfl = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_TMAX")) g->fuse_tmax = std::max(1, std::min(kFusedMaxT, atoi(e)));
+    if (const char *e = getenv("CCP_GS_ALL_BORDER")) g->all_border = atoi(e) != 0;
+    if (const char *e = getenv("CCP_GS_FORCE_BORDER")) g->force_border = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_CHUNK")) g->rows_per_chunk = std::max(1, atoi(e));
     choose_tiling(g);
 
@@ -333,6 +388,10 @@ int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
     g->stage_rows = std::max<long>(1, std::min<long>(geo.local_rows, (8L << 20) / d->width));
     if (st == CCP_OK) st = g->stage.alloc((size_t)g->stage_rows * d->width);
     if (st == CCP_OK && (hipEventCreate(&g->ev0) != hipSuccess || hipEventCreate(&g->ev1) != hipSuccess)) st = CCP_ERR_HIP;
+    if (st == CCP_OK && (hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking) != hipSuccess ||
+                         hipEventCreateWithFlags(&g->ev_main, hipEventDisableTiming) != hipSuccess ||
+                         hipEventCreateWithFlags(&g->ev_side, hipEventDisableTiming) != hipSuccess))
+        st = CCP_ERR_HIP;
     if (st == CCP_OK && (hipMemset(g->x.p, 0, elems * sizeof(double)) != hipSuccess ||
                          hipMemset(g->b.p, 0, elems * sizeof(double)) != hipSuccess))
         st = CCP_ERR_HIP;
@@ -350,6 +409,12 @@ int ccp_grid_destroy(ccp_grid *g)
     (void)hipSetDevice(g->device);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->ev_main) (void)hipEventDestroy(g->ev_main);
+    if (g->ev_side) (void)hipEventDestroy(g->ev_side);
+    if (g->stream2) {
+        (void)hipStreamSynchronize(g->stream2);
+        (void)hipStreamDestroy(g->stream2);
+    }
     delete g;
     return CCP_OK;
 }
@@ -602,10 +667,10 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
         int k0 = 0;
         while (any_active && k0 < max_iteration) {
             const int T = std::min(kFusedMaxCheckedT, max_iteration - k0);
-            long blocks = 0;
-            CCP_TRY(launch_fused(g, T, cur, alt, active, 2, &blocks));
-            hipLaunchKernelGGL(k_check_multi, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks, T, k0 + 1,
-                               epsilon, g->state.p);
+            long blocks[2] = {0, 0};
+            CCP_TRY(launch_fused(g, T, cur, alt, active, 2, blocks));
+            hipLaunchKernelGGL(k_check_multi, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
+                               g->partial.p + g->partial_region, blocks[1], T, k0 + 1, epsilon, g->state.p);
             CCP_HIP(hipGetLastError());
             CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));
             CCP_HIP(hipStreamSynchronize(g->stream));
@@ -650,11 +715,12 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
             if (g->fuse && check_every >= 2 && max_iteration - issued >= check_every) {
                 // a whole check period in fused launches; the last one accumulates the L1 step of
                 // the period's final sweep, so checking costs no extra pass over the grid
-                long blocks = 0;
-                CCP_TRY(run_unchecked(g, check_every, active, true, &blocks));
+                long blocks[2] = {0, 0};
+                CCP_TRY(run_unchecked(g, check_every, active, true, blocks));
                 issued += check_every;
-                hipLaunchKernelGGL(k_check, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks,
-                                   g->partial.p, 0L, epsilon, issued, g->state.p, static_cast<double *>(nullptr));
+                hipLaunchKernelGGL(k_check, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
+                                   g->partial.p + g->partial_region, blocks[1], epsilon, issued, g->state.p,
+                                   static_cast<double *>(nullptr));
                 CCP_HIP(hipGetLastError());
                 ++checks;
                 continue;

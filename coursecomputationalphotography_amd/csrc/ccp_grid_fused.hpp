@@ -79,6 +79,13 @@ struct FusedParams {
     int n_strips;
     double *__restrict__ partial;   // L1 = 1: one double per block; L1 = 2: T doubles per block (per iteration)
     const int *__restrict__ active; // nullable: per-channel "still iterating" flags (device)
+    // Tiles (chunk c, strip s) that can touch a pixel with a missing neighbour — image edges, the
+    // stale edge of a ghost zone — are "border tiles": the first nb_top / last nb_bot chunks and the
+    // first ns_left / last ns_right strips (host: fused_tile_counts).  k_fused_sweep skips them,
+    // k_fused_border runs exactly them, concurrently on a second stream.
+    int n_chunks;
+    int nb_top, nb_bot, ns_left, ns_right;
+    double *__restrict__ partial_border;   // L1 sums of the border launch (same layout, own region)
 };
 
 // How the row window maps onto registers.  G march steps are unrolled per loop trip.
@@ -115,16 +122,31 @@ struct FusedCtx {
     bool col_store;     // lane's pixels belong to the columns this strip stores
     int ra, rb;         // rows to finalise and store
     int m0, m1;         // rows loaded
+    // border tiles only: what depends on the pixel column, per parity p (pixel x = 2j + p)
+    bool col_interior;  // wave-uniform: every pixel column of the strip is in [1, W-2]
+    bool px_ok[2];      // the pixel exists (x < W, half-column in range)
+    bool px_left[2];    // x >= 1
+    bool px_right[2];   // x < W-1
+    bool px_first[2];   // x == 0
 };
 
-// One march step: newest row f, unrolled position i.  STEADY: every row the step touches is known
-// to be inside [m0, m1), so loads and row updates are straight-line code (the only scalar branch
-// left guards the store of the finished row): the s_waitcnt pass can then count the loads in
-// flight instead of draining them, and that is what lets the D-rows-ahead prefetch overlap.
+// One march step: newest row f, unrolled position i.  Three bodies, chosen per loop trip:
+//   kStepFast   : every row the step touches exists (inside [m0, m1)) and is an ordinary image row
+//                 of a strip away from the left/right image edge: loads and row updates are
+//                 straight-line, branch-free code (the only scalar branch left guards the store of
+//                 the finished row), so the s_waitcnt pass can count the loads in flight instead
+//                 of draining them — that is what lets the D-rows-ahead prefetch overlap;
+//   kStepRanged : ordinary rows, but some may not exist yet / any more (pipeline fill and drain):
+//                 the same arithmetic behind wave-uniform range checks;
+//   kStepBorder : (border tiles only) rows at an image edge or at the stale edge of a ghost zone,
+//                 or a strip at the left/right image edge: range checks plus the border-aware
+//                 arithmetic of SURVEY §8a-8.
 // L1: 0 = no step norm; 1 = accumulate sum|x_new - x_old| of the pass's LAST iteration in acc[0];
 // 2 = of EVERY iteration t = 1..T in acc[t-1] (old is the previous level of the same colour, which
 // the window still holds — the reference's per-sweep manhattonDist at no extra memory traffic).
-template <int T, bool BORDER, int L1, int UNR, bool STEADY, int NT, int AN>
+constexpr int kStepFast = 0, kStepRanged = 1, kStepBorder = 2;
+
+template <int T, int MODE, int L1, int UNR, int NT, int AN>
 __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], double (&br)[NT], double (&bk)[NT],
                                            double (&acc)[AN], const FusedCtx &cx, const Geom &g, int f, int i)
 {
@@ -134,9 +156,9 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
     {
         const int q = f + D;
         const int sq = Win::slot(i, -D);
-        if (STEADY || (q >= cx.m0 && q < cx.m1)) {
+        if (MODE == kStepFast || (q >= cx.m0 && q < cx.m1)) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            if (!BORDER || cx.col_ok) {
+            if (MODE != kStepBorder || cx.col_ok) {
                 // uniform row base + lane index
                 const long o0 = row_off(g, q, 0) + cx.jbase, o1 = row_off(g, q, 1) + cx.jbase;
                 a0 = (cx.xin + o0)[cx.lane];
@@ -154,7 +176,7 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
         const int sr = Win::slot(i, h), su = Win::slot(i, h + 1), sd = Win::slot(i, h - 1);
         const int c = (h - 1) & 1;                       // 0 = red, 1 = black
         const int p = ((i - h + 2 * HS + 2) + c) & 1;    // pixel column = 2j + p
-        if (STEADY || (r >= cx.m0 && r < cx.m1)) {
+        if (MODE == kStepFast || (r >= cx.m0 && r < cx.m1)) {
             // opposite colour: rows r-1, r, r+1
             const double up = c ? wr[su] : wk[su];
             const double dn = c ? wr[sd] : wk[sd];
@@ -165,19 +187,39 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
             const double bv = c ? bk[sr] : br[sr];
             const double old = c ? wk[sr] : wr[sr];
             double nv = old;
-            if (!BORDER) {
+            if (MODE != kStepBorder) {
                 nv = (bv + (((up + left) + right) + dn)) * 0.25;
             } else {
-                const int x = 2 * cx.j + p;
-                if (cx.col_ok && x < g.W) {
-                    const Stencil s = classify(g, x, g.y0 + r, r);
-                    double t;
-                    if (gs_update(s, bv, up, left, right, dn, t)) nv = t;
+                // Most rows of a border trip are still ordinary: an image row with both neighbour
+                // rows present, in a strip away from the left/right image edge, takes the plain
+                // update.  Otherwise the stencil of SURVEY §8a-8 is evaluated from the per-lane
+                // column flags and the (wave-uniform) row flags; only a_ii = 3 (image row 0, image
+                // column 0) needs a true division — 1, 2 and 4 are exact reciprocals.
+                const int y = g.y0 + r;
+                const bool row_plain = (y >= 1) && (y <= g.H - 2) && (r >= 1) && (r + 1 < g.local_rows);
+                if (row_plain && cx.col_interior) {
+                    nv = (bv + (((up + left) + right) + dn)) * 0.25;
+                } else if (cx.px_ok[p]) {
+                    const bool cellrow = y < g.H - 1;                        // cell(.,y) rows
+                    const bool cf_up = (y >= 1) && cx.px_right[p];           // cell(x, y-1)
+                    const bool s_left = cx.px_left[p] && cellrow;            // cell(x-1, y)
+                    const bool s_here = cx.px_right[p] && cellrow;           // cell(x, y)
+                    const int diag = (int)cf_up + (int)s_left + 2 * (int)s_here + (int)(cx.px_first[p] && y == 0);
+                    const bool s_up = cf_up && (r >= 1);
+                    const bool s_down = s_here && (r + 1 < g.local_rows);
+                    double sigma = 0.0;
+                    if (s_up) sigma += -1.0 * up;
+                    if (s_left) sigma += -1.0 * left;
+                    if (s_here) sigma += -1.0 * right;
+                    if (s_down) sigma += -1.0 * dn;
+                    const double t = bv - sigma;
+                    if (diag == 3) nv = t / 3.0;
+                    else if (diag != 0) nv = t * (diag == 4 ? 0.25 : (diag == 2 ? 0.5 : 1.0));
                 }
             }
             if ((L1 == 1 && h >= HS - 1) || L1 == 2) {
                 const bool counted = cx.col_store && r >= cx.ra && r < cx.rb && r >= g.own_lo && r < g.own_hi &&
-                                     (!BORDER || (2 * cx.j + p) < g.W);
+                                     (MODE != kStepBorder || cx.px_ok[p]);
                 if (counted) acc[L1 == 2 ? (h - 1) / 2 : 0] += fabs(nv - old);
             }
             if (c) wk[sr] = nv; else wr[sr] = nv;
@@ -198,10 +240,13 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
 }
 
 // One wave: strip `sx`, rows [ra, rb) of channel data at xin/xout/b (already channel-offset).
-template <int T, bool BORDER, int L1, int UNR, int AN>
+// BORDERTILE = false: every pixel the wave can touch is ordinary; trips are kStepFast /
+// kStepRanged and nothing border-related is computed.  BORDERTILE = true: each trip picks among
+// all three bodies (force_border: debug, every trip takes kStepBorder).
+template <int T, bool BORDERTILE, int L1, int UNR, int AN>
 __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, double *__restrict__ xout,
                                            const double *__restrict__ bb, const Geom &g, int sx,
-                                           int ra, int rb, double (&acc)[AN])
+                                           int ra, int rb, double (&acc)[AN], bool force_border = false)
 {
     using Win = FusedWindow<T, UNR>;
     constexpr int HS = Win::HS, D = Win::D, G = Win::G, NT = Win::NT;
@@ -215,6 +260,15 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     cx.col_ok = (cx.j >= 0) && (cx.j < g.pitch);
     const int ux0 = sx * U, ux1 = ux0 + U;              // pixel columns this strip stores
     cx.col_store = cx.col_ok && (2 * cx.j >= ux0) && (2 * cx.j + 1 < ux1);
+    cx.col_interior = (px0 >= 1) && (px0 + 2 * kStripLanes <= g.W - 1);
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int x = 2 * cx.j + p;
+        cx.px_ok[p] = cx.col_ok && x < g.W;
+        cx.px_left[p] = x >= 1;
+        cx.px_right[p] = x < g.W - 1;
+        cx.px_first[p] = x == 0;
+    }
     cx.ra = ra; cx.rb = rb;
     cx.m0 = max(ra - HS, 0);                            // rows this wave loads: [m0, m1)
     cx.m1 = min(rb + HS, g.local_rows);
@@ -230,15 +284,27 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     for (int s = 0; s < NT; ++s) wr[s] = wk[s] = br[s] = bk[s] = 0.0;
 
     for (int fb = base - D; fb <= f_end; fb += G) {
-        if (fb >= s_lo && fb + G - 1 <= s_hi) {
+        bool plain = true;
+        if (BORDERTILE) {
+            // rows the trip may update: fb-HS .. fb+G-2, clipped to the rows this wave holds
+            const int r_first = max(fb - HS, cx.m0), r_last = min(fb + G - 2, cx.m1 - 1);
+            plain = !force_border && cx.col_interior && (g.y0 + r_first >= 1) && (g.y0 + r_last <= g.H - 2) &&
+                    (r_first >= 1) && (r_last + 1 < g.local_rows);
+        }
+        if (plain && fb >= s_lo && fb + G - 1 <= s_hi) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
-                fused_step<T, BORDER, L1, UNR, true, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
-        } else {
+                fused_step<T, kStepFast, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+        } else if (plain) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
                 if (fb + i <= f_end)
-                    fused_step<T, BORDER, L1, UNR, false, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+                    fused_step<T, kStepRanged, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+        } else if (BORDERTILE) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                if (fb + i <= f_end)
+                    fused_step<T, kStepBorder, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
         }
         if (UNR > 0) {
 #pragma unroll
@@ -249,16 +315,31 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     }
 }
 
-// grid = (ceil(n_strips / 4), n_chunks, channels); block = 256 threads = 4 waves = 4 adjacent
-// strips of one chunk.  Each wave picks one of two bodies: the branch-free one when all its
-// pixels have four neighbours, the border-aware one when it touches an image edge or the stale
-// edge of a ghost zone.  (Two separate launches were tried: the border launch ran alone at low
-// occupancy and cost +0.25 ms per pass at 16384^2.)
-// Waves per SIMD the register window of depth T is budgeted for (2nd __launch_bounds__ argument:
-// it caps the allocator, so the straight-line steady-state code cannot trade occupancy for
-// load hoisting).
+// fused_waves_per_simd(T) is the 2nd __launch_bounds__ argument: it caps the register allocator,
+// so the straight-line code cannot trade occupancy for load hoisting.
 __host__ __device__ constexpr int fused_waves_per_simd(int T, int L1 = 0) { return T <= 1 ? 4 : (T <= (L1 == 2 ? 2 : 3) ? 3 : 2); }
 
+__device__ __forceinline__ bool fused_is_border_tile(const FusedParams &P, int chunk, int sx)
+{
+    return chunk < P.nb_top || chunk >= P.n_chunks - P.nb_bot || sx < P.ns_left || sx >= P.n_strips - P.ns_right;
+}
+
+template <int L1, int AN>
+__device__ __forceinline__ void fused_write_partials(double (&acc)[AN], double *__restrict__ partial, int ch, double *scratch)
+{
+    if (L1 != 0) {
+        // partial[((t*channels + ch)*gridDim.y + by)*gridDim.x + bx], t = 0 for L1 = 1
+#pragma unroll
+        for (int t = 0; t < AN; ++t) {
+            const double total = block_sum(acc[t], scratch);
+            if (threadIdx.x == 0)
+                partial[(((long)t * gridDim.z + ch) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total;
+        }
+    }
+}
+
+// Ordinary tiles.  grid = (ceil(n_strips / 4), n_chunks, channels); block = 256 threads = 4 waves =
+// 4 adjacent strips of one chunk; waves of border tiles leave at once (k_fused_border runs them).
 template <int T, int L1, int UNR>
 __global__ void __launch_bounds__(kBlock, fused_waves_per_simd(T, L1))
 k_fused_sweep(FusedParams P)
@@ -268,11 +349,7 @@ k_fused_sweep(FusedParams P)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int sx = blockIdx.x * (kBlock / kWave) + wave;
     const int ch = blockIdx.z;
-    // Workgroups are dispatched in index order.  The waves of the first and the last chunk take
-    // the border-aware body, which runs ~2.6x longer at T=8: give the last chunk index 1 instead
-    // of the highest one so both start at the beginning and never form the tail of the launch.
-    int chunk = blockIdx.y;
-    if (gridDim.y > 2) chunk = blockIdx.y == 1 ? (int)gridDim.y - 1 : (blockIdx.y > 1 ? (int)blockIdx.y - 1 : 0);
+    const int chunk = blockIdx.y;
     const int ra = P.st_lo + chunk * P.rows_per_chunk;
     const int rb = min(ra + P.rows_per_chunk, P.st_hi);
     constexpr int AN = L1 == 2 ? T : 1;
@@ -280,29 +357,56 @@ k_fused_sweep(FusedParams P)
 #pragma unroll
     for (int t = 0; t < AN; ++t) acc[t] = 0.0;
     const bool run = (P.active == nullptr) || (P.active[ch] != 0);   // a converged channel is frozen
-    if (run && sx < P.n_strips && ra < rb) {
+    if (run && sx < P.n_strips && ra < rb && !fused_is_border_tile(P, chunk, sx)) {
         const Geom &g = P.g;
         const long off = (long)ch * g.ch_stride;
-        constexpr int HS = 2 * T;
-        // a wave needs the border-aware update if any pixel it can touch lacks a neighbour:
-        // strip at the left/right image edge, or rows at the top/bottom of the local block
-        // (image border, or the stale edge of the ghost zone)
-        const int px0 = sx * fused_useful_px(T) - fused_halo_px(T);
-        const int px1 = px0 + 2 * kStripLanes;                      // exclusive
-        const bool border = (px0 <= 0) || (px1 >= g.W - 1) || (ra - HS <= 0) || (rb + HS >= g.local_rows) ||
-                            (g.y0 + ra - HS <= 0) || (g.y0 + rb + HS >= g.H - 1);
-        if (border) fused_wave<T, true, L1, UNR, AN>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc);
-        else fused_wave<T, false, L1, UNR, AN>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc);
+        fused_wave<T, false, L1, UNR, AN>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc);
     }
-    if (L1 != 0) {
-        // partial[((t*channels + ch)*gridDim.y + by)*gridDim.x + bx], t = 0 for L1 = 1
+    fused_write_partials<L1, AN>(acc, P.partial, ch, scratch);
+}
+
+// Border tiles, compactly enumerated: first the whole top and bottom chunk rows, then the left and
+// right strips of the chunks in between.  grid = (ceil(n_border_tiles / 4), 1, channels).  Runs on
+// a second stream beside k_fused_sweep: its waves take ~2.6x longer at T=8 when a whole trip is
+// border work, and as part of one launch they used to be the tail every small grid waited for.
+template <int T, int L1, int UNR>
+__global__ void __launch_bounds__(kBlock, fused_waves_per_simd(T, L1))
+k_fused_border(FusedParams P, int force_border)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int id = blockIdx.x * (kBlock / kWave) + wave;
+    const int ch = blockIdx.z;
+    constexpr int AN = L1 == 2 ? T : 1;
+    double acc[AN];
 #pragma unroll
-        for (int t = 0; t < AN; ++t) {
-            const double total = block_sum(acc[t], scratch);
-            if (threadIdx.x == 0)
-                P.partial[(((long)t * gridDim.z + ch) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total;
+    for (int t = 0; t < AN; ++t) acc[t] = 0.0;
+    const int edge_chunks = min(P.nb_top + P.nb_bot, P.n_chunks);
+    const int edge_strips = min(P.ns_left + P.ns_right, P.n_strips);
+    const int n_full = edge_chunks * P.n_strips;                       // whole chunk rows
+    const int n_side = (P.n_chunks - edge_chunks) * edge_strips;       // side strips of the middle chunks
+    const bool run = (P.active == nullptr) || (P.active[ch] != 0);
+    if (run && id < n_full + n_side) {
+        int chunk, sx;
+        if (id < n_full) {
+            const int e = id / P.n_strips;
+            sx = id % P.n_strips;
+            chunk = e < P.nb_top ? e : P.n_chunks - edge_chunks + e;
+        } else {
+            const int k = id - n_full;
+            const int e = k % edge_strips;
+            chunk = P.nb_top + k / edge_strips;
+            sx = e < P.ns_left ? e : P.n_strips - edge_strips + e;
+        }
+        const int ra = P.st_lo + chunk * P.rows_per_chunk;
+        const int rb = min(ra + P.rows_per_chunk, P.st_hi);
+        if (ra < rb) {
+            const Geom &g = P.g;
+            const long off = (long)ch * g.ch_stride;
+            fused_wave<T, true, L1, UNR, AN>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc, force_border != 0);
         }
     }
+    fused_write_partials<L1, AN>(acc, P.partial_border, ch, scratch);
 }
 
 }  // namespace ccp

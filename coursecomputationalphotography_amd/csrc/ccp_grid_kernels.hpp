@@ -267,19 +267,22 @@ k_check(const double *__restrict__ partial0, long blocks0, const double *__restr
 }
 
 // The same rule for a temporally blocked pass that reported the step of EACH of its T sweeps
-// (partial[(t*channels + ch)*blocks + i]): the first sweep whose step is not above epsilon stops
+// (partial[(t*channels + ch)*blocks + i], one region per launch of the pass): the first sweep whose step is not above epsilon stops
 // the channel, exactly where the reference loop would have stopped.  grid = channels.
 __global__ void __launch_bounds__(kBlock)
-k_check_multi(const double *__restrict__ partial, long blocks, int T, int first_sweep_index, double epsilon,
-              SolveState *__restrict__ st)
+k_check_multi(const double *__restrict__ partial0, long blocks0, const double *__restrict__ partial1, long blocks1,
+              int T, int first_sweep_index, double epsilon, SolveState *__restrict__ st)
 {
     __shared__ double scratch[kBlock / kWave];
     const int ch = blockIdx.x;
     const int channels = gridDim.x;
     for (int t = 0; t < T; ++t) {
+        // two regions: the ordinary launch and the border launch of the pass
         double acc = 0.0;
-        const double *__restrict__ p = partial + ((long)t * channels + ch) * blocks;
-        for (long i = threadIdx.x; i < blocks; i += kBlock) acc += p[i];
+        const double *__restrict__ p = partial0 + ((long)t * channels + ch) * blocks0;
+        for (long i = threadIdx.x; i < blocks0; i += kBlock) acc += p[i];
+        const double *__restrict__ q = partial1 + ((long)t * channels + ch) * blocks1;
+        for (long i = threadIdx.x; i < blocks1; i += kBlock) acc += q[i];
         const double eps = block_sum(acc, scratch);
         if (threadIdx.x == 0 && st->active[ch]) {
             st->last_eps[ch] = eps;
