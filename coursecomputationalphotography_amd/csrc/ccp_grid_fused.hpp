@@ -36,7 +36,10 @@ namespace ccp {
 
 constexpr int kFusedMaxT = 8;
 constexpr int kFusedMaxCheckedT = 5;     // deepest pass that also reports the step of each of its sweeps (+2T VGPRs)
-constexpr int kFusedUnroll = 4;          // march steps unrolled per loop trip (shifted window)
+#ifndef CCP_FUSED_UNROLL
+#define CCP_FUSED_UNROLL 2
+#endif
+constexpr int kFusedUnroll = CCP_FUSED_UNROLL;          // march steps unrolled per loop trip (shifted window)
 // rows loaded ahead of the newest row: enough bytes in flight per CU at the occupancy the
 // register window of T allows (T<=5: 3 waves/SIMD, T>=6: 2 waves/SIMD)
 #ifndef CCP_FUSED_D_LO
