@@ -365,6 +365,7 @@ int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
     geo.own_lo = g->ghost_top;
     geo.own_hi = g->ghost_top + d->row_count;
     geo.pitch = (((long)d->width + 1) / 2 + 15) / 16 * 16;
+    if (const char *e = getenv("CCP_GS_PITCH_PAD")) geo.pitch += std::max(0, atoi(e)) / 16 * 16;   // experiment: de-alias rows
     geo.ch_stride = (long)geo.local_rows * 2 * geo.pitch;
     g->cpt = 2;
     if (const char *e = getenv("CCP_GS_CPT")) g->cpt = (atoi(e) == 4) ? 4 : 2;
@@ -538,7 +539,9 @@ int ccp_grid_tune(ccp_grid *g, int32_t max_t, int32_t *chosen_t, int32_t *chosen
     float tab_ms[kFusedMaxT + 1] = {0};
     int tab_rows[kFusedMaxT + 1] = {0};
     const int rows = g->geom.local_rows;
-    const int chunk_candidates[] = {32, 48, 64, 80, 96, 112, 128, 160, 192, 256};
+    const int fixed_candidates[] = {32, 48, 64, 80, 96, 112, 128, 160, 192, 256};
+    int cus = 256;
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device);
     float best = 1e30f;
     int best_t = 1, best_r = saved_chunk;
     hipEvent_t e0, e1;
@@ -546,6 +549,22 @@ int ccp_grid_tune(ccp_grid *g, int32_t max_t, int32_t *chosen_t, int32_t *chosen
     CCP_HIP(hipEventCreate(&e1));
     int status = CCP_OK;
     for (int T = 1; T <= max_t && status == CCP_OK; ++T) {
+        // plus the chunk heights that fill the chip's wave slots in exactly 1..4 rounds: a short
+        // row block has few tiles, and one tile past a whole round costs a round
+        std::vector<int> chunk_candidates(std::begin(fixed_candidates), std::end(fixed_candidates));
+        {
+            const int U = fused_useful_px(T);
+            const long blocks_x = ((g->geom.W + U - 1) / U + kBlock / kWave - 1) / (kBlock / kWave);
+            const long slots = (long)cus * fused_waves_per_simd(T);       // resident workgroups
+            for (int rounds = 1; rounds <= 4; ++rounds) {
+                const long chunks = rounds * slots / (blocks_x * g->desc.channels);
+                if (chunks < 1) continue;
+                int R = (int)((rows + chunks - 1) / chunks);
+                R += R & 1;
+                if (R >= 16 && R <= 1024 && std::find(chunk_candidates.begin(), chunk_candidates.end(), R) == chunk_candidates.end())
+                    chunk_candidates.push_back(R);
+            }
+        }
         for (int R : chunk_candidates) {
             if (R > rows && R != chunk_candidates[0]) continue;
             g->rows_per_chunk = R;

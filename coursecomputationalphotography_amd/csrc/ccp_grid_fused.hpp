@@ -131,6 +131,8 @@ struct FusedCtx {
     bool px_left[2];    // x >= 1
     bool px_right[2];   // x < W-1
     bool px_first[2];   // x == 0
+    unsigned lane_ld;   // lane index clamped to the existing half-columns (kStepSide loads unconditionally)
+    bool has_first;     // wave-uniform: the strip holds pixel column 0 (the a_ii = 3 column)
 };
 
 // One march step: newest row f, unrolled position i.  Three bodies, chosen per loop trip:
@@ -147,7 +149,11 @@ struct FusedCtx {
 // L1: 0 = no step norm; 1 = accumulate sum|x_new - x_old| of the pass's LAST iteration in acc[0];
 // 2 = of EVERY iteration t = 1..T in acc[t-1] (old is the previous level of the same colour, which
 // the window still holds — the reference's per-sweep manhattonDist at no extra memory traffic).
-constexpr int kStepFast = 0, kStepRanged = 1, kStepBorder = 2;
+//   kStepSide   : (border tiles only) ordinary existing rows like kStepFast, but a strip at the
+//                 left/right image edge: straight-line too — absent neighbours are selected to 0
+//                 per lane (adding 0 is exact, so the sum keeps the reference's order), a_ii is
+//                 4 inside, 1 in column W-1 and 3 in column 0 (the only true division).
+constexpr int kStepFast = 0, kStepRanged = 1, kStepBorder = 2, kStepSide = 3;
 
 template <int T, int MODE, int L1, int UNR, int NT, int AN>
 __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], double (&br)[NT], double (&bk)[NT],
@@ -159,9 +165,17 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
     {
         const int q = f + D;
         const int sq = Win::slot(i, -D);
-        if (MODE == kStepFast || (q >= cx.m0 && q < cx.m1)) {
+        if (MODE == kStepFast || MODE == kStepSide || (q >= cx.m0 && q < cx.m1)) {
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            if (MODE != kStepBorder || cx.col_ok) {
+            if (MODE == kStepSide) {
+                // lanes outside the image re-read the nearest existing half-column; their values
+                // are never used (masked as neighbours, never updated or stored)
+                const long o0 = row_off(g, q, 0) + cx.jbase, o1 = row_off(g, q, 1) + cx.jbase;
+                a0 = (cx.xin + o0)[(int)cx.lane_ld];
+                a1 = (cx.xin + o1)[(int)cx.lane_ld];
+                a2 = (cx.bb + o0)[(int)cx.lane_ld];
+                a3 = (cx.bb + o1)[(int)cx.lane_ld];
+            } else if (MODE != kStepBorder || cx.col_ok) {
                 // uniform row base + lane index
                 const long o0 = row_off(g, q, 0) + cx.jbase, o1 = row_off(g, q, 1) + cx.jbase;
                 a0 = (cx.xin + o0)[cx.lane];
@@ -179,7 +193,7 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
         const int sr = Win::slot(i, h), su = Win::slot(i, h + 1), sd = Win::slot(i, h - 1);
         const int c = (h - 1) & 1;                       // 0 = red, 1 = black
         const int p = ((i - h + 2 * HS + 2) + c) & 1;    // pixel column = 2j + p
-        if (MODE == kStepFast || (r >= cx.m0 && r < cx.m1)) {
+        if (MODE == kStepFast || MODE == kStepSide || (r >= cx.m0 && r < cx.m1)) {
             // opposite colour: rows r-1, r, r+1
             const double up = c ? wr[su] : wk[su];
             const double dn = c ? wr[sd] : wk[sd];
@@ -190,7 +204,17 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
             const double bv = c ? bk[sr] : br[sr];
             const double old = c ? wk[sr] : wr[sr];
             double nv = old;
-            if (MODE != kStepBorder) {
+            if (MODE == kStepSide) {
+                // ordinary row y in [1, H-2]: cell(x,y-1), cell(x,y) exist iff x < W-1 (up, right,
+                // down), cell(x-1,y) iff x >= 1 (left); a_ii = 3[x < W-1] + [x >= 1]
+                const bool mr = cx.px_right[p], ml = cx.px_left[p];
+                const double t = bv + ((((mr ? up : 0.0) + (ml ? left : 0.0)) + (mr ? right : 0.0)) + (mr ? dn : 0.0));
+                double q = t * (ml && mr ? 0.25 : 1.0);
+                if (p == 0 && cx.has_first) {
+                    if (cx.px_first[0]) q = t / 3.0;
+                }
+                nv = cx.px_ok[p] ? q : old;
+            } else if (MODE != kStepBorder) {
                 nv = (bv + (((up + left) + right) + dn)) * 0.25;
             } else {
                 // Most rows of a border trip are still ordinary: an image row with both neighbour
@@ -222,7 +246,7 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
             }
             if ((L1 == 1 && h >= HS - 1) || L1 == 2) {
                 const bool counted = cx.col_store && r >= cx.ra && r < cx.rb && r >= g.own_lo && r < g.own_hi &&
-                                     (MODE != kStepBorder || cx.px_ok[p]);
+                                     ((MODE != kStepBorder && MODE != kStepSide) || cx.px_ok[p]);
                 if (counted) acc[L1 == 2 ? (h - 1) / 2 : 0] += fabs(nv - old);
             }
             if (c) wk[sr] = nv; else wr[sr] = nv;
@@ -264,6 +288,8 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     const int ux0 = sx * U, ux1 = ux0 + U;              // pixel columns this strip stores
     cx.col_store = cx.col_ok && (2 * cx.j >= ux0) && (2 * cx.j + 1 < ux1);
     cx.col_interior = (px0 >= 1) && (px0 + 2 * kStripLanes <= g.W - 1);
+    cx.lane_ld = (unsigned)(min(max(cx.j, 0), (int)g.pitch - 1) - cx.jbase);
+    cx.has_first = (px0 <= 0) && (px0 + 2 * kStripLanes > 0);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int x = 2 * cx.j + p;
@@ -287,14 +313,20 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     for (int s = 0; s < NT; ++s) wr[s] = wk[s] = br[s] = bk[s] = 0.0;
 
     for (int fb = base - D; fb <= f_end; fb += G) {
-        bool plain = true;
+        bool plain = true, side = false;
         if (BORDERTILE) {
             // rows the trip may update: fb-HS .. fb+G-2, clipped to the rows this wave holds
             const int r_first = max(fb - HS, cx.m0), r_last = min(fb + G - 2, cx.m1 - 1);
-            plain = !force_border && cx.col_interior && (g.y0 + r_first >= 1) && (g.y0 + r_last <= g.H - 2) &&
-                    (r_first >= 1) && (r_last + 1 < g.local_rows);
+            const bool rows_plain = !force_border && (g.y0 + r_first >= 1) && (g.y0 + r_last <= g.H - 2) &&
+                                    (r_first >= 1) && (r_last + 1 < g.local_rows);
+            plain = rows_plain && cx.col_interior;
+            side = rows_plain && !cx.col_interior && fb >= s_lo && fb + G - 1 <= s_hi;
         }
-        if (plain && fb >= s_lo && fb + G - 1 <= s_hi) {
+        if (BORDERTILE && side) {
+#pragma unroll
+            for (int i = 0; i < G; ++i)
+                fused_step<T, kStepSide, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+        } else if (plain && fb >= s_lo && fb + G - 1 <= s_hi) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
                 fused_step<T, kStepFast, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
