@@ -40,15 +40,6 @@ constexpr int kFusedMaxCheckedT = 5;     // deepest pass that also reports the s
 #define CCP_FUSED_UNROLL 2
 #endif
 constexpr int kFusedUnroll = CCP_FUSED_UNROLL;          // march steps unrolled per loop trip (shifted window)
-// rows loaded ahead of the newest row: enough bytes in flight per CU at the occupancy the
-// register window of T allows (T<=5: 3 waves/SIMD, T>=6: 2 waves/SIMD)
-#ifndef CCP_FUSED_D_LO
-#define CCP_FUSED_D_LO 2
-#endif
-#ifndef CCP_FUSED_D_HI
-#define CCP_FUSED_D_HI 2
-#endif
-__host__ __device__ constexpr int fused_prefetch(int T) { return T <= 5 ? CCP_FUSED_D_LO : CCP_FUSED_D_HI; }
 constexpr int kStripLanes = kWave;       // half-columns per strip
 
 __host__ __device__ constexpr int fused_halo_px(int T) { return 2 * T; }               // per side
@@ -91,37 +82,57 @@ struct FusedParams {
     double *__restrict__ partial_border;   // L1 sums of the border launch (same layout, own region)
 };
 
-// How the row window maps onto registers.  G march steps are unrolled per loop trip.
-//   G == N (UNR = 0): the window rotates by renaming, slot = (step - distance) mod N, no copies,
-//       but the code grows as N*2T row updates (T=5: 74 KB, T=8: 177 KB — past the instruction
-//       cache: T=8 measured 3.0 ms per pass against 2.0 ms for the shifted form).  Kept for
-//       reference; the library instantiates UNR = kFusedUnroll only.
-//   G == UNR (> 0)  : slot = 2T+1 + step - distance inside a trip, then the whole window is
-//       shifted down by UNR slots ((2T+D+1)*4/UNR register moves per step); code ~ UNR*2T updates.
+// How the row window maps onto registers.  G = UNR march steps are unrolled per loop trip: inside
+// a trip the row at `dist` rows behind the newest row of step i sits in slot 2T+1 + i - dist;
+// after the trip the whole window is shifted down by G slots ((2T+1)*4/G register moves per step;
+// code ~ G*2T row updates — the fully renamed form, no moves but N*2T updates, is 177 KB at T=8
+// and lost 1.5x to instruction-cache misses).
+// Rows in flight from memory are not in the window: a trip first issues the loads of the G rows
+// the NEXT trip will start with into landing registers, runs its G steps, shifts the window and
+// only then moves the landed rows in.  Loads and their first use sit in the same loop iteration,
+// a whole trip of arithmetic apart, and nothing that is shifted is the destination of a load in
+// flight.
 template <int T, int UNR>
 struct FusedWindow {
+    static_assert(UNR > 0 && UNR % 2 == 0, "row parity must be a compile-time constant per unrolled step");
     static constexpr int HS = 2 * T;
-    static constexpr int D = fused_prefetch(T);
-    static constexpr int NFULL = HS + 2 + D;
-    static constexpr int G = UNR > 0 ? UNR : NFULL;
-    static constexpr int NT = UNR > 0 ? HS + D + UNR + 1 : NFULL;
-    static_assert(G % 2 == 0 && D % 2 == 0, "row parity must be a compile-time constant per unrolled step");
-    // slot of the row at `dist` rows behind the newest row of unrolled step i (dist in [-D, HS+1])
-    __host__ __device__ static constexpr int slot(int i, int dist)
-    {
-        return UNR > 0 ? (HS + 1 + i - dist) : ((i - D - dist) % NFULL + 2 * NFULL) % NFULL;
-    }
+    static constexpr int G = UNR;
+    static constexpr int NT = HS + G + 1;
+    // slot of the row at `dist` rows behind the newest row of unrolled step i (dist in [0, HS+1])
+    __host__ __device__ static constexpr int slot(int i, int dist) { return HS + 1 + i - dist; }
 };
 
-// Wave-uniform march parameters (SGPRs) and the few per-lane predicates of a strip.
+// Memory goes through raw buffer instructions with one descriptor per image row: a row that does
+// not exist gets num_records = 0 and a lane whose half-column does not exist (or must not be
+// stored) an offset past the row, so loads return 0 and stores are dropped by the address range
+// check instead of by branches.  With no branch around any memory instruction the march is
+// straight-line code and every s_waitcnt the compiler places is an exact count.
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+constexpr unsigned kLaneOut = 0x80000000u;          // byte offset no row reaches
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double *plane, const Geom &g, int row, bool exists)
+{
+    // base of the red half-row; the black half-row follows at +pitch doubles
+    return __builtin_amdgcn_make_buffer_rsrc((void *)(plane + (long)row * 2 * g.pitch), 0,
+                                             exists ? (int)(g.pitch * 16) : 0, 0x00020000);
+}
+__device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t rs, unsigned voff)
+{
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0));
+}
+__device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t rs, unsigned voff)
+{
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, (int)voff, 0, 0);
+}
+
+// Wave-uniform march parameters (SGPRs) and the few per-lane values of a strip.
 struct FusedCtx {
     const double *__restrict__ xin;
     double *__restrict__ xout;
     const double *__restrict__ bb;
-    int jbase;          // half-column of lane 0 (may be negative in the first strip)
-    int j;              // this lane's half-column
-    unsigned lane;
-    bool col_ok;        // lane's half-column exists
+    int j;              // this lane's half-column (may be negative in the first strip)
+    unsigned ld_r, ld_k;   // byte offset of the lane's red / black pixel inside a row, kLaneOut if the half-column does not exist
+    unsigned st_r, st_k;   // the same for stores: kLaneOut unless the strip stores this half-column
     bool col_store;     // lane's pixels belong to the columns this strip stores
     int ra, rb;         // rows to finalise and store
     int m0, m1;         // rows loaded
@@ -131,169 +142,150 @@ struct FusedCtx {
     bool px_left[2];    // x >= 1
     bool px_right[2];   // x < W-1
     bool px_first[2];   // x == 0
-    unsigned lane_ld;   // lane index clamped to the existing half-columns (kStepSide loads unconditionally)
     bool has_first;     // wave-uniform: the strip holds pixel column 0 (the a_ii = 3 column)
 };
 
-// One march step: newest row f, unrolled position i.  Three bodies, chosen per loop trip:
-//   kStepFast   : every row the step touches exists (inside [m0, m1)) and is an ordinary image row
-//                 of a strip away from the left/right image edge: loads and row updates are
-//                 straight-line, branch-free code (the only scalar branch left guards the store of
-//                 the finished row), so the s_waitcnt pass can count the loads in flight instead
-//                 of draining them — that is what lets the D-rows-ahead prefetch overlap;
-//   kStepRanged : ordinary rows, but some may not exist yet / any more (pipeline fill and drain):
-//                 the same arithmetic behind wave-uniform range checks;
-//   kStepBorder : (border tiles only) rows at an image edge or at the stale edge of a ghost zone,
-//                 or a strip at the left/right image edge: range checks plus the border-aware
-//                 arithmetic of SURVEY §8a-8.
+// Row q of x (red, black) and b (red, black); rows outside [m0, m1) and lanes outside the image read 0.
+__device__ __forceinline__ void fused_load_row(const FusedCtx &cx, const Geom &g, int q, double (&dst)[4])
+{
+    const bool exists = q >= cx.m0 && q < cx.m1;
+    const __amdgpu_buffer_rsrc_t rx = row_rsrc(cx.xin, g, q, exists), rbb = row_rsrc(cx.bb, g, q, exists);
+    dst[0] = buf_load(rx, cx.ld_r);
+    dst[1] = buf_load(rx, cx.ld_k);
+    dst[2] = buf_load(rbb, cx.ld_r);
+    dst[3] = buf_load(rbb, cx.ld_k);
+}
+
+// One march step: newest row f, unrolled position i: half-sweep h on row f - h for h = 1..2T, then
+// the store of row f - 2T.  No range checks: rows that do not exist (pipeline fill and drain, the
+// outside of the image) hold zeros or garbage, are updated like any other, are never stored, and
+// by the trapezoid argument never reach a stored value.  Three bodies, chosen per loop trip:
+//   kStepFast   : ordinary image rows of a strip away from the left/right image edge — the only
+//                 body of k_fused_sweep;
+//   kStepSide   : (border tiles) ordinary rows, strip at the left/right image edge: absent
+//                 neighbours are selected to 0 per lane (adding 0 is exact, so the sum keeps the
+//                 reference's order), a_ii is 4 inside, 1 in column W-1 and 3 in column 0 (the
+//                 only true division);
+//   kStepBorder : (border tiles) rows at an image edge or at the stale edge of a ghost zone: the
+//                 border-aware arithmetic of SURVEY §8a-8 from per-lane column flags and
+//                 wave-uniform row flags.
 // L1: 0 = no step norm; 1 = accumulate sum|x_new - x_old| of the pass's LAST iteration in acc[0];
 // 2 = of EVERY iteration t = 1..T in acc[t-1] (old is the previous level of the same colour, which
 // the window still holds — the reference's per-sweep manhattonDist at no extra memory traffic).
-//   kStepSide   : (border tiles only) ordinary existing rows like kStepFast, but a strip at the
-//                 left/right image edge: straight-line too — absent neighbours are selected to 0
-//                 per lane (adding 0 is exact, so the sum keeps the reference's order), a_ii is
-//                 4 inside, 1 in column W-1 and 3 in column 0 (the only true division).
-constexpr int kStepFast = 0, kStepRanged = 1, kStepBorder = 2, kStepSide = 3;
+constexpr int kStepFast = 0, kStepBorder = 2, kStepSide = 3;
 
 template <int T, int MODE, int L1, int UNR, int NT, int AN>
 __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], double (&br)[NT], double (&bk)[NT],
                                            double (&acc)[AN], const FusedCtx &cx, const Geom &g, int f, int i)
 {
     using Win = FusedWindow<T, UNR>;
-    constexpr int HS = Win::HS, D = Win::D;
-    // ---- load row q = f + D into its slot ---------------------------------------------------
-    {
-        const int q = f + D;
-        const int sq = Win::slot(i, -D);
-        if (MODE == kStepFast || MODE == kStepSide || (q >= cx.m0 && q < cx.m1)) {
-            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-            if (MODE == kStepSide) {
-                // lanes outside the image re-read the nearest existing half-column; their values
-                // are never used (masked as neighbours, never updated or stored)
-                const long o0 = row_off(g, q, 0) + cx.jbase, o1 = row_off(g, q, 1) + cx.jbase;
-                a0 = (cx.xin + o0)[(int)cx.lane_ld];
-                a1 = (cx.xin + o1)[(int)cx.lane_ld];
-                a2 = (cx.bb + o0)[(int)cx.lane_ld];
-                a3 = (cx.bb + o1)[(int)cx.lane_ld];
-            } else if (MODE != kStepBorder || cx.col_ok) {
-                // uniform row base + lane index
-                const long o0 = row_off(g, q, 0) + cx.jbase, o1 = row_off(g, q, 1) + cx.jbase;
-                a0 = (cx.xin + o0)[cx.lane];
-                a1 = (cx.xin + o1)[cx.lane];
-                a2 = (cx.bb + o0)[cx.lane];
-                a3 = (cx.bb + o1)[cx.lane];
-            }
-            wr[sq] = a0; wk[sq] = a1; br[sq] = a2; bk[sq] = a3;
-        }
-    }
-    // ---- half-sweep h on row f - h, h = 1..HS ----------------------------------------------
+    constexpr int HS = Win::HS;
 #pragma unroll
     for (int h = 1; h <= HS; ++h) {
         const int r = f - h;
         const int sr = Win::slot(i, h), su = Win::slot(i, h + 1), sd = Win::slot(i, h - 1);
         const int c = (h - 1) & 1;                       // 0 = red, 1 = black
         const int p = ((i - h + 2 * HS + 2) + c) & 1;    // pixel column = 2j + p
-        if (MODE == kStepFast || MODE == kStepSide || (r >= cx.m0 && r < cx.m1)) {
-            // opposite colour: rows r-1, r, r+1
-            const double up = c ? wr[su] : wk[su];
-            const double dn = c ? wr[sd] : wk[sd];
-            const double same = c ? wr[sr] : wk[sr];
-            const double other = p ? lane_next(same) : lane_prev(same);
-            const double left = p ? same : other;
-            const double right = p ? other : same;
-            const double bv = c ? bk[sr] : br[sr];
-            const double old = c ? wk[sr] : wr[sr];
-            double nv = old;
-            if (MODE == kStepSide) {
-                // ordinary row y in [1, H-2]: cell(x,y-1), cell(x,y) exist iff x < W-1 (up, right,
-                // down), cell(x-1,y) iff x >= 1 (left); a_ii = 3[x < W-1] + [x >= 1]
-                const bool mr = cx.px_right[p], ml = cx.px_left[p];
-                const double t = bv + ((((mr ? up : 0.0) + (ml ? left : 0.0)) + (mr ? right : 0.0)) + (mr ? dn : 0.0));
-                double q = t * (ml && mr ? 0.25 : 1.0);
-                if (p == 0 && cx.has_first) {
-                    if (cx.px_first[0]) q = t / 3.0;
-                }
-                nv = cx.px_ok[p] ? q : old;
-            } else if (MODE != kStepBorder) {
+        // opposite colour: rows r-1, r, r+1
+        const double up = c ? wr[su] : wk[su];
+        const double dn = c ? wr[sd] : wk[sd];
+        const double same = c ? wr[sr] : wk[sr];
+        const double other = p ? lane_next(same) : lane_prev(same);
+        const double left = p ? same : other;
+        const double right = p ? other : same;
+        const double bv = c ? bk[sr] : br[sr];
+        const double old = c ? wk[sr] : wr[sr];
+        double nv = old;
+        if (MODE == kStepFast) {
+            nv = (bv + (((up + left) + right) + dn)) * 0.25;
+        } else if (MODE == kStepSide) {
+            // ordinary row y in [1, H-2]: cell(x,y-1), cell(x,y) exist iff x < W-1 (up, right,
+            // down), cell(x-1,y) iff x >= 1 (left); a_ii = 3[x < W-1] + [x >= 1]
+            const bool mr = cx.px_right[p], ml = cx.px_left[p];
+            const double t = bv + ((((mr ? up : 0.0) + (ml ? left : 0.0)) + (mr ? right : 0.0)) + (mr ? dn : 0.0));
+            double q = t * (ml && mr ? 0.25 : 1.0);
+            if (p == 0 && cx.has_first) {
+                if (cx.px_first[0]) q = t / 3.0;
+            }
+            nv = cx.px_ok[p] ? q : old;
+        } else {
+            // Most rows of a border trip are still ordinary: an image row with both neighbour
+            // rows present, in a strip away from the left/right image edge, takes the plain
+            // update.  Otherwise the stencil of SURVEY §8a-8 is evaluated from the per-lane
+            // column flags and the (wave-uniform) row flags; only a_ii = 3 (image row 0, image
+            // column 0) needs a true division — 1, 2 and 4 are exact reciprocals.
+            const int y = g.y0 + r;
+            const bool row_plain = (y >= 1) && (y <= g.H - 2) && (r >= 1) && (r + 1 < g.local_rows);
+            if (row_plain && cx.col_interior) {
                 nv = (bv + (((up + left) + right) + dn)) * 0.25;
-            } else {
-                // Most rows of a border trip are still ordinary: an image row with both neighbour
-                // rows present, in a strip away from the left/right image edge, takes the plain
-                // update.  Otherwise the stencil of SURVEY §8a-8 is evaluated from the per-lane
-                // column flags and the (wave-uniform) row flags; only a_ii = 3 (image row 0, image
-                // column 0) needs a true division — 1, 2 and 4 are exact reciprocals.
-                const int y = g.y0 + r;
-                const bool row_plain = (y >= 1) && (y <= g.H - 2) && (r >= 1) && (r + 1 < g.local_rows);
-                if (row_plain && cx.col_interior) {
-                    nv = (bv + (((up + left) + right) + dn)) * 0.25;
-                } else if (cx.px_ok[p]) {
-                    const bool cellrow = y < g.H - 1;                        // cell(.,y) rows
-                    const bool cf_up = (y >= 1) && cx.px_right[p];           // cell(x, y-1)
-                    const bool s_left = cx.px_left[p] && cellrow;            // cell(x-1, y)
-                    const bool s_here = cx.px_right[p] && cellrow;           // cell(x, y)
-                    const int diag = (int)cf_up + (int)s_left + 2 * (int)s_here + (int)(cx.px_first[p] && y == 0);
-                    const bool s_up = cf_up && (r >= 1);
-                    const bool s_down = s_here && (r + 1 < g.local_rows);
-                    double sigma = 0.0;
-                    if (s_up) sigma += -1.0 * up;
-                    if (s_left) sigma += -1.0 * left;
-                    if (s_here) sigma += -1.0 * right;
-                    if (s_down) sigma += -1.0 * dn;
-                    const double t = bv - sigma;
-                    if (diag == 3) nv = t / 3.0;
-                    else if (diag != 0) nv = t * (diag == 4 ? 0.25 : (diag == 2 ? 0.5 : 1.0));
-                }
+            } else if (cx.px_ok[p]) {
+                const bool cellrow = y < g.H - 1;                        // cell(.,y) rows
+                const bool cf_up = (y >= 1) && cx.px_right[p];           // cell(x, y-1)
+                const bool s_left = cx.px_left[p] && cellrow;            // cell(x-1, y)
+                const bool s_here = cx.px_right[p] && cellrow;           // cell(x, y)
+                const int diag = (int)cf_up + (int)s_left + 2 * (int)s_here + (int)(cx.px_first[p] && y == 0);
+                const bool s_up = cf_up && (r >= 1);
+                const bool s_down = s_here && (r + 1 < g.local_rows);
+                double sigma = 0.0;
+                if (s_up) sigma += -1.0 * up;
+                if (s_left) sigma += -1.0 * left;
+                if (s_here) sigma += -1.0 * right;
+                if (s_down) sigma += -1.0 * dn;
+                const double t = bv - sigma;
+                if (diag == 3) nv = t / 3.0;
+                else if (diag != 0) nv = t * (diag == 4 ? 0.25 : (diag == 2 ? 0.5 : 1.0));
             }
-            if ((L1 == 1 && h >= HS - 1) || L1 == 2) {
-                const bool counted = cx.col_store && r >= cx.ra && r < cx.rb && r >= g.own_lo && r < g.own_hi &&
-                                     ((MODE != kStepBorder && MODE != kStepSide) || cx.px_ok[p]);
-                if (counted) acc[L1 == 2 ? (h - 1) / 2 : 0] += fabs(nv - old);
-            }
-            if (c) wk[sr] = nv; else wr[sr] = nv;
         }
+        if ((L1 == 1 && h >= HS - 1) || L1 == 2) {
+            const bool counted = cx.col_store && r >= cx.ra && r < cx.rb && r >= g.own_lo && r < g.own_hi &&
+                                 (MODE == kStepFast || cx.px_ok[p]);
+            if (counted) acc[L1 == 2 ? (h - 1) / 2 : 0] += fabs(nv - old);
+        }
+        if (c) wk[sr] = nv; else wr[sr] = nv;
     }
-    // ---- row f - HS is final: store it -----------------------------------------------------
+    // ---- row f - HS is final: store it (dropped by the range check outside [ra, rb)) ----------
     {
         const int r = f - HS;
         const int sr = Win::slot(i, HS);
-        if (r >= cx.ra && r < cx.rb && cx.col_store) {
-            (cx.xout + (row_off(g, r, 0) + cx.jbase))[cx.lane] = wr[sr];
-            (cx.xout + (row_off(g, r, 1) + cx.jbase))[cx.lane] = wk[sr];
-        }
+        const __amdgpu_buffer_rsrc_t ro = row_rsrc(cx.xout, g, r, r >= cx.ra && r < cx.rb);
+        buf_store(wr[sr], ro, cx.st_r);
+        buf_store(wk[sr], ro, cx.st_k);
     }
-    // keep the machine scheduler from pulling later steps' loads/updates up across this point:
-    // unconstrained it hoists all G steps' work together and spills the register window
+    // keep the machine scheduler from pulling later steps' work up across this point:
+    // unconstrained it hoists all G steps together and spills the register window
     __builtin_amdgcn_sched_barrier(0);
 }
 
 // One wave: strip `sx`, rows [ra, rb) of channel data at xin/xout/b (already channel-offset).
-// BORDERTILE = false: every pixel the wave can touch is ordinary; trips are kStepFast /
-// kStepRanged and nothing border-related is computed.  BORDERTILE = true: each trip picks among
-// all three bodies (force_border: debug, every trip takes kStepBorder).
+// BORDERTILE = false: every pixel the wave can touch is ordinary: one straight-line loop of
+// kStepFast trips.  BORDERTILE = true: each trip picks among the three bodies (force_border:
+// debug, every trip takes kStepBorder).
 template <int T, bool BORDERTILE, int L1, int UNR, int AN>
 __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, double *__restrict__ xout,
                                            const double *__restrict__ bb, const Geom &g, int sx,
                                            int ra, int rb, double (&acc)[AN], bool force_border = false)
 {
     using Win = FusedWindow<T, UNR>;
-    constexpr int HS = Win::HS, D = Win::D, G = Win::G, NT = Win::NT;
+    constexpr int HS = Win::HS, G = Win::G, NT = Win::NT;
     FusedCtx cx;
     cx.xin = xin; cx.xout = xout; cx.bb = bb;
-    cx.lane = threadIdx.x & (kWave - 1);
+    const int lane = (int)(threadIdx.x & (kWave - 1));
     const int U = fused_useful_px(T);
     const int px0 = sx * U - fused_halo_px(T);          // first pixel column of the strip (even)
-    cx.jbase = px0 / 2;                                 // wave-uniform (sx is): row pointers stay scalar
-    cx.j = cx.jbase + (int)cx.lane;                     // this lane's half-column (may be < 0)
-    cx.col_ok = (cx.j >= 0) && (cx.j < g.pitch);
+    cx.j = px0 / 2 + lane;                              // this lane's half-column (may be < 0)
+    const bool col_ok = (cx.j >= 0) && (cx.j < g.pitch);
     const int ux0 = sx * U, ux1 = ux0 + U;              // pixel columns this strip stores
-    cx.col_store = cx.col_ok && (2 * cx.j >= ux0) && (2 * cx.j + 1 < ux1);
+    cx.col_store = col_ok && (2 * cx.j >= ux0) && (2 * cx.j + 1 < ux1);
+    cx.ld_r = col_ok ? (unsigned)cx.j * 8u : kLaneOut;
+    cx.ld_k = col_ok ? (unsigned)(g.pitch + cx.j) * 8u : kLaneOut;
+    cx.st_r = cx.col_store ? cx.ld_r : kLaneOut;
+    cx.st_k = cx.col_store ? cx.ld_k : kLaneOut;
     cx.col_interior = (px0 >= 1) && (px0 + 2 * kStripLanes <= g.W - 1);
-    cx.lane_ld = (unsigned)(min(max(cx.j, 0), (int)g.pitch - 1) - cx.jbase);
     cx.has_first = (px0 <= 0) && (px0 + 2 * kStripLanes > 0);
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int x = 2 * cx.j + p;
-        cx.px_ok[p] = cx.col_ok && x < g.W;
+        cx.px_ok[p] = col_ok && x < g.W;
         cx.px_left[p] = x >= 1;
         cx.px_right[p] = x < g.W - 1;
         cx.px_first[p] = x == 0;
@@ -305,47 +297,54 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     // trip, so the colour parity of every unrolled row update is a compile-time constant
     const int base = cx.m0 - ((g.y0 + cx.m0) & 1);
     const int f_end = rb - 1 + HS;                      // last step: row rb-1 gets half-sweep HS
-    // steps f in [s_lo, s_hi] touch only existing rows: r = f-h >= m0 for h <= HS+1, f+D < m1
-    const int s_lo = cx.m0 + HS + 1, s_hi = cx.m1 - 1 - D;
 
     double wr[NT], wk[NT], br[NT], bk[NT];              // x red/black, b red/black per window row
+    double land[G][4];                                  // rows in flight
 #pragma unroll
     for (int s = 0; s < NT; ++s) wr[s] = wk[s] = br[s] = bk[s] = 0.0;
-
-    for (int fb = base - D; fb <= f_end; fb += G) {
-        bool plain = true, side = false;
-        if (BORDERTILE) {
-            // rows the trip may update: fb-HS .. fb+G-2, clipped to the rows this wave holds
-            const int r_first = max(fb - HS, cx.m0), r_last = min(fb + G - 2, cx.m1 - 1);
-            const bool rows_plain = !force_border && (g.y0 + r_first >= 1) && (g.y0 + r_last <= g.H - 2) &&
-                                    (r_first >= 1) && (r_last + 1 < g.local_rows);
-            plain = rows_plain && cx.col_interior;
-            side = rows_plain && !cx.col_interior && fb >= s_lo && fb + G - 1 <= s_hi;
-        }
-        if (BORDERTILE && side) {
 #pragma unroll
-            for (int i = 0; i < G; ++i)
-                fused_step<T, kStepSide, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
-        } else if (plain && fb >= s_lo && fb + G - 1 <= s_hi) {
+    for (int i = 0; i < G; ++i) fused_load_row(cx, g, base + i, land[i]);
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        const int s0 = Win::slot(i, 0);
+        wr[s0] = land[i][0]; wk[s0] = land[i][1]; br[s0] = land[i][2]; bk[s0] = land[i][3];
+    }
+
+    for (int fb = base; fb <= f_end; fb += G) {
+#pragma unroll
+        for (int i = 0; i < G; ++i) fused_load_row(cx, g, fb + G + i, land[i]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (!BORDERTILE) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
                 fused_step<T, kStepFast, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
-        } else if (plain) {
+        } else {
+            // rows the trip updates that matter: fb-HS .. fb+G-2, clipped to the rows this wave holds
+            const int r_first = max(fb - HS, cx.m0), r_last = min(fb + G - 2, cx.m1 - 1);
+            const bool rows_plain = !force_border && (g.y0 + r_first >= 1) && (g.y0 + r_last <= g.H - 2) &&
+                                    (r_first >= 1) && (r_last + 1 < g.local_rows);
+            if (rows_plain && cx.col_interior) {
 #pragma unroll
-            for (int i = 0; i < G; ++i)
-                if (fb + i <= f_end)
-                    fused_step<T, kStepRanged, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
-        } else if (BORDERTILE) {
+                for (int i = 0; i < G; ++i)
+                    fused_step<T, kStepFast, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+            } else if (rows_plain) {
 #pragma unroll
-            for (int i = 0; i < G; ++i)
-                if (fb + i <= f_end)
+                for (int i = 0; i < G; ++i)
+                    fused_step<T, kStepSide, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+            } else {
+#pragma unroll
+                for (int i = 0; i < G; ++i)
                     fused_step<T, kStepBorder, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
-        }
-        if (UNR > 0) {
-#pragma unroll
-            for (int s = 0; s + G < NT; ++s) {
-                wr[s] = wr[s + G]; wk[s] = wk[s + G]; br[s] = br[s + G]; bk[s] = bk[s + G];
             }
+        }
+#pragma unroll
+        for (int s = 0; s + G < NT; ++s) {
+            wr[s] = wr[s + G]; wk[s] = wk[s + G]; br[s] = br[s + G]; bk[s] = bk[s + G];
+        }
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            const int s0 = Win::slot(i, 0);
+            wr[s0] = land[i][0]; wk[s0] = land[i][1]; br[s0] = land[i][2]; bk[s0] = land[i][3];
         }
     }
 }
