@@ -349,9 +349,16 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     }
 }
 
-// fused_waves_per_simd(T) is the 2nd __launch_bounds__ argument: it caps the register allocator,
-// so the straight-line code cannot trade occupancy for load hoisting.
-__host__ __device__ constexpr int fused_waves_per_simd(int T, int L1 = 0) { return T <= 1 ? 4 : (T <= (L1 == 2 ? 2 : 3) ? 3 : 2); }
+// The 2nd __launch_bounds__ argument (waves per SIMD) caps the register allocator at what the
+// window of depth T needs anyway ((2T+5) rows x 4 values x 2 VGPRs + addresses), so the scheduler
+// cannot trade occupancy for hoisted loads.  512 VGPRs per SIMD lane: 64 -> 8 waves, 102 -> 5,
+// 128 -> 4, 168 -> 3, 256 -> 2.
+__host__ __device__ constexpr int fused_waves_per_simd(int T, int L1 = 0)
+{
+    return L1 == 0 ? (T <= 2 ? 8 : T <= 3 ? 5 : T <= 5 ? 4 : T <= 7 ? 3 : 2)
+                   : (T <= 1 ? 6 : T <= 3 ? 4 : T <= 5 ? 3 : 2);
+}
+__host__ __device__ constexpr int fused_border_waves_per_simd(int T) { return T <= 1 ? 4 : (T <= 4 ? 3 : 2); }
 
 __device__ __forceinline__ bool fused_is_border_tile(const FusedParams &P, int chunk, int sx)
 {
@@ -404,7 +411,7 @@ k_fused_sweep(FusedParams P)
 // a second stream beside k_fused_sweep: its waves take ~2.6x longer at T=8 when a whole trip is
 // border work, and as part of one launch they used to be the tail every small grid waited for.
 template <int T, int L1, int UNR>
-__global__ void __launch_bounds__(kBlock, fused_waves_per_simd(T, L1))
+__global__ void __launch_bounds__(kBlock, fused_border_waves_per_simd(T))
 k_fused_border(FusedParams P, int force_border)
 {
     __shared__ double scratch[kBlock / kWave];
