@@ -20,6 +20,8 @@ Extra objects in the JSON line:
                  the kernel keeps rows in registers across T iterations its HBM traffic
                  (`traffic`, from the committed rocprofv3 PMC pass) is far BELOW the algorithmic
                  bytes, so `frac` exceeds 1: the path runs above the 24 B/update HBM roofline.
+                 `traffic_gbs` / `traffic_frac_of_peak` price the measured bytes instead: how
+                 close the pass runs to what the memory system can move.
   cpu_baseline — the compiled reference header (oracle/_ref, kind "reference") or the C oracle
                  (kind "port") timed on ONE host core on a bounded sample (N=1, rank 0 only).
 """
@@ -172,7 +174,10 @@ def main():
     roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
                 "traffic_source": traffic_src,
-                "kernel": "k_fused_sweep" if fused else "k_half_sweep",
+                # what the memory system really moved (PMC pass) over the same launch duration
+                "traffic_gbs": (traffic / avg_launch_s / 1e9) if (traffic and launches) else None,
+                "traffic_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and launches) else None,
+                "kernel": "k_fused_sweep (+ k_fused_border on a second stream, same pass)" if fused else "k_half_sweep",
                 "iterations_per_launch": iters_timed / max(launches, 1),
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * updates_per_launch}
