@@ -73,6 +73,26 @@ def test_fused_equals_in_place_kernel_16384(capi, monkeypatch):
     g.close()
 
 
+@pytest.mark.parametrize("W,H,iters", [(3001, 2003, 16), (4096, 1500, 24), (1027, 4099, 11)])
+def test_every_pixel_fused_equals_in_place_unstructured(capi, monkeypatch, W, H, iters):
+    """Unstructured random b and x0 (nothing is a fixed point, nothing cancels), whole image compared
+    pixel by pixel: ordinary tiles, the straight-line side strips (a_ii = 3 in column 0, 1 in column
+    W-1), top/bottom border trips, lanes and rows dropped by the buffer range check."""
+    rng = np.random.Generator(np.random.MT19937(5))
+    b = rng.uniform(-3.0, 3.0, (H, W))
+    x0 = rng.uniform(0.0, 255.0, (H, W))
+    out = []
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("CCP_GS_FUSE", fuse)
+        g = capi.Grid(W, H, 1)
+        g.set_b(b)
+        g.set_x(x0)
+        g.sweep(iters)
+        out.append(g.get_x().copy())
+        g.close()
+    assert np.array_equal(out[0], out[1])
+
+
 def test_three_channel_4096_fused_equals_in_place(capi, monkeypatch):
     """configs[1]: 4096x4096 three-channel blend."""
     W = H = 4096
