@@ -133,7 +133,7 @@ def main():
     tuned = None
     if not args.no_tune:
         # untimed: choose fused depth / chunk rows for this shape (speed only, results identical)
-        tuned = g.tune(min(8, max(1, (ips if world == 1 else solver.iters_per_exchange) // 2)))
+        tuned = g.tune(min(16, max(1, (ips if world == 1 else solver.iters_per_exchange) // 2)))
         g.synchronize()
     for _ in range(args.warmup):
         solver.sweep(ips)

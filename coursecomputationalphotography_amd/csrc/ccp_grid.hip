@@ -213,6 +213,21 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     return CCP_OK;
 }
 
+// run-time depth -> the instantiation of that depth
+template <int TMAX>
+struct FusedDepth {
+    static int launch(int T, ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi, const int *active,
+                      int l1, long *l1_blocks)
+    {
+        if (T == TMAX) return launch_fused_t<TMAX>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks);
+        return FusedDepth<TMAX - 1>::launch(T, g, xin, xout, st_lo, st_hi, active, l1, l1_blocks);
+    }
+};
+template <>
+struct FusedDepth<0> {
+    static int launch(int, ccp_grid *, const double *, double *, int, int, const int *, int, long *) { return CCP_ERR_BAD_ARG; }
+};
+
 // T fused iterations xin -> xout, with the ghost bookkeeping of 2T half-sweeps.
 int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int *active, int l1 = 0,
                  long *l1_blocks = nullptr)
@@ -223,17 +238,7 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int 
     const int st_lo = g->shrink_top ? std::min(s + 2 * T, g->ghost_top) : 0;
     const int st_hi = g->geom.local_rows - (g->shrink_bottom ? std::min(s + 2 * T, g->ghost_bottom) : 0);
     if (st_hi > st_lo) {
-        switch (T) {
-        case 1: CCP_TRY(launch_fused_t<1>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
-        case 2: CCP_TRY(launch_fused_t<2>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
-        case 3: CCP_TRY(launch_fused_t<3>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
-        case 4: CCP_TRY(launch_fused_t<4>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
-        case 5: CCP_TRY(launch_fused_t<5>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
-        case 6: CCP_TRY(launch_fused_t<6>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
-        case 7: CCP_TRY(launch_fused_t<7>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
-        case 8: CCP_TRY(launch_fused_t<8>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks)); break;
-        default: return CCP_ERR_BAD_ARG;
-        }
+        CCP_TRY(FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, st_lo, st_hi, active, l1, l1_blocks));
     }
     if (shrinking) g->half_sweeps_since_refresh += 2 * T;
     return CCP_OK;
@@ -569,16 +574,7 @@ int ccp_grid_tune(ccp_grid *g, int32_t max_t, int32_t *chosen_t, int32_t *chosen
             if (R > rows && R != chunk_candidates[0]) continue;
             g->rows_per_chunk = R;
             auto once = [&]() -> int {
-                switch (T) {
-                case 1: return launch_fused_t<1>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
-                case 2: return launch_fused_t<2>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
-                case 3: return launch_fused_t<3>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
-                case 4: return launch_fused_t<4>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
-                case 5: return launch_fused_t<5>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
-                case 6: return launch_fused_t<6>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
-                case 7: return launch_fused_t<7>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
-                default: return launch_fused_t<8>(g, g->x.p, g->x_alt.p, 0, rows, nullptr);
-                }
+                return FusedDepth<kFusedMaxT>::launch(T, g, g->x.p, g->x_alt.p, 0, rows, nullptr, 0, nullptr);
             };
             status = once();                                   // warm (code, TLB)
             if (status != CCP_OK) break;

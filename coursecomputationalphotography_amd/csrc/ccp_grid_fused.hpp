@@ -34,7 +34,10 @@
 
 namespace ccp {
 
-constexpr int kFusedMaxT = 8;
+#ifndef CCP_FUSED_MAX_T
+#define CCP_FUSED_MAX_T 8
+#endif
+constexpr int kFusedMaxT = CCP_FUSED_MAX_T;          // deepest pass instantiated
 constexpr int kFusedMaxCheckedT = 5;     // deepest pass that also reports the step of each of its sweeps (+2T VGPRs)
 #ifndef CCP_FUSED_UNROLL
 #define CCP_FUSED_UNROLL 2
@@ -358,7 +361,7 @@ __host__ __device__ constexpr int fused_waves_per_simd(int T, int L1 = 0)
     return L1 == 0 ? (T <= 2 ? 8 : T <= 3 ? 5 : T <= 5 ? 4 : T <= 7 ? 3 : 2)
                    : (T <= 1 ? 6 : T <= 3 ? 4 : T <= 5 ? 3 : 2);
 }
-__host__ __device__ constexpr int fused_border_waves_per_simd(int T) { return T <= 1 ? 4 : (T <= 4 ? 3 : 2); }
+__host__ __device__ constexpr int fused_border_waves_per_simd(int T) { return T <= 1 ? 4 : (T <= 4 ? 3 : (T <= 8 ? 2 : 1)); }
 
 __device__ __forceinline__ bool fused_is_border_tile(const FusedParams &P, int chunk, int sx)
 {
