@@ -179,7 +179,16 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     const int waves = kBlock / kWave;
     const int edge_chunks = std::min(P.nb_top + P.nb_bot, P.n_chunks);
     const int edge_strips = std::min(P.ns_left + P.ns_right, P.n_strips);
-    const long n_border = (long)edge_chunks * P.n_strips + (long)(P.n_chunks - edge_chunks) * edge_strips;
+    // side-strip tiles: ~2.5x the time per march step of an ordinary tile -> 2/5 of its march length
+    {
+        const int HS = 2 * T, R = P.rows_per_chunk;
+        int sr = std::max(16, (R + 2 * HS) * 2 / 5 - 2 * HS);
+        sr += sr & 1;
+        if (const char *e = getenv("CCP_GS_SIDE_ROWS")) sr = std::max(2, atoi(e));
+        P.side_rows = std::min(sr, R);
+        P.side_subs = (R + P.side_rows - 1) / P.side_rows;
+    }
+    const long n_border = (long)edge_chunks * (P.n_strips - edge_strips) + (long)P.n_chunks * edge_strips * P.side_subs;
     const bool any_plain = edge_chunks < P.n_chunks && edge_strips < P.n_strips;
     dim3 grid((unsigned)((P.n_strips + waves - 1) / waves), (unsigned)P.n_chunks, (unsigned)g->desc.channels);
     dim3 bgrid((unsigned)((n_border + waves - 1) / waves), 1, (unsigned)g->desc.channels);

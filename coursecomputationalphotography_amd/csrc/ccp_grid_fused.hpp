@@ -82,6 +82,9 @@ struct FusedParams {
     // k_fused_border runs exactly them, concurrently on a second stream.
     int n_chunks;
     int nb_top, nb_bot, ns_left, ns_right;
+    // the side strips of the middle chunks march slower per step (kStepSide), so each chunk of them
+    // is cut into side_subs tiles of side_rows rows: the slow tiles end with the ordinary ones
+    int side_rows, side_subs;
     double *__restrict__ partial_border;   // L1 sums of the border launch (same layout, own region)
 };
 
@@ -409,8 +412,8 @@ k_fused_sweep(FusedParams P)
     fused_write_partials<L1, AN>(acc, P.partial, ch, scratch);
 }
 
-// Border tiles, compactly enumerated: first the whole top and bottom chunk rows, then the left and
-// right strips of the chunks in between.  grid = (ceil(n_border_tiles / 4), 1, channels).  Runs on
+// Border tiles, compactly enumerated: first the top and bottom chunk rows (strips away from the
+// left/right edge), then the left and right strips of every chunk, each cut into side_subs tiles.  grid = (ceil(n_border_tiles / 4), 1, channels).  Runs on
 // a second stream beside k_fused_sweep: its waves take ~2.6x longer at T=8 when a whole trip is
 // border work, and as part of one launch they used to be the tail every small grid waited for.
 template <int T, int L1, int UNR>
@@ -427,23 +430,29 @@ k_fused_border(FusedParams P, int force_border)
     for (int t = 0; t < AN; ++t) acc[t] = 0.0;
     const int edge_chunks = min(P.nb_top + P.nb_bot, P.n_chunks);
     const int edge_strips = min(P.ns_left + P.ns_right, P.n_strips);
-    const int n_full = edge_chunks * P.n_strips;                       // whole chunk rows
-    const int n_side = (P.n_chunks - edge_chunks) * edge_strips;       // side strips of the middle chunks
+    const int inner = P.n_strips - edge_strips;                        // strips away from the left/right edge
+    const int n_full = edge_chunks * inner;                            // top/bottom chunk rows, inner strips
+    const int n_side = P.n_chunks * edge_strips * P.side_subs;         // edge strips of every chunk, cut in sub-tiles
     const bool run = (P.active == nullptr) || (P.active[ch] != 0);
     if (run && id < n_full + n_side) {
-        int chunk, sx;
+        int chunk, sx, ra, rb;
         if (id < n_full) {
-            const int e = id / P.n_strips;
-            sx = id % P.n_strips;
+            const int e = id / inner;
+            sx = P.ns_left + id % inner;
             chunk = e < P.nb_top ? e : P.n_chunks - edge_chunks + e;
+            ra = P.st_lo + chunk * P.rows_per_chunk;
+            rb = min(ra + P.rows_per_chunk, P.st_hi);
         } else {
-            const int k = id - n_full;
+            int k = id - n_full;
+            const int sub = k % P.side_subs;
+            k /= P.side_subs;
             const int e = k % edge_strips;
-            chunk = P.nb_top + k / edge_strips;
+            chunk = k / edge_strips;
             sx = e < P.ns_left ? e : P.n_strips - edge_strips + e;
+            const int c0 = P.st_lo + chunk * P.rows_per_chunk;
+            ra = c0 + sub * P.side_rows;
+            rb = min(min(ra + P.side_rows, c0 + P.rows_per_chunk), P.st_hi);
         }
-        const int ra = P.st_lo + chunk * P.rows_per_chunk;
-        const int rb = min(ra + P.rows_per_chunk, P.st_hi);
         if (ra < rb) {
             const Geom &g = P.g;
             const long off = (long)ch * g.ch_stride;
