@@ -10,24 +10,25 @@
 // Schedule (one wavefront = one worker; no LDS, no barriers):
 //   * a wave owns a strip of 64 half-columns (128 pixel columns), one per lane, and marches
 //     down the image rows of its chunk; lane i holds the red and the black pixel of its
-//     half-column for every row inside a sliding window of N = 2T+4 rows (registers, the march
-//     loop is unrolled N-fold so the window rotates by renaming);
+//     half-column (x and b) for every row inside a sliding window of 2T+3 rows in registers;
 //   * time skewing along the march: when row f is the newest row, row f-h receives half-sweep
 //     h (h = 1..2T, red for odd h, black for even h).  Processing h in increasing order keeps
 //     every neighbour at exactly the level the sequential red-black sweep would see;
-//   * the row that just received half-sweep 2T is final and is stored; loads run D = 2 rows
-//     ahead of the newest row;
+//   * the row that just received half-sweep 2T is final and is stored; the rows the next loop
+//     trip starts with are loaded a whole trip ahead into landing registers (FusedWindow);
 //   * the horizontal neighbour in the adjacent half-column comes from the adjacent lane by
 //     DPP (v_mov_b32_dpp wave_shr:1 / wave_shl:1), never from memory;
 //   * strips overlap by 2T pixel columns per side and chunks by 2T rows per side: the values in
 //     those halos go stale one column/row per half-sweep and are never stored (trapezoid
-//     blocking).  Useful fraction: (128-4T)/128 in x, R/(R+4T) in y.
+//     blocking).  Useful fraction: (128-4T)/128 in x, R/(R+4T) in y;
 //   * x is read from one buffer and written to another (a neighbour strip still needs the old
-//     values of the halo columns): the host ping-pongs an even number of launches.
+//     values of the halo columns): the host ping-pongs an even number of launches;
+//   * all memory accesses are raw buffer instructions whose range check drops what must not be
+//     read or written (row_rsrc below): the march has no branch around a memory instruction.
 //
 // Arithmetic per update is exactly k_half_sweep's (and therefore the reference's on the
 // colour-major matrix): interior  x = (b + (((up + left) + right) + down)) * 0.25,
-// border pixels through classify()/gs_update().
+// border pixels as classify()/gs_update() do.
 #pragma once
 
 #include "ccp_grid_kernels.hpp"
