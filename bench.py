@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--ghost", type=int, default=64, help="ghost rows per side (N>1); exchange every ghost/2 iterations")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo stages halos through the host (several ranks on one GPU, testing only)")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange halos after the whole pass instead of beside it")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (testing with --backend gloo)")
     ap.add_argument("--no-tune", action="store_true", help="skip ccp_grid_tune (use the built-in defaults)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -113,7 +114,7 @@ def main():
     row_begin, row_count = parts[rank]
     ghost = args.ghost if world > 1 else 0
     blk = rowblock.GridBlock(W, H, C, row_begin, row_count, ghost, local_rank)
-    solver = rowblock.RowBlockSolver(blk, rank, world, max(ghost, 2), dist).set_partition(parts, H)
+    solver = rowblock.RowBlockSolver(blk, rank, world, max(ghost, 2), dist, overlap=not args.no_overlap).set_partition(parts, H)
     g = blk.grid
 
     # synthetic system, generated on device: x_true -> b = A x_true -> x0 = 1.0
@@ -212,7 +213,7 @@ def main():
                                    f"{W}x{H} {C}-channel Poisson blend, red-black Gauss-Seidel",
                        "iters_per_step": ips, "channels": C,
                        "tuned": None if tuned is None else {"fused_depth": tuned[0], "rows_per_chunk": tuned[1], "ms_per_iteration": tuned[2]},
-                       "partition": "single block" if world == 1 else f"{world} row blocks, ghost {ghost}, halo exchange every {ghost // 2} iterations over " + ("RCCL" if args.backend == "nccl" else "gloo (host-staged, test only)")},
+                       "partition": "single block" if world == 1 else f"{world} row blocks, ghost {ghost}, halo exchange every {ghost // 2} iterations over " + ("RCCL" if args.backend == "nccl" else "gloo (host-staged, test only)") + (", exchange beside the last pass of each interval" if solver.overlap else "")},
             "roofline_frac_of_value": value * BYTES_PER_UPDATE / 1e9 / (HBM_PEAK_GBS * world),
             "roofline": roofline,
         }

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
     "ccp_grid_get_b_host", "ccp_grid_fill_x", "ccp_grid_b_from_x", "ccp_grid_randomize_x",
-    "ccp_grid_sweep", "ccp_grid_tune", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_conjugate_gradient",
+    "ccp_grid_sweep", "ccp_grid_sweep_edges_first", "ccp_grid_stream_wait_edges", "ccp_grid_tune", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_conjugate_gradient",
     "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_assemble_from_images", "ccp_grid_store_u8",
     "ccp_grid_set_x_u8", "ccp_grid_last_timing",
 )
@@ -116,6 +116,8 @@ def load() -> C.CDLL:
     L.ccp_grid_b_from_x.argtypes = [vp]
     L.ccp_grid_randomize_x.argtypes = [vp, C.c_uint64, dbl, dbl]
     L.ccp_grid_sweep.argtypes = [vp, i32]
+    L.ccp_grid_sweep_edges_first.argtypes = [vp, i32, i32]
+    L.ccp_grid_stream_wait_edges.argtypes = [vp, vp]
     L.ccp_grid_sweep_l1.argtypes = [vp, vp]
     L.ccp_grid_tune.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float)]
     L.ccp_grid_halo_refreshed.argtypes = [vp]
@@ -312,6 +314,13 @@ class Grid:
 
     def sweep(self, iterations):
         check(self.L.ccp_grid_sweep(self.h, iterations), "ccp_grid_sweep")
+
+    def sweep_edges_first(self, iterations, edge_rows):
+        """sweep(), with the rows a neighbour block needs finished first in the last pass."""
+        check(self.L.ccp_grid_sweep_edges_first(self.h, iterations, edge_rows), "ccp_grid_sweep_edges_first")
+
+    def stream_wait_edges(self, stream_handle: int):
+        check(self.L.ccp_grid_stream_wait_edges(self.h, C.c_void_p(stream_handle)), "ccp_grid_stream_wait_edges")
 
     def tune(self, max_t: int = 8):
         """Time the (depth, rows-per-chunk) candidates on this shape; returns (T, rows, ms/iter)."""

@@ -21,6 +21,10 @@ struct ccp_grid {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // border tiles of a fused pass run here, beside the ordinary ones
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    // ccp_grid_sweep_edges_first: the last pass finishes the rows a neighbour block needs (top /
+    // bottom band) on these two streams, beside the middle of the block on `stream`
+    hipStream_t stream_e[2] = {nullptr, nullptr};
+    hipEvent_t ev_prev = nullptr, ev_edge[2] = {nullptr, nullptr};
     DevBuf<double> x, b;
     DevBuf<double> cg_r, cg_p, cg_ap;   // conjugate-gradient work vectors, one channel each
     DevBuf<CgState> cg_state;
@@ -238,8 +242,13 @@ struct FusedDepth<0> {
 };
 
 // T fused iterations xin -> xout, with the ghost bookkeeping of 2T half-sweeps.
+// edge_rows > 0 (row blocks with neighbours): the pass is issued as up to three launches — the band
+// of `edge_rows` owned rows next to each neighbour first, each on its own stream, then the middle
+// on the main stream beside them — and ev_edge[] fire when the bands are final, so the halo
+// exchange can start while the middle of the block is still being swept.  Same tiles, same
+// arithmetic: the only difference to one launch is two extra row seams (re-read halo rows).
 int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int *active, int l1 = 0,
-                 long *l1_blocks = nullptr)
+                 long *l1_blocks = nullptr, int edge_rows = 0)
 {
     const bool shrinking = g->shrink_top || g->shrink_bottom;
     const int s = g->half_sweeps_since_refresh;
@@ -247,7 +256,34 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int 
     const int st_lo = g->shrink_top ? std::min(s + 2 * T, g->ghost_top) : 0;
     const int st_hi = g->geom.local_rows - (g->shrink_bottom ? std::min(s + 2 * T, g->ghost_bottom) : 0);
     if (st_hi > st_lo) {
-        CCP_TRY(FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, st_lo, st_hi, active, l1, l1_blocks));
+        const int top_end = (edge_rows > 0 && g->shrink_top) ? std::min(g->geom.own_lo + edge_rows, st_hi) : st_lo;
+        const int bot_begin = (edge_rows > 0 && g->shrink_bottom) ? std::max(g->geom.own_hi - edge_rows, top_end) : st_hi;
+        const int band[2][2] = {{st_lo, top_end}, {bot_begin, st_hi}};
+        const bool split = l1 == 0 && (top_end > st_lo || st_hi > bot_begin) && bot_begin > top_end;
+        if (!split) {
+            CCP_TRY(FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, st_lo, st_hi, active, l1, l1_blocks));
+            if (edge_rows > 0)
+                for (int i = 0; i < 2; ++i) CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream));
+        } else {
+            const int before = g->last_launches;
+            hipStream_t main_stream = g->stream;
+            CCP_HIP(hipEventRecord(g->ev_prev, main_stream));
+            for (int i = 0; i < 2; ++i) {
+                if (band[i][1] > band[i][0]) {
+                    CCP_HIP(hipStreamWaitEvent(g->stream_e[i], g->ev_prev, 0));
+                    g->stream = g->stream_e[i];
+                    const int st = FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, band[i][0], band[i][1], active, 0, nullptr);
+                    g->stream = main_stream;
+                    CCP_TRY(st);
+                    CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream_e[i]));
+                } else {
+                    CCP_HIP(hipEventRecord(g->ev_edge[i], main_stream));
+                }
+            }
+            CCP_TRY(FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, top_end, bot_begin, active, 0, nullptr));
+            for (int i = 0; i < 2; ++i) CCP_HIP(hipStreamWaitEvent(main_stream, g->ev_edge[i], 0));
+            g->last_launches = before + 1;            // one pass
+        }
     }
     if (shrinking) g->half_sweeps_since_refresh += 2 * T;
     return CCP_OK;
@@ -257,11 +293,13 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int 
 // in g->x), a lone leftover iteration through the in-place half-sweep kernels.
 // l1_last: the last launch also accumulates the L1 step of the final iteration (fused check).
 int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool l1_last = false,
-                  long *l1_blocks = nullptr)
+                  long *l1_blocks = nullptr, int edge_rows = 0)
 {
     if (!g->fuse || iterations < 2) {
         if (l1_last) return CCP_ERR_STATE;
         for (int k = 0; k < iterations; ++k) CCP_TRY(one_iteration(g, false, active, nullptr));
+        if (edge_rows > 0)
+            for (int i = 0; i < 2; ++i) CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream));
         return CCP_OK;
     }
     if (!g->x_alt.p) {
@@ -299,7 +337,7 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool
     double *cur = g->x.p, *alt = g->x_alt.p;
     for (size_t k = 0; k < plan.size(); ++k) {
         const bool last = k + 1 == plan.size();
-        CCP_TRY(launch_fused(g, plan[k], cur, alt, active, (l1_last && last) ? 1 : 0, l1_blocks));
+        CCP_TRY(launch_fused(g, plan[k], cur, alt, active, (l1_last && last) ? 1 : 0, l1_blocks, last ? edge_rows : 0));
         std::swap(cur, alt);
     }
     return CCP_OK;
@@ -407,6 +445,15 @@ int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
                          hipEventCreateWithFlags(&g->ev_main, hipEventDisableTiming) != hipSuccess ||
                          hipEventCreateWithFlags(&g->ev_side, hipEventDisableTiming) != hipSuccess))
         st = CCP_ERR_HIP;
+    if (st == CCP_OK && (g->ghost_top || g->ghost_bottom)) {
+        int lo = 0, hi = 0;                              // hi = greatest priority (numerically lowest)
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        for (int i = 0; i < 2 && st == CCP_OK; ++i)
+            if (hipStreamCreateWithPriority(&g->stream_e[i], hipStreamNonBlocking, hi) != hipSuccess ||
+                hipEventCreateWithFlags(&g->ev_edge[i], hipEventDisableTiming) != hipSuccess)
+                st = CCP_ERR_HIP;
+        if (st == CCP_OK && hipEventCreateWithFlags(&g->ev_prev, hipEventDisableTiming) != hipSuccess) st = CCP_ERR_HIP;
+    }
     if (st == CCP_OK && (hipMemset(g->x.p, 0, elems * sizeof(double)) != hipSuccess ||
                          hipMemset(g->b.p, 0, elems * sizeof(double)) != hipSuccess))
         st = CCP_ERR_HIP;
@@ -430,6 +477,14 @@ int ccp_grid_destroy(ccp_grid *g)
         (void)hipStreamSynchronize(g->stream2);
         (void)hipStreamDestroy(g->stream2);
     }
+    for (int i = 0; i < 2; ++i) {
+        if (g->stream_e[i]) {
+            (void)hipStreamSynchronize(g->stream_e[i]);
+            (void)hipStreamDestroy(g->stream_e[i]);
+        }
+        if (g->ev_edge[i]) (void)hipEventDestroy(g->ev_edge[i]);
+    }
+    if (g->ev_prev) (void)hipEventDestroy(g->ev_prev);
     delete g;
     return CCP_OK;
 }
@@ -534,6 +589,27 @@ int ccp_grid_sweep(ccp_grid *g, int32_t iterations)
     begin_timing(g);
     CCP_TRY(run_unchecked(g, iterations));
     end_timing(g);
+    return CCP_OK;
+}
+
+int ccp_grid_sweep_edges_first(ccp_grid *g, int32_t iterations, int32_t edge_rows)
+{
+    CCP_TRY(bind(g));
+    if (iterations < 0 || edge_rows < 0) return CCP_ERR_BAD_ARG;
+    if (!g->stream_e[0]) return ccp_grid_sweep(g, iterations);          // no neighbour blocks: nothing to hand over early
+    begin_timing(g);
+    CCP_TRY(run_unchecked(g, iterations, nullptr, false, nullptr, std::max(1, edge_rows)));
+    if (iterations == 0)
+        for (int i = 0; i < 2; ++i) CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream));
+    end_timing(g);
+    return CCP_OK;
+}
+
+int ccp_grid_stream_wait_edges(ccp_grid *g, void *hip_stream)
+{
+    CCP_TRY(bind(g));
+    if (!g->stream_e[0]) return CCP_OK;
+    for (int i = 0; i < 2; ++i) CCP_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(hip_stream), g->ev_edge[i], 0));
     return CCP_OK;
 }
 

@@ -55,9 +55,23 @@ class GridBlock:
         self.local_rows, self.row_count = lay.local_rows, row_count
         self.x_rows = torch.as_tensor(_DevArray(lay.x_dev, (channels, lay.local_rows, 2 * lay.pitch)),
                                       device=torch.device("cuda", device_index))
+        self._side = None
 
     def sweep(self, iterations: int) -> None:
         self.grid.sweep(iterations)
+
+    def sweep_edges_first(self, iterations: int, edge_rows: int) -> None:
+        self.grid.sweep_edges_first(iterations, edge_rows)
+
+    def side_stream(self):
+        """The torch stream halo messages are issued on; it waits for the edge rows only."""
+        import torch
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.x_rows.device)
+        return self._side
+
+    def side_stream_wait_edges(self) -> None:
+        self.grid.stream_wait_edges(self.side_stream().cuda_stream)
 
     def sweep_l1(self) -> np.ndarray:
         return self.grid.sweep_l1()
@@ -72,53 +86,69 @@ class GridBlock:
 class RowBlockSolver:
     """Drives one block per rank.  ``dist`` is torch.distributed (already initialised)."""
 
-    def __init__(self, block, rank: int, world: int, ghost: int, dist, group=None):
+    def __init__(self, block, rank: int, world: int, ghost: int, dist, group=None, overlap: bool = True):
         if ghost < 2 or ghost % 2:
             raise ValueError("ghost must be an even number >= 2 (two rows per iteration)")
         self.block, self.rank, self.world, self.ghost, self.dist, self.group = block, rank, world, ghost, dist, group
         self.iters_per_exchange = ghost // 2
         self.since_exchange = 0
+        # overlap: the pass that uses up the ghost rows finishes the rows the neighbours need first
+        # and the exchange runs on a side stream beside the rest of that pass (device blocks only)
+        self.overlap = overlap and world > 1 and hasattr(block, "sweep_edges_first")
         self._views = None
         if world > 1 and block.row_count < ghost:
             raise ValueError(f"row block of {block.row_count} rows is thinner than the ghost depth {ghost}")
 
     # -- halo exchange ---------------------------------------------------------------------
-    def exchange_halos(self) -> None:
-        """Send the outermost owned rows to the neighbours' ghost rows (both directions)."""
+    def exchange_halos(self, after_edges: bool = False) -> None:
+        """Send the outermost owned rows to the neighbours' ghost rows (both directions).
+        after_edges: the sweeps were issued with sweep_edges_first — run the messages on the side
+        stream, which waits for the edge rows only, and let the main stream wait for the result."""
         blk, dist = self.block, self.dist
-        if self.world > 1:
-            x = blk.x_rows
-            if self._views is None:                     # the row views never change: build them once
-                C = x.shape[0]
-                gt, gb = blk.ghost_top, blk.ghost_bottom
-                own_lo, own_hi = gt, gt + blk.row_count
-                sends, recvs = [], []                   # (tensor view, peer)
-                for ch in range(C):
-                    if self.rank > 0:      # upper neighbour: my top owned rows <-> my top ghosts
-                        n_send = self._peer_ghost_bottom(self.rank - 1)
-                        sends.append((x[ch, own_lo:own_lo + n_send], self.rank - 1))
-                        recvs.append((x[ch, 0:gt], self.rank - 1))
-                    if self.rank < self.world - 1:
-                        n_send = self._peer_ghost_top(self.rank + 1)
-                        sends.append((x[ch, own_hi - n_send:own_hi], self.rank + 1))
-                        recvs.append((x[ch, own_hi:own_hi + gb], self.rank + 1))
-                self._views = (sends, recvs)
-            sends, recvs = self._views
-            # gloo cannot move device memory: stage through host copies (CPU tests of the GPU
-            # path with several ranks on one card; RCCL sends the device rows directly)
-            staged = x.is_cuda and dist.get_backend(self.group) == "gloo"
-            out = [(t.cpu() if staged else t, p) for t, p in sends]
-            inn = [((t.new_empty(t.shape, device="cpu") if staged else t), p) for t, p in recvs]
-            ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in out]
-            ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in inn]
-            if ops:
-                for req in dist.batch_isend_irecv(ops):
-                    req.wait()
-            if staged:
-                for (dst, _), (src, _) in zip(recvs, inn):
-                    dst.copy_(src)
+        if self.world > 1 and after_edges:
+            import torch
+            side = blk.side_stream()
+            blk.side_stream_wait_edges()
+            with torch.cuda.stream(side):
+                self._move_halos()
+            torch.cuda.current_stream(blk.x_rows.device).wait_stream(side)
+        elif self.world > 1:
+            self._move_halos()
         blk.halo_refreshed()
         self.since_exchange = 0
+
+    def _move_halos(self) -> None:
+        blk, dist = self.block, self.dist
+        x = blk.x_rows
+        if self._views is None:                     # the row views never change: build them once
+            C = x.shape[0]
+            gt, gb = blk.ghost_top, blk.ghost_bottom
+            own_lo, own_hi = gt, gt + blk.row_count
+            sends, recvs = [], []                   # (tensor view, peer)
+            for ch in range(C):
+                if self.rank > 0:      # upper neighbour: my top owned rows <-> my top ghosts
+                    n_send = self._peer_ghost_bottom(self.rank - 1)
+                    sends.append((x[ch, own_lo:own_lo + n_send], self.rank - 1))
+                    recvs.append((x[ch, 0:gt], self.rank - 1))
+                if self.rank < self.world - 1:
+                    n_send = self._peer_ghost_top(self.rank + 1)
+                    sends.append((x[ch, own_hi - n_send:own_hi], self.rank + 1))
+                    recvs.append((x[ch, own_hi:own_hi + gb], self.rank + 1))
+            self._views = (sends, recvs)
+        sends, recvs = self._views
+        # gloo cannot move device memory: stage through host copies (CPU tests of the GPU
+        # path with several ranks on one card; RCCL sends the device rows directly)
+        staged = x.is_cuda and dist.get_backend(self.group) == "gloo"
+        out = [(t.cpu() if staged else t, p) for t, p in sends]
+        inn = [((t.new_empty(t.shape, device="cpu") if staged else t), p) for t, p in recvs]
+        ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in out]
+        ops += [dist.P2POp(dist.irecv, t, p, self.group) for t, p in inn]
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        if staged:
+            for (dst, _), (src, _) in zip(recvs, inn):
+                dst.copy_(src)
 
     # ghost depths of the neighbours (they may be clipped by the image border)
     def _peer_ghost_top(self, peer: int) -> int:
@@ -141,8 +171,14 @@ class RowBlockSolver:
             if self.world > 1 and self.since_exchange >= self.iters_per_exchange:
                 self.exchange_halos()
             room = left if self.world == 1 else min(left, self.iters_per_exchange - self.since_exchange)
-            self.block.sweep(room)
-            self.since_exchange += room
+            if self.overlap and self.since_exchange + room == self.iters_per_exchange:
+                # these sweeps use up the ghost rows: exchange right away, beside their last pass
+                self.block.sweep_edges_first(room, self.ghost)
+                self.since_exchange += room
+                self.exchange_halos(after_edges=True)
+            else:
+                self.block.sweep(room)
+                self.since_exchange += room
             left -= room
 
     def sweep_l1(self) -> np.ndarray:

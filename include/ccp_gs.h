@@ -179,6 +179,15 @@ int ccp_grid_randomize_x(ccp_grid *g, uint64_t seed, double lo, double hi);
  * With ghosts: each sweep invalidates two more ghost rows, so at most ghost/2 iterations may
  * run between two halo refreshes (enforced: CCP_ERR_STATE). */
 int ccp_grid_sweep(ccp_grid *g, int32_t iterations);
+
+/* The same sweeps for a row block with neighbour blocks: the LAST pass finalises the
+ * `edge_rows` owned rows next to each neighbour first, on streams of their own, beside the middle of
+ * the block, so the halo exchange can overlap the rest of the pass.  Results are identical to
+ * ccp_grid_sweep.  ccp_grid_stream_wait_edges makes `hip_stream` (the stream the caller's
+ * send/receive is issued on) wait until those rows are final; the handle's own stream already
+ * waits for them.  A block without ghost rows: plain ccp_grid_sweep / no-op. */
+int ccp_grid_sweep_edges_first(ccp_grid *g, int32_t iterations, int32_t edge_rows);
+int ccp_grid_stream_wait_edges(ccp_grid *g, void *hip_stream);
 /* Pick the temporal-blocking depth (iterations fused per kernel pass, <= max_t) and the rows a
  * wave finalises per pass by timing the candidates on this handle's actual shape (a few dozen
  * launches into the scratch buffer; x, b and the ghost bookkeeping are left untouched).  Results

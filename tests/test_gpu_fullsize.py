@@ -201,8 +201,9 @@ class ThreadDist:
         t.copy_(total)
 
 
-@pytest.mark.parametrize("W,H,world,ghost,iters", [(4096, 4096, 3, 16, 40), (1000, 333, 4, 8, 21)])
-def test_row_blocked_gridblocks_equal_single_block(capi, W, H, world, ghost, iters):
+@pytest.mark.parametrize("overlap", [True, False])
+@pytest.mark.parametrize("W,H,world,ghost,iters", [(4096, 4096, 3, 16, 40), (1000, 333, 4, 8, 21), (16384, 1600, 2, 64, 70)])
+def test_row_blocked_gridblocks_equal_single_block(capi, W, H, world, ghost, iters, overlap):
     import torch
     from coursecomputationalphotography_amd import rowblock
     whole = make(capi, W, H)
@@ -222,7 +223,8 @@ def test_row_blocked_gridblocks_equal_single_block(capi, W, H, world, ghost, ite
             blk.grid.randomize_x(1234, 0.0, 255.0)          # same field on every partition
             blk.grid.b_from_x()
             blk.grid.fill_x(1.0)
-            solver = rowblock.RowBlockSolver(blk, rank, world, ghost, dist).set_partition(parts, H)
+            solver = rowblock.RowBlockSolver(blk, rank, world, ghost, dist, overlap=overlap).set_partition(parts, H)
+            assert solver.overlap == overlap
             solver.exchange_halos()
             solver.sweep(iters)
             res = solver.rel_residual()
