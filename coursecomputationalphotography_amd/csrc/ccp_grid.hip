@@ -417,7 +417,6 @@ int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
     geo.own_lo = g->ghost_top;
     geo.own_hi = g->ghost_top + d->row_count;
     geo.pitch = (((long)d->width + 1) / 2 + 15) / 16 * 16;
-    if (const char *e = getenv("CCP_GS_PITCH_PAD")) geo.pitch += std::max(0, atoi(e)) / 16 * 16;   // experiment: de-alias rows
     geo.ch_stride = (long)geo.local_rows * 2 * geo.pitch;
     g->cpt = 2;
     if (const char *e = getenv("CCP_GS_CPT")) g->cpt = (atoi(e) == 4) ? 4 : 2;

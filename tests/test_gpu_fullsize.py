@@ -180,7 +180,11 @@ class ThreadDist:
         reqs = []
         for op in ops:
             if op.op == "isend":
-                self.box[(me, op.peer)].put(op.tensor.clone())
+                msg = op.tensor.clone()
+                # the receiver copies on ITS stream: hand the message over only once it is complete
+                # (a real backend orders send and receive itself)
+                torch.cuda.current_stream().synchronize()
+                self.box[(me, op.peer)].put(msg)
                 reqs.append(self._Req(lambda: None))
             else:
                 def recv(t=op.tensor, src=op.peer):
