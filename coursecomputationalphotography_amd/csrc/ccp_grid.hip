@@ -747,8 +747,9 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
         issued = max_iteration;
         any_active = false;
     }
-    if (any_active && check_every == 1 && g->fuse) {
-        // The reference tests its stop rule after EVERY sweep.  A temporally blocked pass knows the
+    if (any_active && check_every >= 1 && g->fuse) {
+        // The reference tests its stop rule after EVERY sweep (check_every = 1; k > 1 tests every k-th
+        // sweep with the same machinery).  A temporally blocked pass knows the
         // previous level of every pixel it updates, so it reports the step of each of its T sweeps
         // (L1 = 2) at no extra traffic; k_check_multi finds the first sweep that meets the rule.  If
         // that sweep is inside the pass, the channel is re-run from the pass's input buffer (still
@@ -769,7 +770,7 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
             long blocks[2] = {0, 0};
             CCP_TRY(launch_fused(g, T, cur, alt, active, 2, blocks));
             hipLaunchKernelGGL(k_check_multi, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
-                               g->partial.p + g->partial_region, blocks[1], T, k0 + 1, epsilon, g->state.p);
+                               g->partial.p + g->partial_region, blocks[1], T, k0 + 1, check_every, epsilon, g->state.p);
             CCP_HIP(hipGetLastError());
             CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));
             CCP_HIP(hipStreamSynchronize(g->stream));

@@ -39,7 +39,7 @@ namespace ccp {
 #define CCP_FUSED_MAX_T 8
 #endif
 constexpr int kFusedMaxT = CCP_FUSED_MAX_T;          // deepest pass instantiated
-constexpr int kFusedMaxCheckedT = 5;     // deepest pass that also reports the step of each of its sweeps (+2T VGPRs)
+constexpr int kFusedMaxCheckedT = 8;     // deepest pass that also reports the step of each of its sweeps (+2T+4 VGPRs)
 #ifndef CCP_FUSED_UNROLL
 #define CCP_FUSED_UNROLL 2
 #endif
@@ -365,7 +365,7 @@ __host__ __device__ constexpr int fused_waves_per_simd(int T, int L1 = 0)
     return L1 == 0 ? (T <= 2 ? 8 : T <= 3 ? 5 : T <= 5 ? 4 : T <= 7 ? 3 : 2)
                    : (T <= 1 ? 6 : T <= 3 ? 4 : T <= 5 ? 3 : 2);
 }
-__host__ __device__ constexpr int fused_border_waves_per_simd(int T) { return T <= 1 ? 4 : (T <= 4 ? 3 : (T <= 8 ? 2 : 1)); }
+__host__ __device__ constexpr int fused_border_waves_per_simd(int T, int L1 = 0) { return T <= 1 ? 4 : (T <= 4 ? 3 : (T <= (L1 == 2 ? 7 : 8) ? 2 : 1)); }
 
 __device__ __forceinline__ bool fused_is_border_tile(const FusedParams &P, int chunk, int sx)
 {
@@ -418,7 +418,7 @@ k_fused_sweep(FusedParams P)
 // a second stream beside k_fused_sweep: its waves take ~2.6x longer at T=8 when a whole trip is
 // border work, and as part of one launch they used to be the tail every small grid waited for.
 template <int T, int L1, int UNR>
-__global__ void __launch_bounds__(kBlock, fused_border_waves_per_simd(T))
+__global__ void __launch_bounds__(kBlock, fused_border_waves_per_simd(T, L1))
 k_fused_border(FusedParams P, int force_border)
 {
     __shared__ double scratch[kBlock / kWave];

@@ -271,12 +271,13 @@ k_check(const double *__restrict__ partial0, long blocks0, const double *__restr
 // the channel, exactly where the reference loop would have stopped.  grid = channels.
 __global__ void __launch_bounds__(kBlock)
 k_check_multi(const double *__restrict__ partial0, long blocks0, const double *__restrict__ partial1, long blocks1,
-              int T, int first_sweep_index, double epsilon, SolveState *__restrict__ st)
+              int T, int first_sweep_index, int every, double epsilon, SolveState *__restrict__ st)
 {
     __shared__ double scratch[kBlock / kWave];
     const int ch = blockIdx.x;
     const int channels = gridDim.x;
     for (int t = 0; t < T; ++t) {
+        if ((first_sweep_index + t) % every != 0) continue;    // the rule is evaluated every `every`-th sweep (block-uniform)
         // two regions: the ordinary launch and the border launch of the pass
         double acc = 0.0;
         const double *__restrict__ p = partial0 + ((long)t * channels + ch) * blocks0;
