@@ -50,7 +50,7 @@ def parse():
     ap.add_argument("--ghost", type=int, default=64, help="ghost rows per side (N>1); exchange every ghost/2 iterations")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo stages halos through the host (several ranks on one GPU, testing only)")
-    ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange halos after the whole pass instead of beside it")
+    ap.add_argument("--overlap", action="store_true", help="N>1: finish the edge rows first and exchange halos beside the rest of the pass (measured slower, see DESIGN.md)")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (testing with --backend gloo)")
     ap.add_argument("--no-tune", action="store_true", help="skip ccp_grid_tune (use the built-in defaults)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -114,7 +114,7 @@ def main():
     row_begin, row_count = parts[rank]
     ghost = args.ghost if world > 1 else 0
     blk = rowblock.GridBlock(W, H, C, row_begin, row_count, ghost, local_rank)
-    solver = rowblock.RowBlockSolver(blk, rank, world, max(ghost, 2), dist, overlap=not args.no_overlap).set_partition(parts, H)
+    solver = rowblock.RowBlockSolver(blk, rank, world, max(ghost, 2), dist, overlap=args.overlap).set_partition(parts, H)
     g = blk.grid
 
     # synthetic system, generated on device: x_true -> b = A x_true -> x0 = 1.0

@@ -24,6 +24,7 @@ struct ccp_grid {
     // ccp_grid_sweep_edges_first: the last pass finishes the rows a neighbour block needs (top /
     // bottom band) on these two streams, beside the middle of the block on `stream`
     hipStream_t stream_e[2] = {nullptr, nullptr};
+    hipStream_t stream_eb[2] = {nullptr, nullptr};   // border tiles of the two bands
     hipEvent_t ev_prev = nullptr, ev_edge[2] = {nullptr, nullptr};
     DevBuf<double> x, b;
     DevBuf<double> cg_r, cg_p, cg_ap;   // conjugate-gradient work vectors, one channel each
@@ -141,8 +142,11 @@ void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P)
     const Geom &geo = g->geom;
     const int HS = 2 * T, R = P.rows_per_chunk;
     P.n_chunks = (P.st_hi - P.st_lo + R - 1) / R;
-    auto top = [&](int c) { const int ra = P.st_lo + c * R; return (ra - HS <= 0) || (geo.y0 + ra - HS <= 0); };
-    auto bot = [&](int c) { const int rb = std::min(P.st_lo + (c + 1) * R, P.st_hi); return (rb + HS >= geo.local_rows) || (geo.y0 + rb + HS >= geo.H - 1); };
+    // Only IMAGE edges need the border arithmetic.  At the stale edge of a ghost zone the rows next to
+    // the edge are invalid by construction (validity recedes one row per half-sweep, they are neither
+    // stored nor used), so a tile there is an ordinary tile: the rows beyond the block read as 0.
+    auto top = [&](int c) { const int ra = P.st_lo + c * R; return geo.y0 + ra - HS <= 0; };
+    auto bot = [&](int c) { const int rb = std::min(P.st_lo + (c + 1) * R, P.st_hi); return geo.y0 + rb + HS >= geo.H - 1; };
     P.nb_top = 0;
     while (P.nb_top < P.n_chunks && top(P.nb_top)) ++P.nb_top;
     P.nb_bot = 0;
@@ -164,7 +168,7 @@ void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P)
 // l1_blocks[0/1]: block results per (sweep, channel) of the ordinary / the border launch.
 template <int T>
 int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi, const int *active,
-                   int l1 = 0, long *l1_blocks = nullptr)
+                   int l1 = 0, long *l1_blocks = nullptr, int rows_override = 0, hipStream_t border_stream = nullptr)
 {
     FusedParams P;
     P.xin = xin;
@@ -173,7 +177,7 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     P.g = g->geom;
     P.st_lo = st_lo;
     P.st_hi = st_hi;
-    P.rows_per_chunk = (g->tuned && g->tune_rows[T] > 0) ? g->tune_rows[T] : g->rows_per_chunk;
+    P.rows_per_chunk = rows_override > 0 ? rows_override : ((g->tuned && g->tune_rows[T] > 0) ? g->tune_rows[T] : g->rows_per_chunk);
     const int U = fused_useful_px(T);
     P.n_strips = (g->geom.W + U - 1) / U;
     P.partial = g->partial.p;
@@ -202,11 +206,12 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     }
     if (l1 == 2 && T > kFusedMaxCheckedT) return CCP_ERR_BAD_ARG;
     constexpr int TC = T <= kFusedMaxCheckedT ? T : 1;       // per-sweep sums exist up to kFusedMaxCheckedT
+    hipStream_t bstream = border_stream ? border_stream : g->stream2;
     // The border launch sees everything queued on the main stream so far, runs beside the ordinary
     // tiles, and whatever comes next on the main stream waits for it.
     if (n_border) {
         CCP_HIP(hipEventRecord(g->ev_main, g->stream));
-        CCP_HIP(hipStreamWaitEvent(g->stream2, g->ev_main, 0));
+        CCP_HIP(hipStreamWaitEvent(bstream, g->ev_main, 0));
     }
     if (any_plain) {
         if (l1 == 2) hipLaunchKernelGGL((k_fused_sweep<TC, 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
@@ -215,10 +220,10 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     }
     if (n_border) {
         const int fb = g->force_border ? 1 : 0;
-        if (l1 == 2) hipLaunchKernelGGL((k_fused_border<TC, 2, kFusedUnroll>), bgrid, dim3(kBlock), 0, g->stream2, P, fb);
-        else if (l1 == 1) hipLaunchKernelGGL((k_fused_border<T, 1, kFusedUnroll>), bgrid, dim3(kBlock), 0, g->stream2, P, fb);
-        else hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll>), bgrid, dim3(kBlock), 0, g->stream2, P, fb);
-        CCP_HIP(hipEventRecord(g->ev_side, g->stream2));
+        if (l1 == 2) hipLaunchKernelGGL((k_fused_border<TC, 2, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
+        else if (l1 == 1) hipLaunchKernelGGL((k_fused_border<T, 1, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
+        else hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
+        CCP_HIP(hipEventRecord(g->ev_side, bstream));
         CCP_HIP(hipStreamWaitEvent(g->stream, g->ev_side, 0));
     }
     CCP_HIP(hipGetLastError());
@@ -230,15 +235,15 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
 template <int TMAX>
 struct FusedDepth {
     static int launch(int T, ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi, const int *active,
-                      int l1, long *l1_blocks)
+                      int l1, long *l1_blocks, int rows_override = 0, hipStream_t border_stream = nullptr)
     {
-        if (T == TMAX) return launch_fused_t<TMAX>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks);
-        return FusedDepth<TMAX - 1>::launch(T, g, xin, xout, st_lo, st_hi, active, l1, l1_blocks);
+        if (T == TMAX) return launch_fused_t<TMAX>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks, rows_override, border_stream);
+        return FusedDepth<TMAX - 1>::launch(T, g, xin, xout, st_lo, st_hi, active, l1, l1_blocks, rows_override, border_stream);
     }
 };
 template <>
 struct FusedDepth<0> {
-    static int launch(int, ccp_grid *, const double *, double *, int, int, const int *, int, long *) { return CCP_ERR_BAD_ARG; }
+    static int launch(int, ccp_grid *, const double *, double *, int, int, const int *, int, long *, int = 0, hipStream_t = nullptr) { return CCP_ERR_BAD_ARG; }
 };
 
 // T fused iterations xin -> xout, with the ghost bookkeeping of 2T half-sweeps.
@@ -268,19 +273,33 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int 
             const int before = g->last_launches;
             hipStream_t main_stream = g->stream;
             CCP_HIP(hipEventRecord(g->ev_prev, main_stream));
+            static const int mode = getenv("CCP_GS_EDGE_MODE") ? atoi(getenv("CCP_GS_EDGE_MODE")) : 2;
             for (int i = 0; i < 2; ++i) {
                 if (band[i][1] > band[i][0]) {
-                    CCP_HIP(hipStreamWaitEvent(g->stream_e[i], g->ev_prev, 0));
-                    g->stream = g->stream_e[i];
-                    const int st = FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, band[i][0], band[i][1], active, 0, nullptr);
+                    // mode 0: bands on the main stream before the middle; 1: both bands on one extra stream,
+                    // their border tiles on the shared border stream; 2: a stream pair per band
+                    hipStream_t bs = mode == 0 ? main_stream : g->stream_e[mode == 1 ? 0 : i];
+                    hipStream_t bbs = mode == 2 ? g->stream_eb[i] : nullptr;
+                    if (mode != 0) CCP_HIP(hipStreamWaitEvent(bs, g->ev_prev, 0));
+                    g->stream = bs;
+                    const int st = FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, band[i][0], band[i][1], active, 0, nullptr,
+                                                                  band[i][1] - band[i][0], bbs);
                     g->stream = main_stream;
                     CCP_TRY(st);
-                    CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream_e[i]));
+                    CCP_HIP(hipEventRecord(g->ev_edge[i], bs));
                 } else {
                     CCP_HIP(hipEventRecord(g->ev_edge[i], main_stream));
                 }
             }
-            CCP_TRY(FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, top_end, bot_begin, active, 0, nullptr));
+            // the bands take tile slots too: give the middle correspondingly fewer, taller chunks, so the
+            // split pass needs no more rounds on the chip than the whole pass would
+            const int R = (g->tuned && g->tune_rows[T] > 0) ? g->tune_rows[T] : g->rows_per_chunk;
+            const int n_whole = (st_hi - st_lo + R - 1) / R;
+            const int n_bands = (band[0][1] > band[0][0]) + (band[1][1] > band[1][0]);
+            const int n_mid = std::max(1, n_whole - n_bands);
+            int r_mid = (bot_begin - top_end + n_mid - 1) / n_mid;
+            r_mid += r_mid & 1;
+            CCP_TRY(FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, top_end, bot_begin, active, 0, nullptr, std::max(R, r_mid)));
             for (int i = 0; i < 2; ++i) CCP_HIP(hipStreamWaitEvent(main_stream, g->ev_edge[i], 0));
             g->last_launches = before + 1;            // one pass
         }
@@ -447,8 +466,10 @@ int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
     if (st == CCP_OK && (g->ghost_top || g->ghost_bottom)) {
         int lo = 0, hi = 0;                              // hi = greatest priority (numerically lowest)
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        if (const char *e = getenv("CCP_GS_EDGE_PRIO")) { if (atoi(e) == 0) hi = lo; }
         for (int i = 0; i < 2 && st == CCP_OK; ++i)
             if (hipStreamCreateWithPriority(&g->stream_e[i], hipStreamNonBlocking, hi) != hipSuccess ||
+                hipStreamCreateWithPriority(&g->stream_eb[i], hipStreamNonBlocking, hi) != hipSuccess ||
                 hipEventCreateWithFlags(&g->ev_edge[i], hipEventDisableTiming) != hipSuccess)
                 st = CCP_ERR_HIP;
         if (st == CCP_OK && hipEventCreateWithFlags(&g->ev_prev, hipEventDisableTiming) != hipSuccess) st = CCP_ERR_HIP;
@@ -480,6 +501,10 @@ int ccp_grid_destroy(ccp_grid *g)
         if (g->stream_e[i]) {
             (void)hipStreamSynchronize(g->stream_e[i]);
             (void)hipStreamDestroy(g->stream_e[i]);
+        }
+        if (g->stream_eb[i]) {
+            (void)hipStreamSynchronize(g->stream_eb[i]);
+            (void)hipStreamDestroy(g->stream_eb[i]);
         }
         if (g->ev_edge[i]) (void)hipEventDestroy(g->ev_edge[i]);
     }

@@ -222,7 +222,7 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
             // column flags and the (wave-uniform) row flags; only a_ii = 3 (image row 0, image
             // column 0) needs a true division — 1, 2 and 4 are exact reciprocals.
             const int y = g.y0 + r;
-            const bool row_plain = (y >= 1) && (y <= g.H - 2) && (r >= 1) && (r + 1 < g.local_rows);
+            const bool row_plain = (y >= 1) && (y <= g.H - 2);
             if (row_plain && cx.col_interior) {
                 nv = (bv + (((up + left) + right) + dn)) * 0.25;
             } else if (cx.px_ok[p]) {
@@ -328,8 +328,7 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
         } else {
             // rows the trip updates that matter: fb-HS .. fb+G-2, clipped to the rows this wave holds
             const int r_first = max(fb - HS, cx.m0), r_last = min(fb + G - 2, cx.m1 - 1);
-            const bool rows_plain = !force_border && (g.y0 + r_first >= 1) && (g.y0 + r_last <= g.H - 2) &&
-                                    (r_first >= 1) && (r_last + 1 < g.local_rows);
+            const bool rows_plain = !force_border && (g.y0 + r_first >= 1) && (g.y0 + r_last <= g.H - 2);
             if (rows_plain && cx.col_interior) {
 #pragma unroll
                 for (int i = 0; i < G; ++i)

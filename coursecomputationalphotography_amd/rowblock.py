@@ -86,14 +86,17 @@ class GridBlock:
 class RowBlockSolver:
     """Drives one block per rank.  ``dist`` is torch.distributed (already initialised)."""
 
-    def __init__(self, block, rank: int, world: int, ghost: int, dist, group=None, overlap: bool = True):
+    def __init__(self, block, rank: int, world: int, ghost: int, dist, group=None, overlap: bool = False):
         if ghost < 2 or ghost % 2:
             raise ValueError("ghost must be an even number >= 2 (two rows per iteration)")
         self.block, self.rank, self.world, self.ghost, self.dist, self.group = block, rank, world, ghost, dist, group
         self.iters_per_exchange = ghost // 2
         self.since_exchange = 0
         # overlap: the pass that uses up the ghost rows finishes the rows the neighbours need first
-        # and the exchange runs on a side stream beside the rest of that pass (device blocks only)
+        # and the exchange runs on a side stream beside the rest of that pass (device blocks only).
+        # Off by default: on MI355X the extra band launches cost a 2048-row block 0.17-0.25 ms per
+        # interval (a pass has a floor of one wave lifetime however few tiles it has), more than the
+        # ~0.13 ms message they could hide (tools/rank_block_bench.py, DESIGN.md section 5).
         self.overlap = overlap and world > 1 and hasattr(block, "sweep_edges_first")
         self._views = None
         if world > 1 and block.row_count < ghost:

@@ -1,0 +1,43 @@
+"""Time the sweeps of ONE interior row block of a multi-GPU run on one card: W x H image, the block
+of `rows` owned rows starting at `row_begin`, `ghost` ghost rows per side; ghost/2 iterations per
+interval, halos declared refreshed (no neighbour here — the values are irrelevant for timing)."""
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from coursecomputationalphotography_amd import capi  # noqa: E402
+
+
+def main():
+    W = H = 16384
+    world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+    ghost = int(sys.argv[2]) if len(sys.argv) > 2 else 64
+    edges_first = (sys.argv[3] == "edges") if len(sys.argv) > 3 else False
+    rows = H // world
+    g = capi.Grid(W, H, 1, rows * (world // 2), rows, ghost, 0)
+    g.randomize_x(1)
+    g.b_from_x()
+    g.fill_x(1.0)
+    k = ghost // 2
+    tuned = g.tune(min(8, k // 2))
+    g.halo_refreshed()
+    out = []
+    for rep in range(6):
+        if edges_first:
+            g.sweep_edges_first(k, ghost)
+        else:
+            g.sweep(k)
+        g.synchronize()
+        ms, launches = g.last_timing()
+        out.append(ms)
+        g.halo_refreshed()
+    best = min(out[1:])
+    print(json.dumps({"world": world, "block_rows": rows, "ghost": ghost, "iterations_per_interval": k,
+                      "tuned": tuned, "ms_per_interval": best, "edges_first": edges_first,
+                      "block_updates_per_s": W * rows * k / best * 1e3,
+                      "node_updates_per_s_if_exchange_hidden": W * H * k / best * 1e3}))
+
+
+if __name__ == "__main__":
+    main()
