@@ -141,12 +141,21 @@ void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P)
 {
     const Geom &geo = g->geom;
     const int HS = 2 * T, R = P.rows_per_chunk;
-    P.n_chunks = (P.st_hi - P.st_lo + R - 1) / R;
     // Only IMAGE edges need the border arithmetic.  At the stale edge of a ghost zone the rows next to
     // the edge are invalid by construction (validity recedes one row per half-sweep, they are neither
     // stored nor used), so a tile there is an ordinary tile: the rows beyond the block read as 0.
-    auto top = [&](int c) { const int ra = P.st_lo + c * R; return geo.y0 + ra - HS <= 0; };
-    auto bot = [&](int c) { const int rb = std::min(P.st_lo + (c + 1) * R, P.st_hi); return geo.y0 + rb + HS >= geo.H - 1; };
+    // A chunk row at an image edge is cut short: HS + 16 rows, enough for the chunk next to it to be
+    // clear of the edge (its halo starts below image row 0 / ends above image row H-1).
+    const int rows = P.st_hi - P.st_lo;
+    const int edge_rows = HS + 16;
+    const bool at_top = geo.y0 + P.st_lo - HS <= 0, at_bot = geo.y0 + P.st_hi + HS >= geo.H - 1;
+    static const bool short_edges = !(getenv("CCP_GS_SHORT_EDGES") && atoi(getenv("CCP_GS_SHORT_EDGES")) == 0);
+    P.first_rows = (short_edges && at_top && rows > 2 * edge_rows + R / 2 && R > edge_rows) ? edge_rows : 0;
+    P.last_rows = (short_edges && at_bot && rows > 2 * edge_rows + R / 2 && R > edge_rows) ? edge_rows : 0;
+    const int mid = rows - P.first_rows - P.last_rows;
+    P.n_chunks = (mid + R - 1) / R + (P.first_rows > 0) + (P.last_rows > 0);
+    auto top = [&](int c) { int ra, rb; fused_chunk_rows(P, c, ra, rb); return geo.y0 + ra - HS <= 0; };
+    auto bot = [&](int c) { int ra, rb; fused_chunk_rows(P, c, ra, rb); return geo.y0 + rb + HS >= geo.H - 1; };
     P.nb_top = 0;
     while (P.nb_top < P.n_chunks && top(P.nb_top)) ++P.nb_top;
     P.nb_bot = 0;
@@ -670,10 +679,13 @@ int ccp_grid_tune(ccp_grid *g, int32_t max_t, int32_t *chosen_t, int32_t *chosen
             const int U = fused_useful_px(T);
             const long blocks_x = ((g->geom.W + U - 1) / U + kBlock / kWave - 1) / (kBlock / kWave);
             const long slots = (long)cus * fused_waves_per_simd(T);       // resident workgroups
+            // chunk rows at an image edge are short ones of their own (fused_tile_counts)
+            const int n_short = (g->geom.y0 - 2 * T <= 0) + (g->geom.y0 + rows + 2 * T >= g->geom.H - 1);
+            const int short_rows = n_short * (2 * T + 16);
             for (int rounds = 1; rounds <= 4; ++rounds) {
-                const long chunks = rounds * slots / (blocks_x * g->desc.channels);
-                if (chunks < 1) continue;
-                int R = (int)((rows + chunks - 1) / chunks);
+                const long chunks = rounds * slots / (blocks_x * g->desc.channels) - n_short;
+                if (chunks < 1 || rows <= short_rows) continue;
+                int R = (int)((rows - short_rows + chunks - 1) / chunks);
                 R += R & 1;
                 if (R >= 16 && R <= 1024 && std::find(chunk_candidates.begin(), chunk_candidates.end(), R) == chunk_candidates.end())
                     chunk_candidates.push_back(R);

@@ -74,6 +74,10 @@ struct FusedParams {
     Geom g;
     int st_lo, st_hi;          // local rows to finalise and store
     int rows_per_chunk;
+    // A chunk row that touches the image top / bottom runs in k_fused_border, whose waves march
+    // slower: it is kept short (first_rows / last_rows > 0) so those tiles end early; the chunks in
+    // between have rows_per_chunk rows (fused_chunk_rows).
+    int first_rows, last_rows;
     int n_strips;
     double *__restrict__ partial;   // L1 = 1: one double per block; L1 = 2: T doubles per block (per iteration)
     const int *__restrict__ active; // nullable: per-channel "still iterating" flags (device)
@@ -88,6 +92,23 @@ struct FusedParams {
     int side_rows, side_subs;
     double *__restrict__ partial_border;   // L1 sums of the border launch (same layout, own region)
 };
+
+// rows [ra, rb) of chunk c
+__host__ __device__ __forceinline__ void fused_chunk_rows(const FusedParams &P, int c, int &ra, int &rb)
+{
+    if (P.first_rows > 0 && c == 0) {
+        ra = P.st_lo;
+        rb = P.st_lo + P.first_rows;
+    } else if (P.last_rows > 0 && c == P.n_chunks - 1) {
+        ra = P.st_hi - P.last_rows;
+        rb = P.st_hi;
+    } else {
+        const int k = c - (P.first_rows > 0 ? 1 : 0);
+        const int end = P.st_hi - P.last_rows;
+        ra = P.st_lo + P.first_rows + k * P.rows_per_chunk;
+        rb = ra + P.rows_per_chunk < end ? ra + P.rows_per_chunk : end;
+    }
+}
 
 // How the row window maps onto registers.  G = UNR march steps are unrolled per loop trip: inside
 // a trip the row at `dist` rows behind the newest row of step i sits in slot 2T+1 + i - dist;
@@ -397,8 +418,8 @@ k_fused_sweep(FusedParams P)
     const int sx = blockIdx.x * (kBlock / kWave) + wave;
     const int ch = blockIdx.z;
     const int chunk = blockIdx.y;
-    const int ra = P.st_lo + chunk * P.rows_per_chunk;
-    const int rb = min(ra + P.rows_per_chunk, P.st_hi);
+    int ra, rb;
+    fused_chunk_rows(P, chunk, ra, rb);
     constexpr int AN = L1 == 2 ? T : 1;
     double acc[AN];
 #pragma unroll
@@ -440,8 +461,7 @@ k_fused_border(FusedParams P, int force_border)
             const int e = id / inner;
             sx = P.ns_left + id % inner;
             chunk = e < P.nb_top ? e : P.n_chunks - edge_chunks + e;
-            ra = P.st_lo + chunk * P.rows_per_chunk;
-            rb = min(ra + P.rows_per_chunk, P.st_hi);
+            fused_chunk_rows(P, chunk, ra, rb);
         } else {
             int k = id - n_full;
             const int sub = k % P.side_subs;
@@ -449,9 +469,10 @@ k_fused_border(FusedParams P, int force_border)
             const int e = k % edge_strips;
             chunk = k / edge_strips;
             sx = e < P.ns_left ? e : P.n_strips - edge_strips + e;
-            const int c0 = P.st_lo + chunk * P.rows_per_chunk;
+            int c0, c1;
+            fused_chunk_rows(P, chunk, c0, c1);
             ra = c0 + sub * P.side_rows;
-            rb = min(min(ra + P.side_rows, c0 + P.rows_per_chunk), P.st_hi);
+            rb = min(ra + P.side_rows, c1);
         }
         if (ra < rb) {
             const Geom &g = P.g;

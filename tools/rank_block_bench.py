@@ -14,8 +14,9 @@ def main():
     world = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     ghost = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     edges_first = (sys.argv[3] == "edges") if len(sys.argv) > 3 else False
+    rank = int(sys.argv[4]) if len(sys.argv) > 4 else world // 2
     rows = H // world
-    g = capi.Grid(W, H, 1, rows * (world // 2), rows, ghost, 0)
+    g = capi.Grid(W, H, 1, rows * rank, rows, ghost, 0)
     g.randomize_x(1)
     g.b_from_x()
     g.fill_x(1.0)
@@ -33,7 +34,7 @@ def main():
         out.append(ms)
         g.halo_refreshed()
     best = min(out[1:])
-    print(json.dumps({"world": world, "block_rows": rows, "ghost": ghost, "iterations_per_interval": k,
+    print(json.dumps({"world": world, "rank": rank, "block_rows": rows, "ghost": ghost, "iterations_per_interval": k,
                       "tuned": tuned, "ms_per_interval": best, "edges_first": edges_first,
                       "block_updates_per_s": W * rows * k / best * 1e3,
                       "node_updates_per_s_if_exchange_hidden": W * H * k / best * 1e3}))
