@@ -21,6 +21,7 @@ struct ccp_grid {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // border tiles of a fused pass run here, beside the ordinary ones
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
+    hipEvent_t ev_band[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // the same pair for each band launch
     // ccp_grid_sweep_edges_first: the last pass finishes the rows a neighbour block needs (top /
     // bottom band) on these two streams, beside the middle of the block on `stream`
     hipStream_t stream_e[2] = {nullptr, nullptr};
@@ -216,11 +217,15 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     if (l1 == 2 && T > kFusedMaxCheckedT) return CCP_ERR_BAD_ARG;
     constexpr int TC = T <= kFusedMaxCheckedT ? T : 1;       // per-sweep sums exist up to kFusedMaxCheckedT
     hipStream_t bstream = border_stream ? border_stream : g->stream2;
+    // each concurrently issued launch orders its two kernels through an event pair of its own
+    const int band_i = border_stream == nullptr ? -1 : (border_stream == g->stream_eb[0] ? 0 : 1);
+    hipEvent_t ev_main = band_i < 0 ? g->ev_main : g->ev_band[band_i][0];
+    hipEvent_t ev_side = band_i < 0 ? g->ev_side : g->ev_band[band_i][1];
     // The border launch sees everything queued on the main stream so far, runs beside the ordinary
     // tiles, and whatever comes next on the main stream waits for it.
     if (n_border) {
-        CCP_HIP(hipEventRecord(g->ev_main, g->stream));
-        CCP_HIP(hipStreamWaitEvent(bstream, g->ev_main, 0));
+        CCP_HIP(hipEventRecord(ev_main, g->stream));
+        CCP_HIP(hipStreamWaitEvent(bstream, ev_main, 0));
     }
     if (any_plain) {
         if (l1 == 2) hipLaunchKernelGGL((k_fused_sweep<TC, 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
@@ -232,8 +237,8 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
         if (l1 == 2) hipLaunchKernelGGL((k_fused_border<TC, 2, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
         else if (l1 == 1) hipLaunchKernelGGL((k_fused_border<T, 1, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
         else hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
-        CCP_HIP(hipEventRecord(g->ev_side, bstream));
-        CCP_HIP(hipStreamWaitEvent(g->stream, g->ev_side, 0));
+        CCP_HIP(hipEventRecord(ev_side, bstream));
+        CCP_HIP(hipStreamWaitEvent(g->stream, ev_side, 0));
     }
     CCP_HIP(hipGetLastError());
     g->last_launches++;
@@ -479,7 +484,9 @@ int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
         for (int i = 0; i < 2 && st == CCP_OK; ++i)
             if (hipStreamCreateWithPriority(&g->stream_e[i], hipStreamNonBlocking, hi) != hipSuccess ||
                 hipStreamCreateWithPriority(&g->stream_eb[i], hipStreamNonBlocking, hi) != hipSuccess ||
-                hipEventCreateWithFlags(&g->ev_edge[i], hipEventDisableTiming) != hipSuccess)
+                hipEventCreateWithFlags(&g->ev_edge[i], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&g->ev_band[i][0], hipEventDisableTiming) != hipSuccess ||
+                hipEventCreateWithFlags(&g->ev_band[i][1], hipEventDisableTiming) != hipSuccess)
                 st = CCP_ERR_HIP;
         if (st == CCP_OK && hipEventCreateWithFlags(&g->ev_prev, hipEventDisableTiming) != hipSuccess) st = CCP_ERR_HIP;
     }
@@ -516,6 +523,8 @@ int ccp_grid_destroy(ccp_grid *g)
             (void)hipStreamDestroy(g->stream_eb[i]);
         }
         if (g->ev_edge[i]) (void)hipEventDestroy(g->ev_edge[i]);
+        for (int k = 0; k < 2; ++k)
+            if (g->ev_band[i][k]) (void)hipEventDestroy(g->ev_band[i][k]);
     }
     if (g->ev_prev) (void)hipEventDestroy(g->ev_prev);
     delete g;

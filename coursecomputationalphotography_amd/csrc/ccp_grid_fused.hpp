@@ -221,12 +221,15 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
         const double other = p ? lane_next(same) : lane_prev(same);
         const double left = p ? same : other;
         const double right = p ? other : same;
-        const double bv = c ? bk[sr] : br[sr];
+        // the window holds b/4 (exact): (b + s)/4 == fma(s, 1/4, b/4) bit for bit — scaling by a power
+        // of two commutes with the one rounding — and saves an instruction per update
+        const double bq = c ? bk[sr] : br[sr];
         const double old = c ? wk[sr] : wr[sr];
         double nv = old;
         if (MODE == kStepFast) {
-            nv = (bv + (((up + left) + right) + dn)) * 0.25;
+            nv = __builtin_fma(((up + left) + right) + dn, 0.25, bq);
         } else if (MODE == kStepSide) {
+            const double bv = bq * 4.0;
             // ordinary row y in [1, H-2]: cell(x,y-1), cell(x,y) exist iff x < W-1 (up, right,
             // down), cell(x-1,y) iff x >= 1 (left); a_ii = 3[x < W-1] + [x >= 1]
             const bool mr = cx.px_right[p], ml = cx.px_left[p];
@@ -244,8 +247,9 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
             // column 0) needs a true division — 1, 2 and 4 are exact reciprocals.
             const int y = g.y0 + r;
             const bool row_plain = (y >= 1) && (y <= g.H - 2);
+            const double bv = bq * 4.0;
             if (row_plain && cx.col_interior) {
-                nv = (bv + (((up + left) + right) + dn)) * 0.25;
+                nv = __builtin_fma(((up + left) + right) + dn, 0.25, bq);
             } else if (cx.px_ok[p]) {
                 const bool cellrow = y < g.H - 1;                        // cell(.,y) rows
                 const bool cf_up = (y >= 1) && cx.px_right[p];           // cell(x, y-1)
@@ -335,7 +339,7 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int s0 = Win::slot(i, 0);
-        wr[s0] = land[i][0]; wk[s0] = land[i][1]; br[s0] = land[i][2]; bk[s0] = land[i][3];
+        wr[s0] = land[i][0]; wk[s0] = land[i][1]; br[s0] = land[i][2] * 0.25; bk[s0] = land[i][3] * 0.25;
     }
 
     for (int fb = base; fb <= f_end; fb += G) {
@@ -371,7 +375,7 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int s0 = Win::slot(i, 0);
-            wr[s0] = land[i][0]; wk[s0] = land[i][1]; br[s0] = land[i][2]; bk[s0] = land[i][3];
+            wr[s0] = land[i][0]; wk[s0] = land[i][1]; br[s0] = land[i][2] * 0.25; bk[s0] = land[i][3] * 0.25;
         }
     }
 }

@@ -188,7 +188,11 @@ class ThreadDist:
                 reqs.append(self._Req(lambda: None))
             else:
                 def recv(t=op.tensor, src=op.peer):
-                    t.copy_(self.box[(src, me)].get(timeout=60))
+                    msg = self.box[(src, me)].get(timeout=60)
+                    t.copy_(msg)
+                    # msg was allocated on the sender's stream: keep it alive until this copy has run,
+                    # or the caching allocator hands its memory to the sender's next message
+                    torch.cuda.current_stream().synchronize()
                 reqs.append(self._Req(recv))
         torch.cuda.synchronize()
         return reqs
