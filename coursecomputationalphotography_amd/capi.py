@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
     "ccp_grid_get_b_host", "ccp_grid_fill_x", "ccp_grid_b_from_x", "ccp_grid_randomize_x",
-    "ccp_grid_sweep", "ccp_grid_sweep_edges_first", "ccp_grid_stream_wait_edges", "ccp_grid_tune", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_conjugate_gradient",
+    "ccp_grid_sweep", "ccp_grid_sweep_edges_first", "ccp_grid_stream_wait_edges", "ccp_grid_tune", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_gauss_seidel_lexicographic", "ccp_grid_conjugate_gradient",
     "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_assemble_from_images", "ccp_grid_store_u8",
     "ccp_grid_set_x_u8", "ccp_grid_last_timing",
 )
@@ -122,6 +122,7 @@ def load() -> C.CDLL:
     L.ccp_grid_tune.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float)]
     L.ccp_grid_halo_refreshed.argtypes = [vp]
     L.ccp_grid_gauss_seidel.argtypes = [vp, dbl, i32, i32, C.POINTER(Report)]
+    L.ccp_grid_gauss_seidel_lexicographic.argtypes = [vp, dbl, i32, i32, C.POINTER(Report)]
     L.ccp_grid_residual_norm2.argtypes = [vp, vp]
     L.ccp_grid_abs_sum.argtypes = [vp, vp]
     L.ccp_grid_assemble_rhs.argtypes = [vp, vp, vp, i64, vp]
@@ -339,6 +340,13 @@ class Grid:
     def gauss_seidel(self, epsilon=1e-6, max_iteration=1000, check_every=1):
         reps = (Report * self.C)()
         check(self.L.ccp_grid_gauss_seidel(self.h, epsilon, max_iteration, check_every, reps), "ccp_grid_gauss_seidel")
+        return list(reps)
+
+    def gauss_seidel_lexicographic(self, epsilon=1e-6, max_iteration=1000, check_every=1):
+        """The reference's own sweep order (index order), bit-identical iterates; whole-image handles."""
+        reps = (Report * self.C)()
+        check(self.L.ccp_grid_gauss_seidel_lexicographic(self.h, epsilon, max_iteration, check_every, reps),
+              "ccp_grid_gauss_seidel_lexicographic")
         return list(reps)
 
     def conjugate_gradient(self, epsilon=1e-16, max_iteration=1000):

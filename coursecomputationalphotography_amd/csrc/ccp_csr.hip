@@ -442,6 +442,24 @@ int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *
             return ccp_grid_get_x_host(m->grid, 0, x_out, 0, m->poisson_h);
         }
     }
+    if (ordering == CCP_ORDER_LEXICOGRAPHIC && m->allow_structured) {
+        // The reference's own order on the recognised Poisson matrix: the hyperplane pipeline of
+        // ccp_grid_lex.hpp — the same iterates as the level schedule below, without a launch per level
+        // and per sweep.
+        detect_poisson(m);
+        if (m->poisson_w > 1 && m->poisson_h > 1) {
+            if (!m->grid) {
+                ccp_grid_desc d{m->poisson_w, m->poisson_h, 1, 0, m->poisson_h, 0, m->device, 0};
+                CCP_TRY(ccp_grid_create(&d, &m->grid));
+            }
+            CCP_TRY(ccp_grid_set_stream(m->grid, m->stream));
+            CCP_TRY(ccp_grid_set_b_host(m->grid, 0, b, 0, m->poisson_h));
+            if (x0) CCP_TRY(ccp_grid_set_x_host(m->grid, 0, x0, 0, m->poisson_h));
+            else CCP_TRY(ccp_grid_fill_x(m->grid, 1.0));                       // sparse-matrix.h:352
+            CCP_TRY(ccp_grid_gauss_seidel_lexicographic(m->grid, epsilon, max_iteration, check_every, report));
+            return ccp_grid_get_x_host(m->grid, 0, x_out, 0, m->poisson_h);
+        }
+    }
     Schedule &sc = ordering == CCP_ORDER_MULTICOLOUR ? m->multicolour : m->lexicographic;
     CCP_TRY(ordering == CCP_ORDER_MULTICOLOUR ? ensure_multicolour(m) : ensure_lexicographic(m));
     const long n = m->n_rows;

@@ -1,6 +1,7 @@
 // ccp_grid.hip — C ABI of the structured (matrix-free) Poisson grid path.  See include/ccp_gs.h.
 #include "ccp_grid_kernels.hpp"
 #include "ccp_grid_fused.hpp"
+#include "ccp_grid_lex.hpp"
 #include "ccp_cg.hpp"
 
 #include <algorithm>
@@ -45,6 +46,9 @@ struct ccp_grid {
     DevBuf<double> small;        // 4*kMaxChannels doubles of reduced results
     DevBuf<SolveState> state;
     DevBuf<int> redo_mask;       // per-channel flags for re-running one channel of a checked pass
+    // lexicographic (reference-order) path: diagonal-major copies of x and b, snapshot, step sums
+    DevBuf<double> lex_x, lex_b, lex_snap, lex_partial, lex_eps;
+    LexGeom lexg{};
     DevBuf<double> stage;        // natural-order staging rows for host transfers
     long stage_rows = 0;
     int half_sweeps_since_refresh = 0;
@@ -904,6 +908,136 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
             report[ch].converged = host.converged[ch];
             report[ch].iterations = host.converged[ch] ? host.iterations[ch] : issued;
             report[ch].last_l1_step = host.last_eps[ch];
+            report[ch].seconds = ms * 1e-3;
+        }
+    }
+    return CCP_OK;
+}
+
+namespace {
+
+// `iterations` lexicographic sweeps of the channels in `mask`, pipelined over the hyperplanes
+// tau = x + y + 2k (ccp_grid_lex.hpp).  partial != nullptr: per-sweep step sums are written too.
+int lex_run(ccp_grid *g, int iterations, unsigned mask, double *partial)
+{
+    const LexGeom &lg = g->lexg;
+    const int d_max = lg.n_diag - 1;
+    const int C = g->desc.channels;
+    for (int tau = 0; tau <= d_max + 2 * (iterations - 1); ++tau) {
+        const int k_lo = std::max(0, (tau - d_max + 1) / 2);          // smallest k with tau - 2k <= d_max
+        const int k_hi = std::min(iterations - 1, tau / 2);           // largest k with tau - 2k >= 0
+        if (k_hi < k_lo) continue;
+        dim3 grid((unsigned)lg.nbx, (unsigned)(k_hi - k_lo + 1), (unsigned)C);
+        if (partial)
+            hipLaunchKernelGGL((k_lex_plane<true>), grid, dim3(kBlock), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg,
+                               tau, k_lo, mask, partial);
+        else
+            hipLaunchKernelGGL((k_lex_plane<false>), grid, dim3(kBlock), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg,
+                               tau, k_lo, mask, static_cast<double *>(nullptr));
+    }
+    CCP_HIP(hipGetLastError());
+    return CCP_OK;
+}
+
+}  // namespace
+
+int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max_iteration, int32_t check_every,
+                                        ccp_gs_report *report)
+{
+    CCP_TRY(bind(g));
+    if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;   // whole image only
+    if (max_iteration < 0 || check_every < 0) return CCP_ERR_BAD_ARG;
+    const int C = g->desc.channels, W = g->desc.width, H = g->desc.height;
+    LexGeom &lg = g->lexg;
+    lg.W = W;
+    lg.H = H;
+    lg.P = ((long)W + 15) / 16 * 16;
+    lg.n_diag = W + H - 1;
+    lg.plane = (long)lg.n_diag * lg.P;
+    lg.nbx = (std::min(W, H) + kLexTile - 1) / kLexTile;
+    const size_t elems = (size_t)lg.plane * C;
+    if (g->lex_x.n != elems) {
+        CCP_TRY(g->lex_x.alloc(elems));
+        CCP_TRY(g->lex_b.alloc(elems));
+    }
+    begin_timing(g);
+    dim3 cgrid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, (unsigned)C);
+    hipLaunchKernelGGL((k_lex_convert<true>), cgrid, dim3(kBlock), 0, g->stream, g->x.p, g->lex_x.p, g->geom, lg);
+    hipLaunchKernelGGL((k_lex_convert<true>), cgrid, dim3(kBlock), 0, g->stream, g->b.p, g->lex_b.p, g->geom, lg);
+    CCP_HIP(hipGetLastError());
+
+    const unsigned all = (C >= 32) ? 0xffffffffu : ((1u << C) - 1u);
+    int iterations_of[kMaxChannels], converged[kMaxChannels];
+    double last_eps[kMaxChannels];
+    for (int ch = 0; ch < C; ++ch) {
+        iterations_of[ch] = max_iteration;
+        converged[ch] = 0;
+        last_eps[ch] = 10.0;                                              // `double eps = 10` (sparse-matrix.h:354)
+    }
+    if (check_every == 0 || !(10.0 > epsilon)) {
+        // fixed count — or the reference loop never starts (eps = 10 <= epsilon)
+        const int n = check_every == 0 ? max_iteration : 0;
+        if (n > 0) CCP_TRY(lex_run(g, n, all, nullptr));
+        for (int ch = 0; ch < C; ++ch) iterations_of[ch] = n;
+    } else {
+        const int batch_max = 64;
+        const long per = (long)lg.n_diag * lg.nbx;                          // partials per (iteration, channel)
+        if (g->lex_partial.n != (size_t)per * batch_max * C) CCP_TRY(g->lex_partial.alloc((size_t)per * batch_max * C));
+        if (g->lex_eps.n != (size_t)batch_max * C) CCP_TRY(g->lex_eps.alloc((size_t)batch_max * C));
+        if (g->lex_snap.n != elems) CCP_TRY(g->lex_snap.alloc(elems));
+        std::vector<double> eps_host((size_t)batch_max * C);
+        unsigned mask = all;
+        int done = 0;
+        while (mask && done < max_iteration) {
+            const int kb = std::min(batch_max, max_iteration - done);
+            CCP_HIP(hipMemcpyAsync(g->lex_snap.p, g->lex_x.p, elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+            CCP_TRY(lex_run(g, kb, mask, g->lex_partial.p));
+            hipLaunchKernelGGL(k_lex_reduce, dim3((unsigned)kb, (unsigned)C), dim3(kBlock), 0, g->stream, g->lex_partial.p, per,
+                               g->lex_eps.p);
+            CCP_HIP(hipGetLastError());
+            CCP_HIP(hipMemcpyAsync(eps_host.data(), g->lex_eps.p, sizeof(double) * kb * C, hipMemcpyDeviceToHost, g->stream));
+            CCP_HIP(hipStreamSynchronize(g->stream));
+            for (int ch = 0; ch < C; ++ch) {
+                if (!((mask >> ch) & 1u)) continue;
+                int stop = -1;
+                for (int k = 0; k < kb; ++k) {
+                    if ((done + k + 1) % check_every != 0) continue;
+                    last_eps[ch] = eps_host[(size_t)k * C + ch];
+                    if (!(last_eps[ch] > epsilon)) {
+                        stop = k;
+                        break;
+                    }
+                }
+                if (stop < 0) continue;
+                converged[ch] = 1;
+                iterations_of[ch] = done + stop + 1;
+                mask &= ~(1u << ch);
+                if (stop < kb - 1) {
+                    // the pipeline ran past the sweep the rule stops at: redo exactly stop+1 sweeps of
+                    // this channel from the snapshot taken before the batch
+                    CCP_HIP(hipMemcpyAsync(g->lex_x.p + (size_t)ch * lg.plane, g->lex_snap.p + (size_t)ch * lg.plane,
+                                           (size_t)lg.plane * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+                    CCP_TRY(lex_run(g, stop + 1, 1u << ch, nullptr));
+                }
+            }
+            done += kb;
+        }
+        for (int ch = 0; ch < C; ++ch)
+            if (!converged[ch]) iterations_of[ch] = done;
+    }
+    hipLaunchKernelGGL((k_lex_convert<false>), cgrid, dim3(kBlock), 0, g->stream, g->x.p, g->lex_x.p, g->geom, lg);
+    CCP_HIP(hipGetLastError());
+    end_timing(g);
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    float ms = 0.f;
+    CCP_HIP(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+    g->last_ms = ms;
+    g->timing_pending = false;
+    if (report) {
+        for (int ch = 0; ch < C; ++ch) {
+            report[ch].converged = converged[ch];
+            report[ch].iterations = iterations_of[ch];
+            report[ch].last_l1_step = last_eps[ch];
             report[ch].seconds = ms * 1e-3;
         }
     }

@@ -212,6 +212,14 @@ int ccp_grid_halo_refreshed(ccp_grid *g);
 int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration,
                           int32_t check_every, ccp_gs_report *report);
 
+/* The same loop in the reference's OWN sweep order (index order, sparse-matrix.h:357-370): iterates,
+ * stop sweep and result are those of SparseMatrix::gaussSeidel on the unpermuted matrix, bit for bit
+ * (eps to summation order).  The sweep is pipelined over the hyperplanes x + y + 2k (pixel, iteration),
+ * one launch per hyperplane, on a diagonal-major copy of x and b (2x the image's memory while it runs).
+ * Whole-image handles only (no ghost rows: CCP_ERR_STATE).  check_every as above. */
+int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max_iteration,
+                                        int32_t check_every, ccp_gs_report *report);
+
 /* conjugateGradient (sparse-matrix.h:396-434) on the resident system, matrix-free, channel by
  * channel; the resident x is the initial guess (ccp_grid_fill_x(g, 0) for the reference default,
  * ccp_grid_set_x_u8 for the composite start of PhotoMontage.cpp:599-610).  report: `channels`

@@ -1,0 +1,152 @@
+"""GPU parity of the reference-ORDER (lexicographic) Gauss-Seidel on the structured Poisson grid —
+`ccp_grid_gauss_seidel_lexicographic` and its dispatch from the general CSR entry point.
+
+Checker: the golden fixtures (x_lex_k*: iterates of the compiled reference header itself, the
+UNPERMUTED matrix) and the CPU oracle on seeded systems.  Bar: bit-exact iterates, identical stop
+sweep; the stop quantity eps agrees to summation order (1e-12 relative).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from coursecomputationalphotography_amd import capi
+    assert capi.device_count() >= 1, "no HIP device: the product path has no CPU fallback"
+    return capi
+
+
+def run_lex(capi, W, H, b, epsilon, max_it, check_every, channels=1, x0=None):
+    g = capi.Grid(W, H, channels)
+    for ch in range(channels):
+        g.set_b(np.asarray(b).reshape(channels, H, W)[ch], ch)
+    if x0 is None:
+        g.fill_x(1.0)
+    else:
+        for ch in range(channels):
+            g.set_x(np.asarray(x0).reshape(channels, H, W)[ch], ch)
+    reps = g.gauss_seidel_lexicographic(epsilon, max_it, check_every)
+    out = np.stack([g.get_x(ch).ravel() for ch in range(channels)])
+    g.close()
+    return out, reps
+
+
+@pytest.mark.parametrize("name", ["poisson_8x8.npz", "poisson_17x13.npz", "poisson_64x64.npz"])
+def test_iterates_match_reference_fixture(capi, golden, name):
+    d = golden(name)
+    W, H = int(d["W"]), int(d["H"])
+    for k in (1, 2, 10, 50):
+        x, reps = run_lex(capi, W, H, d["b"], 0.0, k, 0)
+        assert np.array_equal(x[0], d[f"x_lex_k{k}"]), f"{name} k={k}: max abs diff {np.abs(x[0] - d[f'x_lex_k{k}']).max()}"
+        assert reps[0].iterations == k
+
+
+@pytest.mark.parametrize("W,H", [(2, 2), (1, 5), (5, 1), (3, 6), (33, 7), (130, 5), (1030, 9), (9, 1030), (391, 301), (2050, 1030)])
+def test_vs_oracle_seeded(capi, orc, W, H):
+    from coursecomputationalphotography_amd import synth
+    b, _ = synth.poisson_system(W, H, 99)
+    m = orc.from_csr(*synth.poisson_csr(W, H))
+    for k in (1, 3, 8):
+        want, _, _ = m.gauss_seidel(b, 0.0, k)
+        x, _ = run_lex(capi, W, H, b, 0.0, k, 0)
+        assert np.array_equal(x[0], want), (W, H, k, np.abs(x[0] - want).max())
+
+
+@pytest.mark.parametrize("stop_at", [1, 5, 63, 64, 65, 100])
+def test_stop_rule_is_the_references(capi, orc, stop_at):
+    """`while (eps > epsilon && cnt < max_iteration)` (sparse-matrix.h:356): epsilon is set just above the
+    oracle's eps after sweep `stop_at`, so the loop must stop exactly there — inside the first pipelined
+    batch of 64, at its end, and in the second batch."""
+    from coursecomputationalphotography_amd import synth
+    W, H = 97, 61
+    b, _ = synth.poisson_system(W, H, 5)
+    b = b * 1e-3                                     # keeps eps below its start value of 10
+    m = orc.from_csr(*synth.poisson_csr(W, H))
+    _, it, eps_k = m.gauss_seidel(b, 0.0, stop_at)
+    assert it == stop_at
+    epsilon = eps_k * (1.0 + 1e-9)
+    want, it_want, eps_want = m.gauss_seidel(b, epsilon, 1000)
+    x, reps = run_lex(capi, W, H, b, epsilon, 1000, 1)
+    assert reps[0].iterations == it_want          # stop_at, or 0 when epsilon >= 10 and the loop never starts
+    if it_want > 0:
+        assert reps[0].converged == 1 and abs(reps[0].last_l1_step - eps_want) <= 1e-12 * eps_want
+    assert np.array_equal(x[0], want)
+
+
+def test_max_iteration_without_convergence_and_check_every(capi, orc):
+    from coursecomputationalphotography_amd import synth
+    W, H = 50, 40
+    b, _ = synth.poisson_system(W, H, 6)
+    m = orc.from_csr(*synth.poisson_csr(W, H))
+    want, it, eps = m.gauss_seidel(b * 1e-3, 1e-30, 70)
+    x, reps = run_lex(capi, W, H, b * 1e-3, 1e-30, 70, 1)
+    assert it == 70 and reps[0].iterations == 70 and reps[0].converged == 0
+    assert abs(reps[0].last_l1_step - eps) <= 1e-12 * eps
+    assert np.array_equal(x[0], want)
+    # rule tested every 7th sweep only: stops at the first multiple of 7 at or after the reference's stop sweep
+    _, _, eps20 = m.gauss_seidel(b * 1e-3, 0.0, 20)
+    epsilon = eps20 * (1.0 + 1e-9)
+    x7, reps7 = run_lex(capi, W, H, b * 1e-3, epsilon, 500, 7)
+    assert reps7[0].iterations == 21 and reps7[0].converged == 1
+    want21, _, _ = m.gauss_seidel(b * 1e-3, 0.0, 21)
+    assert np.array_equal(x7[0], want21)
+
+
+def test_three_channels_stop_independently(capi, orc):
+    """One epsilon, three channels scaled so that the rule fires at sweeps 20, 70 (second batch) and 130."""
+    from coursecomputationalphotography_amd import synth
+    W, H = 64, 48
+    m = orc.from_csr(*synth.poisson_csr(W, H))
+    x0 = np.zeros(W * H)                              # from x0 = 0 the sweep is linear in b: eps scales with b
+    epsilon, bs = 0.05, []
+    for seed, k in ((1, 20), (2, 70), (3, 130)):
+        b = synth.poisson_system(W, H, seed)[0]
+        _, _, eps_k = m.gauss_seidel(b, 0.0, k, x0=x0)
+        bs.append(b * (epsilon / eps_k * (1.0 - 1e-9)))
+    wants = [m.gauss_seidel(b, epsilon, 300, x0=x0) for b in bs]
+    assert [w[1] for w in wants] == [20, 70, 130]
+    x, reps = run_lex(capi, W, H, np.stack(bs), epsilon, 300, 1, channels=3, x0=np.zeros((3, H, W)))
+    for ch in range(3):
+        assert reps[ch].iterations == wants[ch][1] and reps[ch].converged == 1
+        assert np.array_equal(x[ch], wants[ch][0])
+
+
+def test_start_vector_extension(capi, orc):
+    from coursecomputationalphotography_amd import synth
+    W, H = 77, 33
+    b, xt = synth.poisson_system(W, H, 8)
+    x0 = (xt * 0.5 + 3.0)
+    m = orc.from_csr(*synth.poisson_csr(W, H))
+    want, _, _ = m.gauss_seidel(b, 0.0, 9, x0=x0.ravel())
+    x, _ = run_lex(capi, W, H, b, 0.0, 9, 0, x0=x0)
+    assert np.array_equal(x[0], want)
+
+
+def test_csr_entry_point_reaches_the_structured_path(capi, orc):
+    """The unchanged reference call (ConvertFromEigen -> gaussSeidel, default order) on SolveChannel's
+    matrix: recognised, swept by the hyperplane pipeline, same bits as the oracle."""
+    from coursecomputationalphotography_amd import synth
+    W, H = 211, 157
+    v, c, r = synth.poisson_csr(W, H)
+    b, _ = synth.poisson_system(W, H, 9)
+    m = capi.CsrMatrix()
+    m.upload_compressed(v, c, r)
+    om = orc.from_csr(v, c, r)
+    epsilon = om.gauss_seidel(b * 1e-3, 0.0, 90)[2] * (1.0 + 1e-9)         # the rule fires at sweep 90
+    x, rep = m.gauss_seidel(b * 1e-3, epsilon=epsilon, max_iteration=400, check_every=1, ordering=capi.ORDER_LEXICOGRAPHIC)
+    want, it, eps = om.gauss_seidel(b * 1e-3, epsilon, 400)
+    assert it == 90 and rep.iterations == it and rep.converged == 1
+    assert np.array_equal(x, want)
+    m.close()
+
+
+def test_mid_size_against_oracle(capi, orc):
+    """2048x1536 (3.1 M unknowns), 6 sweeps: many blocks per diagonal, thousands of launches."""
+    from coursecomputationalphotography_amd import synth
+    W, H = 2048, 1536
+    b, _ = synth.poisson_system(W, H, 10)
+    want, _, _ = orc.from_csr(*synth.poisson_csr(W, H)).gauss_seidel(b, 0.0, 6)
+    x, reps = run_lex(capi, W, H, b, 0.0, 6, 0)
+    assert np.array_equal(x[0], want)
