@@ -55,6 +55,8 @@ def parse():
     ap.add_argument("--no-tune", action="store_true", help="skip ccp_grid_tune (use the built-in defaults)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-converge", action="store_true", help="skip the untimed iterations-to-1e-5 run")
+    ap.add_argument("--no-reference-order", action="store_true", help="skip the untimed lexicographic-order run (N=1)")
+    ap.add_argument("--reference-order-iters", type=int, default=128)
     ap.add_argument("--converge-cap", type=int, default=6000)
     ap.add_argument("--cpu-sample", type=int, default=4096, help="edge of the CPU baseline sample grid")
     ap.add_argument("--cpu-iters", type=int, default=24)
@@ -200,6 +202,20 @@ def main():
         extra["rel_residual_final"] = rel
         # the reference's own stop quantity, sum|x_k - x_{k-1}| (sparse-matrix.h:376), one more sweep
         extra["l1_step_after"] = [done + 1, float(solver.sweep_l1().max())]
+
+    if world == 1 and not args.no_reference_order:
+        # untimed extra: the reference's OWN sweep order (lexicographic), bit-identical iterates, on the
+        # same system from the same start vector (ccp_grid_gauss_seidel_lexicographic)
+        g.fill_x(1.0)
+        g.gauss_seidel_lexicographic(0.0, 4, 0)                       # allocations, code load
+        g.fill_x(1.0)
+        rep = g.gauss_seidel_lexicographic(0.0, args.reference_order_iters, 0)[0]
+        extra["reference_order"] = {
+            "what": "lexicographic Gauss-Seidel (the reference's index-order sweep, sparse-matrix.h:357-370), "
+                    "hyperplane-pipelined; iterates bit-identical to the reference's",
+            "iterations": rep.iterations, "seconds": rep.seconds,
+            "pixel_updates_per_s": float(W) * H * C * rep.iterations / rep.seconds,
+            "rel_residual_after": float(solver.rel_residual().max())}
 
     if rank == 0:
         out = {
