@@ -27,7 +27,9 @@ struct ImageView {
     std::size_t step;          // bytes per image row
 };
 
-enum class Solver { GaussSeidel, ConjugateGradient };
+// GaussSeidel: red-black order (the fast path).  GaussSeidelReferenceOrder: the reference's index-order
+// sweep, iterates bit-identical to SparseMatrix::gaussSeidel on the matrix SolveChannel builds.
+enum class Solver { GaussSeidel, ConjugateGradient, GaussSeidelReferenceOrder };
 
 namespace detail {
 inline void check(int status, const char *what)
@@ -50,6 +52,9 @@ inline void solve(ccp_grid *g, Solver solver, int iterations, int channels)
     std::vector<ccp_gs_report> rep(channels);
     if (solver == Solver::GaussSeidel)
         check(ccp_grid_gauss_seidel(g, 1e-10, iterations, /*check_every=*/0, rep.data()), "ccp_grid_gauss_seidel");
+    else if (solver == Solver::GaussSeidelReferenceOrder)
+        check(ccp_grid_gauss_seidel_lexicographic(g, 1e-10, iterations, /*check_every=*/0, rep.data()),
+              "ccp_grid_gauss_seidel_lexicographic");
     else
         check(ccp_grid_conjugate_gradient(g, 1e-10, iterations, rep.data()), "ccp_grid_conjugate_gradient");
 }
@@ -90,7 +95,7 @@ inline void SolveChannel(int channel_idx, int constraint, const ImageView &gx, c
         }
         detail::check(ccp_grid_set_x_u8(h.g, plane.data(), W), "ccp_grid_set_x_u8");
     } else {
-        detail::check(ccp_grid_fill_x(h.g, solver == Solver::GaussSeidel ? 1.0 : 0.0), "ccp_grid_fill_x");
+        detail::check(ccp_grid_fill_x(h.g, solver == Solver::ConjugateGradient ? 0.0 : 1.0), "ccp_grid_fill_x");
     }
     detail::solve(h.g, solver, iterations, 1);
     std::vector<uint8_t> out((std::size_t)W * H);
@@ -121,7 +126,7 @@ inline void BuildSolveGradientFusion(const std::vector<ImageView> &images, const
                                                 static_cast<const uint8_t *>(label.data), (int64_t)label.step,
                                                 fast_init_value ? 1 : 0),
                   "ccp_grid_assemble_from_images");
-    if (!fast_init_value) detail::check(ccp_grid_fill_x(h.g, solver == Solver::GaussSeidel ? 1.0 : 0.0), "ccp_grid_fill_x");
+    if (!fast_init_value) detail::check(ccp_grid_fill_x(h.g, solver == Solver::ConjugateGradient ? 0.0 : 1.0), "ccp_grid_fill_x");
     detail::solve(h.g, solver, iterations, 3);
     detail::check(ccp_grid_store_u8(h.g, static_cast<uint8_t *>(result.data), (int64_t)result.step), "ccp_grid_store_u8");
 }
