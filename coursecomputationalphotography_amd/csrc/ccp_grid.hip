@@ -33,6 +33,9 @@ struct ccp_grid {
     DevBuf<CgState> cg_state;
     DevBuf<double> x_alt;        // ping-pong partner of x for the temporally blocked sweep
     bool fuse = true;            // use k_fused_sweep for unchecked sweeps
+    bool short_edges = true;     // chunk rows at an image edge are short (CCP_GS_SHORT_EDGES=0 turns it off)
+    int edge_mode = 2;           // CCP_GS_EDGE_MODE: where ccp_grid_sweep_edges_first issues the bands
+    int side_rows_override = 0;  // CCP_GS_SIDE_ROWS
     int fuse_tmax = kFusedMaxT;  // iterations fused per launch (<= kFusedMaxT)
     int rows_per_chunk = 128;    // rows a fused wave finalises (plus 4T halo rows); default for every T
     // per-depth launch cost (ms) and chunk rows measured by ccp_grid_tune; index = T
@@ -154,7 +157,7 @@ void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P)
     const int rows = P.st_hi - P.st_lo;
     const int edge_rows = HS + 16;
     const bool at_top = geo.y0 + P.st_lo - HS <= 0, at_bot = geo.y0 + P.st_hi + HS >= geo.H - 1;
-    static const bool short_edges = !(getenv("CCP_GS_SHORT_EDGES") && atoi(getenv("CCP_GS_SHORT_EDGES")) == 0);
+    const bool short_edges = g->short_edges;
     P.first_rows = (short_edges && at_top && rows > 2 * edge_rows + R / 2 && R > edge_rows) ? edge_rows : 0;
     P.last_rows = (short_edges && at_bot && rows > 2 * edge_rows + R / 2 && R > edge_rows) ? edge_rows : 0;
     const int mid = rows - P.first_rows - P.last_rows;
@@ -206,7 +209,7 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
         const int HS = 2 * T, R = P.rows_per_chunk;
         int sr = std::max(16, (R + 2 * HS) * 2 / 5 - 2 * HS);
         sr += sr & 1;
-        if (const char *e = getenv("CCP_GS_SIDE_ROWS")) sr = std::max(2, atoi(e));
+        if (g->side_rows_override > 0) sr = std::max(2, g->side_rows_override);
         P.side_rows = std::min(sr, R);
         P.side_subs = (R + P.side_rows - 1) / P.side_rows;
     }
@@ -291,7 +294,7 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int 
             const int before = g->last_launches;
             hipStream_t main_stream = g->stream;
             CCP_HIP(hipEventRecord(g->ev_prev, main_stream));
-            static const int mode = getenv("CCP_GS_EDGE_MODE") ? atoi(getenv("CCP_GS_EDGE_MODE")) : 2;
+            const int mode = g->edge_mode;
             for (int i = 0; i < 2; ++i) {
                 if (band[i][1] > band[i][0]) {
                     // mode 0: bands on the main stream before the middle; 1: both bands on one extra stream,
@@ -459,6 +462,9 @@ int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
     if (const char *e = getenv("CCP_GS_CPT")) g->cpt = (atoi(e) == 4) ? 4 : 2;
     if (const char *e = getenv("CCP_GS_SHFL")) g->shfl = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
+    if (const char *e = getenv("CCP_GS_SHORT_EDGES")) g->short_edges = atoi(e) != 0;
+    if (const char *e = getenv("CCP_GS_EDGE_MODE")) g->edge_mode = std::max(0, std::min(2, atoi(e)));
+    if (const char *e = getenv("CCP_GS_SIDE_ROWS")) g->side_rows_override = atoi(e);
     if (const char *e = getenv("CCP_GS_TMAX")) g->fuse_tmax = std::max(1, std::min(kFusedMaxT, atoi(e)));
     if (const char *e = getenv("CCP_GS_ALL_BORDER")) g->all_border = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_FORCE_BORDER")) g->force_border = atoi(e) != 0;

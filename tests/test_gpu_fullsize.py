@@ -93,6 +93,30 @@ def test_every_pixel_fused_equals_in_place_unstructured(capi, monkeypatch, W, H,
     assert np.array_equal(out[0], out[1])
 
 
+@pytest.mark.parametrize("env", [{"CCP_GS_ALL_BORDER": "1"}, {"CCP_GS_ALL_BORDER": "1", "CCP_GS_FORCE_BORDER": "1"},
+                                 {"CCP_GS_SHORT_EDGES": "0"}, {"CCP_GS_SIDE_ROWS": "10"}, {"CCP_GS_TMAX": "3"},
+                                 {"CCP_GS_TMAX": "5", "CCP_GS_CHUNK": "40"}, {"CCP_GS_CHUNK": "1000"}])
+def test_tiling_switches_never_change_results(capi, monkeypatch, env):
+    """Every debugging / tiling switch of DESIGN section 8 on a grid with several strips and chunks: the
+    temporally blocked pass must reproduce the in-place kernels bit for bit whatever the tiling."""
+    W, H, iters = 1500, 900, 14
+    rng = np.random.Generator(np.random.MT19937(11))
+    b = rng.uniform(-3.0, 3.0, (H, W))
+    x0 = rng.uniform(0.0, 255.0, (H, W))
+    out = []
+    for fuse in ("1", "0"):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("CCP_GS_FUSE", fuse)
+        g = capi.Grid(W, H, 1)
+        g.set_b(b)
+        g.set_x(x0)
+        g.sweep(iters)
+        out.append(g.get_x().copy())
+        g.close()
+    assert np.array_equal(out[0], out[1])
+
+
 def test_three_channel_4096_fused_equals_in_place(capi, monkeypatch):
     """configs[1]: 4096x4096 three-channel blend."""
     W = H = 4096
