@@ -986,7 +986,7 @@ int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max
         if (n > 0) CCP_TRY(lex_run(g, n, all, nullptr));
         for (int ch = 0; ch < C; ++ch) iterations_of[ch] = n;
     } else {
-        const int batch_max = 64;
+        const int batch_max = 128;                                       // sweeps in flight between two looks at the rule
         const long per = (long)lg.n_diag * lg.nbx;                          // partials per (iteration, channel)
         if (g->lex_partial.n != (size_t)per * batch_max * C) CCP_TRY(g->lex_partial.alloc((size_t)per * batch_max * C));
         if (g->lex_eps.n != (size_t)batch_max * C) CCP_TRY(g->lex_eps.alloc((size_t)batch_max * C));

@@ -54,11 +54,11 @@ def test_vs_oracle_seeded(capi, orc, W, H):
         assert np.array_equal(x[0], want), (W, H, k, np.abs(x[0] - want).max())
 
 
-@pytest.mark.parametrize("stop_at", [1, 5, 63, 64, 65, 100])
+@pytest.mark.parametrize("stop_at", [1, 5, 127, 128, 129, 200])
 def test_stop_rule_is_the_references(capi, orc, stop_at):
     """`while (eps > epsilon && cnt < max_iteration)` (sparse-matrix.h:356): epsilon is set just above the
     oracle's eps after sweep `stop_at`, so the loop must stop exactly there — inside the first pipelined
-    batch of 64, at its end, and in the second batch."""
+    batch of 128, at its end, and in the second batch."""
     from coursecomputationalphotography_amd import synth
     W, H = 97, 61
     b, _ = synth.poisson_system(W, H, 5)
@@ -95,7 +95,7 @@ def test_max_iteration_without_convergence_and_check_every(capi, orc):
 
 
 def test_three_channels_stop_independently(capi, orc):
-    """One epsilon, three channels scaled so that the rule fires at sweeps 20, 70 (second batch) and 130."""
+    """One epsilon, three channels scaled so that the rule fires at sweeps 20, 70 and 130 (second batch)."""
     from coursecomputationalphotography_amd import synth
     W, H = 64, 48
     m = orc.from_csr(*synth.poisson_csr(W, H))
