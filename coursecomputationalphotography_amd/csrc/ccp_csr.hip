@@ -8,6 +8,10 @@
 #include <cstring>
 #include <numeric>
 #include <vector>
+#include <memory>
+#include <thread>
+#include <atomic>
+#include <chrono>
 
 using namespace ccp;
 
@@ -70,6 +74,33 @@ struct ccp_csr {
 };
 
 namespace {
+
+// Host-side schedule construction is embarrassingly parallel per slice / per row: plain std::thread
+// workers over contiguous ranges (no OpenMP runtime to depend on).
+template <typename F>
+void parallel_ranges(long n, long min_per_thread, F &&body)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    long workers = std::max<long>(1, std::min<long>(hw ? hw : 1, 32));
+    workers = std::max<long>(1, std::min<long>(workers, n / std::max<long>(1, min_per_thread)));
+    if (workers <= 1) {
+        body(0L, n);
+        return;
+    }
+    std::vector<std::thread> pool;
+    const long chunk = (n + workers - 1) / workers;
+    for (long w = 0; w < workers; ++w) {
+        const long lo = w * chunk, hi = std::min(n, lo + chunk);
+        if (lo >= hi) break;
+        pool.emplace_back([&body, lo, hi] { body(lo, hi); });
+    }
+    for (auto &t : pool) t.join();
+}
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 int bind(ccp_csr *m)
 {
@@ -152,6 +183,7 @@ int upload_vec(DevBuf<T> &d, const std::vector<T> &h, hipStream_t s)
 int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int n_groups, bool sort_by_permuted)
 {
     const int n = m->n_rows;
+    const double t_begin = now_s();
     std::vector<long> gcount((size_t)n_groups + 1, 0);
     for (int i = 0; i < n; ++i) gcount[(size_t)group[i] + 1]++;
     for (int g = 0; g < n_groups; ++g) gcount[g + 1] += gcount[g];
@@ -165,6 +197,7 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
     // solved; SpMV uses the identity schedule where inv is the identity anyway)
     auto map_col = [&](int c) { return (c >= 0 && c < n) ? inv[c] : c; };
 
+    const double t_perm = now_s();
     std::vector<int> srow0, srows, swidth;
     std::vector<long> soff;
     sc.group_slice_ptr.assign((size_t)n_groups + 1, 0);
@@ -190,35 +223,64 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
     }
     sc.n_slices = (int)srow0.size();
     sc.n_groups = n_groups;
-    std::vector<int> cols((size_t)std::max<long>(total, 1), -1);
-    std::vector<double> vals((size_t)std::max<long>(total, 1), 0.0);
-    std::vector<std::pair<int, double>> tmp;
-    for (int s = 0; s < sc.n_slices; ++s) {
-        for (int t = 0; t < srows[s]; ++t) {
-            const int old = perm[srow0[s] + t];
-            tmp.clear();
-            for (long k = m->row_ptr[old]; k < m->row_ptr[old + 1]; ++k)
-                tmp.emplace_back(map_col(m->col[k]), m->val[k]);
-            if (sort_by_permuted)
-                std::stable_sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-            for (size_t k = 0; k < tmp.size(); ++k) {
-                cols[(size_t)soff[s] + k * kWave + t] = tmp[k].first;
-                vals[(size_t)soff[s] + k * kWave + t] = tmp[k].second;
+    const double t_fill0 = now_s();
+    // uninitialised on purpose: every element is written below, by the thread that first touches its page
+    const size_t n_entries = (size_t)std::max<long>(total, 1);
+    std::unique_ptr<int[]> cols(new int[n_entries]);
+    std::unique_ptr<double[]> vals(new double[n_entries]);
+    parallel_ranges(sc.n_slices, 256, [&](long s_lo, long s_hi) {
+        std::vector<std::pair<int, double>> tmp;
+        for (long s = s_lo; s < s_hi; ++s) {
+            // padding: column -1, value 0
+            const size_t base = (size_t)soff[s], len = (size_t)swidth[s] * kWave;
+            std::fill(cols.get() + base, cols.get() + base + len, -1);
+            std::fill(vals.get() + base, vals.get() + base + len, 0.0);
+            for (int t = 0; t < srows[s]; ++t) {
+                const int old = perm[srow0[s] + t];
+                tmp.clear();
+                for (long k = m->row_ptr[old]; k < m->row_ptr[old + 1]; ++k)
+                    tmp.emplace_back(map_col(m->col[k]), m->val[k]);
+                if (sort_by_permuted) {
+                    // stable insertion sort: rows are a handful of entries
+                    for (size_t a = 1; a < tmp.size(); ++a) {
+                        const auto v = tmp[a];
+                        size_t b = a;
+                        while (b > 0 && tmp[b - 1].first > v.first) {
+                            tmp[b] = tmp[b - 1];
+                            --b;
+                        }
+                        tmp[b] = v;
+                    }
+                }
+                for (size_t k = 0; k < tmp.size(); ++k) {
+                    cols[base + k * kWave + t] = tmp[k].first;
+                    vals[base + k * kWave + t] = tmp[k].second;
+                }
             }
         }
-    }
+    });
+    const double t_fill1 = now_s();
     CCP_TRY(upload_vec(sc.slice_off, soff, m->stream));
     CCP_TRY(upload_vec(sc.slice_width, swidth, m->stream));
     CCP_TRY(upload_vec(sc.slice_row0, srow0, m->stream));
     CCP_TRY(upload_vec(sc.slice_rows, srows, m->stream));
-    CCP_TRY(upload_vec(sc.cols, cols, m->stream));
-    CCP_TRY(upload_vec(sc.vals, vals, m->stream));
+    if (total == 0) {
+        cols[0] = -1;
+        vals[0] = 0.0;
+    }
+    CCP_TRY(sc.cols.alloc(n_entries));
+    CCP_TRY(sc.vals.alloc(n_entries));
+    CCP_HIP(hipMemcpyAsync(sc.cols.p, cols.get(), n_entries * sizeof(int), hipMemcpyHostToDevice, m->stream));
+    CCP_HIP(hipMemcpyAsync(sc.vals.p, vals.get(), n_entries * sizeof(double), hipMemcpyHostToDevice, m->stream));
     CCP_TRY(upload_vec(sc.perm, perm, m->stream));
     CCP_TRY(upload_vec(sc.group_ptr_dev, sc.group_slice_ptr, m->stream));
     sc.max_group_slices = 0;
     for (int g = 0; g < n_groups; ++g)
         sc.max_group_slices = std::max(sc.max_group_slices, sc.group_slice_ptr[g + 1] - sc.group_slice_ptr[g]);
     CCP_HIP(hipStreamSynchronize(m->stream));      // host vectors die at scope exit
+    if (getenv("CCP_GS_DEBUG"))
+        fprintf(stderr, "[ccp_gs] schedule of %d slices: permutation %.3f s, slice table %.3f s, fill %.3f s, upload %.3f s\n",
+                sc.n_slices, t_perm - t_begin, t_fill0 - t_perm, t_fill1 - t_fill0, now_s() - t_fill1);
     sc.built = true;
     return CCP_OK;
 }
@@ -281,20 +343,33 @@ int ensure_natural(ccp_csr *m)
 int ensure_multicolour(ccp_csr *m)
 {
     if (m->multicolour.built) return CCP_OK;
-    std::vector<long> lptr;
-    std::vector<int> lidx;
-    build_lower(m, lptr, lidx);
+    const double t0 = now_s();
     std::vector<int> colour;
     int nc;
     if (!m->user_colour.empty()) {
         colour = m->user_colour;
         nc = m->user_n_colours;
-        for (int i = 0; i < m->n_rows; ++i)
-            for (long k = lptr[i]; k < lptr[i + 1]; ++k)
-                if (colour[lidx[k]] == colour[i]) return CCP_ERR_UNSUPPORTED;   // not a proper colouring
+        // a proper colouring: no stored off-diagonal entry couples two rows of one colour
+        std::atomic<int> bad{0};
+        const int n = m->n_rows;
+        parallel_ranges(n, 1 << 16, [&](long lo, long hi) {
+            for (long i = lo; i < hi && !bad.load(std::memory_order_relaxed); ++i)
+                for (long k = m->row_ptr[i]; k < m->row_ptr[i + 1]; ++k) {
+                    const int c = m->col[k];
+                    if (c != (int)i && c >= 0 && c < n && colour[c] == colour[i]) {
+                        bad.store(1, std::memory_order_relaxed);
+                        break;
+                    }
+                }
+        });
+        if (bad.load()) return CCP_ERR_UNSUPPORTED;
     } else {
+        std::vector<long> lptr;
+        std::vector<int> lidx;
+        build_lower(m, lptr, lidx);
         nc = greedy_colouring(lptr, lidx, m->n_rows, colour);
     }
+    if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] colouring (%d colours) in %.3f s\n", nc, now_s() - t0);
     return build_schedule(m, m->multicolour, colour, nc, true);
 }
 
