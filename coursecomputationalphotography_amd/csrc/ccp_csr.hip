@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <cstdint>
 #include <numeric>
 #include <vector>
 #include <memory>
@@ -26,8 +27,10 @@ struct Schedule {
     int n_slices = 0;
     DevBuf<long> slice_off;
     DevBuf<int> slice_width, slice_row0, slice_rows, cols, perm;
-    DevBuf<int> group_ptr_dev;           // group_slice_ptr on the device (one-workgroup solver)
+    DevBuf<int> group_ptr_dev;           // group_slice_ptr on the device (one-workgroup and pipelined solvers)
+    DevBuf<long> group_block_off_dev;
     int max_group_slices = 0;
+    int level_span = -1;                 // lexicographic: max level difference of two coupled rows (-1: not a level schedule)
     DevBuf<double> vals;
     void reset()
     {
@@ -36,8 +39,9 @@ struct Schedule {
         group_slice_ptr.clear();
         group_block_off.clear();
         slice_off.release(); slice_width.release(); slice_row0.release(); slice_rows.release();
-        cols.release(); perm.release(); vals.release(); group_ptr_dev.release();
+        cols.release(); perm.release(); vals.release(); group_ptr_dev.release(); group_block_off_dev.release();
         max_group_slices = 0;
+        level_span = -1;
     }
     SellView view() const
     {
@@ -62,6 +66,8 @@ struct ccp_csr {
     Schedule multicolour;    // colour-major, columns sorted by permuted index (reference on P A P^T)
     Schedule lexicographic;  // level-major, original storage order kept inside a row
     DevBuf<double> x, b, tmp, partial;
+    DevBuf<double> pipe_partial, pipe_eps, pipe_snap;   // pipelined level schedule: step sums per sweep, snapshot
+    bool allow_pipeline = true;            // CCP_GS_PIPELINE=0: one launch per level and sweep
     DevBuf<double> cg_p, cg_ap;            // conjugate-gradient work vectors (allocated on first use)
     DevBuf<CgState> cg_state;
     DevBuf<CsrSolveState> state;
@@ -169,6 +175,63 @@ int level_schedule(const std::vector<long> &lptr, const std::vector<int> &lidx, 
     return n_levels;
 }
 
+// A potential with phi(i) - phi(j) == 1 for EVERY coupled pair j < i, if one exists (5-point-like
+// stencils on any region: phi = x + y up to a constant per connected component).  Rows of equal phi
+// are uncoupled and ascending phi is a topological order of the sweep's dependences, so it is as
+// valid a schedule as the levels — and its span is 1, which is what lets the sweeps pipeline
+// (k_sell_gs_pipe) however irregular the region.  Levels alone can differ by hundreds across one
+// coupling on an irregular mask.  Returns the number of groups, 0 if no such potential exists.
+int unit_potential(const std::vector<long> &lptr, const std::vector<int> &lidx, int n, std::vector<int> &phi)
+{
+    // upper adjacency (j -> i > j) from the lower lists
+    std::vector<long> uptr((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i)
+        for (long k = lptr[i]; k < lptr[i + 1]; ++k) uptr[(size_t)lidx[k] + 1]++;
+    for (int i = 0; i < n; ++i) uptr[i + 1] += uptr[i];
+    std::vector<int> uidx((size_t)uptr[n]);
+    {
+        std::vector<long> fill(uptr.begin(), uptr.end() - 1);
+        for (int i = 0; i < n; ++i)
+            for (long k = lptr[i]; k < lptr[i + 1]; ++k) uidx[fill[lidx[k]]++] = i;
+    }
+    const int unset = INT32_MIN;
+    phi.assign(n, unset);
+    std::vector<int> queue;
+    queue.reserve(1024);
+    int max_phi = 0;
+    for (int root = 0; root < n; ++root) {
+        if (phi[root] != unset) continue;
+        // breadth-first over the component; potentials relative to the root, shifted to min 0 afterwards
+        queue.clear();
+        queue.push_back(root);
+        phi[root] = 0;
+        int lo = 0;
+        for (size_t q = 0; q < queue.size(); ++q) {
+            const int i = queue[q];
+            for (long k = lptr[i]; k < lptr[i + 1]; ++k) {
+                const int j = lidx[k];
+                if (phi[j] == unset) {
+                    phi[j] = phi[i] - 1;
+                    lo = std::min(lo, phi[j]);
+                    queue.push_back(j);
+                } else if (phi[j] != phi[i] - 1) return 0;
+            }
+            for (long k = uptr[i]; k < uptr[i + 1]; ++k) {
+                const int j = uidx[k];
+                if (phi[j] == unset) {
+                    phi[j] = phi[i] + 1;
+                    queue.push_back(j);
+                } else if (phi[j] != phi[i] + 1) return 0;
+            }
+        }
+        for (int i : queue) {
+            phi[i] -= lo;
+            max_phi = std::max(max_phi, phi[i]);
+        }
+    }
+    return n ? max_phi + 1 : 0;
+}
+
 template <typename T>
 int upload_vec(DevBuf<T> &d, const std::vector<T> &h, hipStream_t s)
 {
@@ -274,6 +337,7 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
     CCP_HIP(hipMemcpyAsync(sc.vals.p, vals.get(), n_entries * sizeof(double), hipMemcpyHostToDevice, m->stream));
     CCP_TRY(upload_vec(sc.perm, perm, m->stream));
     CCP_TRY(upload_vec(sc.group_ptr_dev, sc.group_slice_ptr, m->stream));
+    CCP_TRY(upload_vec(sc.group_block_off_dev, sc.group_block_off, m->stream));
     sc.max_group_slices = 0;
     for (int g = 0; g < n_groups; ++g)
         sc.max_group_slices = std::max(sc.max_group_slices, sc.group_slice_ptr[g + 1] - sc.group_slice_ptr[g]);
@@ -380,8 +444,18 @@ int ensure_lexicographic(ccp_csr *m)
     std::vector<int> lidx;
     build_lower(m, lptr, lidx);
     std::vector<int> level;
-    const int nl = level_schedule(lptr, lidx, m->n_rows, level);
-    return build_schedule(m, m->lexicographic, level, nl, false);
+    int nl = m->allow_pipeline ? unit_potential(lptr, lidx, m->n_rows, level) : 0;
+    int span = 1;
+    if (nl == 0) {
+        nl = level_schedule(lptr, lidx, m->n_rows, level);
+        span = 0;
+        for (int i = 0; i < m->n_rows; ++i)
+            for (long k = lptr[i]; k < lptr[i + 1]; ++k) span = std::max(span, level[i] - level[lidx[k]]);
+    }
+    CCP_TRY(build_schedule(m, m->lexicographic, level, nl, false));
+    m->lexicographic.level_span = span;
+    if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] level schedule: %d levels, span %d\n", nl, span);
+    return CCP_OK;
 }
 
 // partial-sum scratch large enough for `blocks` block results of two doubles each
@@ -466,6 +540,7 @@ int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values,
     m->grid = nullptr;
     if (const char *e = getenv("CCP_GS_STRUCTURED")) m->allow_structured = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_ONE_BLOCK")) m->allow_one_block = atoi(e) != 0;
+    if (const char *e = getenv("CCP_GS_PIPELINE")) m->allow_pipeline = atoi(e) != 0;
     const size_t vec = (size_t)std::max(std::max(n_rows, n_cols), 2);
     CCP_TRY(m->x.alloc(vec));
     CCP_TRY(m->b.alloc(vec));
@@ -573,6 +648,76 @@ int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *
                            m->b.p, m->state.p, epsilon, max_iteration, check_every);
         CCP_HIP(hipGetLastError());
         issued = max_iteration;
+        any_active = false;
+    }
+    if (any_active && ordering == CCP_ORDER_LEXICOGRAPHIC && m->allow_pipeline && sc.level_span >= 0 && sc.n_groups > 1) {
+        // level schedule pipelined over sweeps (k_sell_gs_pipe): n_levels + stride*K launches per batch
+        const int stride = sc.level_span + 1, n_levels = sc.n_groups;
+        unsigned max_blocks = 1;
+        for (int g = 0; g < n_levels; ++g)
+            max_blocks = std::max(max_blocks, (unsigned)(sc.group_block_off[g + 1] - sc.group_block_off[g]));
+        const long per_sweep = sc.group_block_off[n_levels];
+        auto run = [&](int sweeps, double *partial) -> int {
+            for (long tau = 0; tau <= (long)(n_levels - 1) + (long)stride * (sweeps - 1); ++tau) {
+                const long k_hi = std::min<long>(sweeps - 1, tau / stride);
+                const long k_lo = std::max<long>(0, (tau - (n_levels - 1) + stride - 1) / stride);
+                if (k_hi < k_lo) continue;
+                dim3 grid(max_blocks, (unsigned)(k_hi - k_lo + 1));
+                if (partial)
+                    hipLaunchKernelGGL((k_sell_gs_pipe<true>), grid, dim3(kBlock), 0, s, view, sc.group_ptr_dev.p,
+                                       sc.group_block_off_dev.p, (int)tau, stride, (int)k_lo, m->x.p, m->b.p, partial, per_sweep);
+                else
+                    hipLaunchKernelGGL((k_sell_gs_pipe<false>), grid, dim3(kBlock), 0, s, view, sc.group_ptr_dev.p,
+                                       sc.group_block_off_dev.p, (int)tau, stride, (int)k_lo, m->x.p, m->b.p,
+                                       static_cast<double *>(nullptr), per_sweep);
+            }
+            CCP_HIP(hipGetLastError());
+            return CCP_OK;
+        };
+        if (check_every == 0) {
+            while (issued < max_iteration) {               // gridDim.y carries the sweeps in flight: keep it small
+                const int kb = std::min(32768, max_iteration - issued);
+                CCP_TRY(run(kb, nullptr));
+                issued += kb;
+            }
+        } else {
+            const int batch_max = 128;
+            if (m->pipe_partial.n != (size_t)per_sweep * batch_max) CCP_TRY(m->pipe_partial.alloc((size_t)per_sweep * batch_max));
+            if (m->pipe_eps.n != (size_t)batch_max) CCP_TRY(m->pipe_eps.alloc(batch_max));
+            if (m->pipe_snap.n != (size_t)std::max<long>(n, 2)) CCP_TRY(m->pipe_snap.alloc((size_t)std::max<long>(n, 2)));
+            std::vector<double> eps_host(batch_max);
+            bool stopped = false;
+            while (!stopped && issued < max_iteration) {
+                const int kb = std::min(batch_max, max_iteration - issued);
+                CCP_HIP(hipMemcpyAsync(m->pipe_snap.p, m->x.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+                CCP_TRY(run(kb, m->pipe_partial.p));
+                hipLaunchKernelGGL(k_reduce_sweeps, dim3((unsigned)kb), dim3(kBlock), 0, s, m->pipe_partial.p, per_sweep, m->pipe_eps.p);
+                CCP_HIP(hipGetLastError());
+                CCP_HIP(hipMemcpyAsync(eps_host.data(), m->pipe_eps.p, sizeof(double) * kb, hipMemcpyDeviceToHost, s));
+                CCP_HIP(hipStreamSynchronize(s));
+                int stop = -1;
+                for (int k = 0; k < kb; ++k) {
+                    if ((issued + k + 1) % check_every != 0) continue;
+                    host.last_eps = eps_host[k];
+                    if (!(host.last_eps > epsilon)) {
+                        stop = k;
+                        break;
+                    }
+                }
+                if (stop >= 0) {
+                    stopped = true;
+                    host.converged = 1;
+                    host.iterations = issued + stop + 1;
+                    if (stop < kb - 1) {      // the pipeline ran past the stop sweep: redo exactly stop+1 sweeps from the snapshot
+                        CCP_HIP(hipMemcpyAsync(m->x.p, m->pipe_snap.p, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+                        CCP_TRY(run(stop + 1, nullptr));
+                    }
+                }
+                issued += kb;
+            }
+            host.active = stopped ? 0 : 1;
+            CCP_HIP(hipMemcpyAsync(m->state.p, &host, sizeof(host), hipMemcpyHostToDevice, s));
+        }
         any_active = false;
     }
     while (any_active && issued < max_iteration) {

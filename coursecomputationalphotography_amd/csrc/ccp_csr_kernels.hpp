@@ -72,6 +72,66 @@ k_sell_gs(SellView m, int s_first, int s_last, double *__restrict__ x, const dou
     }
 }
 
+// The level schedule, pipelined over sweeps.  Row i of level l in sweep k reads the NEW values of
+// its coupled rows j < i (lower levels, same sweep) and the OLD values of its coupled rows j > i
+// (higher levels, previous sweep).  With span = max over coupled pairs of the level difference and
+// stride = span + 1, every value row (l, k) needs was produced at a time tau' < tau = l + stride*k:
+// lower level same sweep trivially; level l' <= l + span of sweep k-1 at l' + stride*(k-1) < tau.
+// One launch per tau updates level tau - stride*k of every sweep k in flight: n_levels + stride*K
+// launches instead of n_levels*K, same iterates.  Levels in flight in one launch differ by multiples
+// of stride > span, so none of them is coupled to another: no hazard inside a launch.
+// grid = (blocks of the widest level, sweeps in flight); blockIdx.y -> k = k_lo + blockIdx.y.
+// L1: partial[k*partial_per_sweep + group_block_off[level] + blockIdx.x] (every slot written once per batch).
+template <bool L1>
+__global__ void __launch_bounds__(kBlock)
+k_sell_gs_pipe(SellView m, const int *__restrict__ group_slice_ptr, const long *__restrict__ group_block_off, int tau,
+               int stride, int k_lo, double *__restrict__ x, const double *__restrict__ b,
+               double *__restrict__ partial, long partial_per_sweep)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int k = k_lo + blockIdx.y;
+    const int level = tau - stride * k;
+    const int s_first = group_slice_ptr[level], s_last = group_slice_ptr[level + 1];
+    const int s = s_first + blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (s_first + (int)blockIdx.x * (kBlock / kWave) >= s_last) return;        // block beyond this level (uniform)
+    double acc = 0.0;
+    if (s < s_last && lane < m.slice_rows[s]) {
+        const int row = m.slice_row0[s] + lane;
+        const long off = m.slice_off[s] + lane;
+        const int width = m.slice_width[s];
+        double a_ii = 0.0;
+        double sigma = 0.0;
+        for (int q = 0; q < width; ++q) {
+            const int c = m.cols[off + (long)q * kWave];
+            const double v = m.vals[off + (long)q * kWave];
+            if (c == row) a_ii = v;
+            else if (c >= 0) sigma += v * x[c];
+        }
+        if (a_ii != 0.0) {
+            const double nv = (b[row] - sigma) / a_ii;
+            if (L1) acc = fabs(nv - x[row]);
+            x[row] = nv;
+        }
+    }
+    if (L1) {
+        const double t = block_sum(acc, scratch);
+        if (threadIdx.x == 0) partial[(long)k * partial_per_sweep + group_block_off[level] + blockIdx.x] = t;
+    }
+}
+
+// eps[k] = sum of the partials of sweep k in a fixed order.  grid = sweeps
+__global__ void __launch_bounds__(kBlock)
+k_reduce_sweeps(const double *__restrict__ partial, long per_sweep, double *__restrict__ eps)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const double *__restrict__ p = partial + (long)blockIdx.x * per_sweep;
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < per_sweep; i += kBlock) acc += p[i];
+    const double t = block_sum(acc, scratch);
+    if (threadIdx.x == 0) eps[blockIdx.x] = t;
+}
+
 // Whole solve in ONE workgroup: all groups (levels / colours) of all sweeps, __syncthreads()
 // between groups, stop rule evaluated in the kernel.  For schedules whose groups are narrow —
 // the level schedule of the lexicographic order has W+H-1 levels of <= min(W,H) rows on a grid —

@@ -168,3 +168,45 @@ def test_level_schedule_and_hyperplane_pipeline_agree(capi, monkeypatch):
         out.append(x)
         m.close()
     assert np.array_equal(out[0], out[1])
+
+
+@pytest.mark.parametrize("kind", ["mask", "random"])
+def test_pipelined_level_schedule_equals_launch_per_level(capi, orc, monkeypatch, kind):
+    """General matrices in the reference's order: sweeps pipelined over a unit-span potential (irregular
+    5-point mask) or over the levels with their span (random sparse matrix) against one launch per level
+    and sweep, and against the oracle; stop rule included."""
+    from coursecomputationalphotography_amd import synth
+    if kind == "mask":
+        mask = synth.disc_mask(300, 260, seed=7)
+        v, c, r, _, ys, _ = synth.masked_laplacian_csr(mask)
+        n = len(ys)
+    else:
+        rng = np.random.Generator(np.random.MT19937(3))
+        n = 4000
+        rows, cols, vals = [], [], []
+        for i in range(n):
+            nb = rng.choice(n, size=4, replace=False)
+            for j in nb:
+                if j != i:
+                    rows.append(i); cols.append(int(j)); vals.append(float(rng.uniform(-1, 1)))
+            rows.append(i); cols.append(i); vals.append(float(8.0 + rng.uniform(0, 1)))
+        order = np.lexsort((np.array(cols), np.array(rows)))
+        rr, cc, vv = np.array(rows)[order], np.array(cols)[order], np.array(vals)[order]
+        r = np.concatenate([[0], np.cumsum(np.bincount(rr, minlength=n))]).astype(np.int64)
+        v, c = vv, cc.astype(np.int32)
+    b = synth.x_true(n, 5) * 1e-6                    # with x0 = 0 the step sums stay far below the start value 10
+    x0 = np.zeros(n)
+    om = orc.from_csr(v, c, r)
+    epsilon = om.gauss_seidel(b, 0.0, 17, x0=x0)[2] * (1.0 + 1e-9)
+    want, it, _ = om.gauss_seidel(b, epsilon, 300, x0=x0)
+    want9, _, _ = om.gauss_seidel(b, 0.0, 9, x0=x0)
+    assert it == 17
+    for pipeline in ("1", "0"):
+        monkeypatch.setenv("CCP_GS_PIPELINE", pipeline)
+        m = capi.CsrMatrix()
+        m.upload_compressed(v, c, r)
+        x9, _ = m.gauss_seidel(b, 0.0, 9, x0=x0, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+        x, rep = m.gauss_seidel(b, epsilon, 300, x0=x0, check_every=1, ordering=capi.ORDER_LEXICOGRAPHIC)
+        m.close()
+        assert np.array_equal(x9, want9), (kind, pipeline)
+        assert rep.iterations == it and rep.converged == 1 and np.array_equal(x, want), (kind, pipeline)

@@ -1,23 +1,33 @@
 #!/usr/bin/env python3
-"""Exact (lexicographic, level-scheduled) Gauss-Seidel on the GPU vs the reference CPU sweep:
-BASELINE.json configs[0] (512x512) and larger."""
-import argparse, json, os, sys, time
+"""Reference-order (lexicographic) Gauss-Seidel through the GENERAL matrix entry point: level schedule
+pipelined over sweeps (k_sell_gs_pipe) on the photomontage-style irregular mask (not SolveChannel's
+matrix, so the structured path does not apply), against one launch per level and sweep."""
+import argparse, json, os, subprocess, sys
 sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
 import numpy as np
-from coursecomputationalphotography_amd import capi, synth
-import oracle
-ap = argparse.ArgumentParser(); ap.add_argument("--size", type=int, default=512); ap.add_argument("--iters", type=int, default=100)
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--canvas", type=int, default=2048)
+ap.add_argument("--iters", type=int, default=50)
+ap.add_argument("--child", default="")
 a = ap.parse_args()
-W = H = a.size
-v, c, r = synth.poisson_csr(W, H); b, _ = synth.poisson_system(W, H, 1234)
-m = capi.CsrMatrix().upload_compressed(v, c, r)
-m.gauss_seidel(b, 0.0, 2, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)      # builds the level schedule
-x, rep = m.gauss_seidel(b, 0.0, a.iters, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
-x1, rep1 = m.gauss_seidel(b, 0.0, a.iters, check_every=1, ordering=capi.ORDER_LEXICOGRAPHIC)
-out = {"size": a.size, "iters": a.iters, "gpu_lexicographic_updates_per_s": W * H * a.iters / rep.seconds,
-       "gpu_lexicographic_checked_updates_per_s": W * H * a.iters / rep1.seconds, "ms_per_iteration": rep.seconds / a.iters * 1e3}
-try:
-    ref = oracle.Ref(); secs = ref.gs_csr_timed(v, c, r, b, min(a.iters, 20)); out["cpu_reference_updates_per_s"] = W * H * min(a.iters, 20) / secs
-except Exception as e:
-    om = oracle.Oracle().from_csr(v, c, r); t0 = time.perf_counter(); want, _, _ = om.gauss_seidel(b, 0.0, min(a.iters, 20)); out["cpu_port_updates_per_s"] = W * H * min(a.iters, 20) / (time.perf_counter() - t0)
-print(json.dumps(out))
+if a.child:
+    from coursecomputationalphotography_amd import capi, synth
+    mask = synth.disc_mask(a.canvas, a.canvas, seed=4321)
+    v, c, r, colour, ys, xs = synth.masked_laplacian_csr(mask)
+    n = len(ys)
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    b = m.apply_to_vector(synth.x_true(n, 4321))
+    m.gauss_seidel(b, 0.0, 2, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+    x, rep = m.gauss_seidel(b, 0.0, a.iters, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+    x1, rep1 = m.gauss_seidel(b, 1e-300, a.iters, check_every=1, ordering=capi.ORDER_LEXICOGRAPHIC)
+    print(json.dumps({"mode": a.child, "canvas": a.canvas, "unknowns": n, "iters": a.iters,
+                      "fixed_count_updates_per_s": n * a.iters / rep.seconds,
+                      "stop_rule_every_sweep_updates_per_s": n * rep1.iterations / rep1.seconds,
+                      "checksum": float(np.abs(x).sum()), "same_result": bool(np.array_equal(x, x1))}))
+else:
+    for mode, env in (("pipelined", {}), ("one_launch_per_level", {"CCP_GS_PIPELINE": "0"})):
+        iters = a.iters if mode == "pipelined" else min(a.iters, 5)
+        out = subprocess.run([sys.executable, __file__, "--canvas", str(a.canvas), "--iters", str(iters), "--child", mode],
+                             env={**os.environ, **env}, capture_output=True, text=True)
+        print(out.stdout.strip() or out.stderr[-400:], flush=True)
