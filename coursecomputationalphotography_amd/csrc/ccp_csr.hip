@@ -516,14 +516,18 @@ int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values,
         const long nnz = m->row_ptr[n_rows];
         m->col.resize((size_t)nnz);
         m->val.resize((size_t)nnz);
-        for (int i = 0; i < n_rows; ++i) {
-            const long nz = row_num_nze[i];
-            if (!nz) continue;
-            std::memcpy(&m->col[m->row_ptr[i]], col_offset + row_begin[i], sizeof(int32_t) * (size_t)nz);
-            std::memcpy(&m->val[m->row_ptr[i]], values + row_begin[i], sizeof(double) * (size_t)nz);
-            for (long k = m->row_ptr[i]; k < m->row_ptr[i + 1]; ++k)
-                if (m->col[k] < 0 || m->col[k] >= n_cols) return CCP_ERR_BAD_ARG;
-        }
+        std::atomic<int> bad{0};
+        parallel_ranges(n_rows, 1 << 15, [&](long lo, long hi) {       // compaction of the live entries, by row ranges
+            for (long i = lo; i < hi; ++i) {
+                const long nz = row_num_nze[i];
+                if (!nz) continue;
+                std::memcpy(&m->col[m->row_ptr[i]], col_offset + row_begin[i], sizeof(int32_t) * (size_t)nz);
+                std::memcpy(&m->val[m->row_ptr[i]], values + row_begin[i], sizeof(double) * (size_t)nz);
+                for (long k = m->row_ptr[i]; k < m->row_ptr[i + 1]; ++k)
+                    if (m->col[k] < 0 || m->col[k] >= n_cols) bad.store(1, std::memory_order_relaxed);
+            }
+        });
+        if (bad.load()) return CCP_ERR_BAD_ARG;
     } catch (const std::bad_alloc &) {
         return CCP_ERR_ALLOC;
     }
