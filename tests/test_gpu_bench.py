@@ -31,6 +31,10 @@ def test_bench_contract_line_single_gpu():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["value"] > 1e10 and d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
     assert "workload" in d["config"]
+    assert d["roofline"]["frac"] > 0 and "traffic" in d["roofline"]
+    # the untimed reference-order run on the same system
+    ro = d["reference_order"]
+    assert ro["iterations"] == 128 and ro["pixel_updates_per_s"] > 1e8 and 0 < ro["rel_residual_after"] < 1.0
 
 
 def test_bench_two_ranks_on_one_card_matches_single():
