@@ -983,7 +983,11 @@ int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max
     if (check_every == 0 || !(10.0 > epsilon)) {
         // fixed count — or the reference loop never starts (eps = 10 <= epsilon)
         const int n = check_every == 0 ? max_iteration : 0;
-        if (n > 0) CCP_TRY(lex_run(g, n, all, nullptr));
+        for (int done = 0; done < n;) {                    // gridDim.y carries the sweeps in flight: keep it small
+            const int kb = std::min(32768, n - done);
+            CCP_TRY(lex_run(g, kb, all, nullptr));
+            done += kb;
+        }
         for (int ch = 0; ch < C; ++ch) iterations_of[ch] = n;
     } else {
         const int batch_max = 128;                                       // sweeps in flight between two looks at the rule
