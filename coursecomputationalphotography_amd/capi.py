@@ -24,7 +24,7 @@ ORDER_MULTICOLOUR = 1
 ABI_SYMBOLS = (
     "ccp_status_string", "ccp_abi_version", "ccp_device_count",
     "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_set_colouring",
-    "ccp_csr_gauss_seidel", "ccp_csr_conjugate_gradient", "ccp_csr_apply_to_vector", "ccp_csr_residual_norm2",
+    "ccp_csr_gauss_seidel", "ccp_csr_conjugate_gradient", "ccp_csr_conjugate_gradient_jacobi", "ccp_csr_apply_to_vector", "ccp_csr_residual_norm2",
     "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
     "ccp_grid_get_b_host", "ccp_grid_fill_x", "ccp_grid_b_from_x", "ccp_grid_randomize_x",
@@ -102,6 +102,7 @@ def load() -> C.CDLL:
     L.ccp_csr_set_colouring.argtypes = [vp, vp, i32]
     L.ccp_csr_gauss_seidel.argtypes = [vp, vp, vp, vp, dbl, i32, i32, i32, C.POINTER(Report)]
     L.ccp_csr_conjugate_gradient.argtypes = [vp, vp, vp, vp, dbl, i32, C.POINTER(Report)]
+    L.ccp_csr_conjugate_gradient_jacobi.argtypes = [vp, vp, vp, dbl, i32, C.POINTER(Report)]
     L.ccp_grid_conjugate_gradient.argtypes = [vp, dbl, i32, C.POINTER(Report)]
     L.ccp_csr_apply_to_vector.argtypes = [vp, vp, vp]
     L.ccp_csr_residual_norm2.argtypes = [vp, vp, vp, C.POINTER(dbl), C.POINTER(dbl)]
@@ -223,6 +224,15 @@ class CsrMatrix:
         rep = Report()
         check(self.L.ccp_csr_conjugate_gradient(self.h, _ptr(b), _ptr(ia), _ptr(x), epsilon, max_iteration,
                                                 C.byref(rep)), "ccp_csr_conjugate_gradient")
+        return x, rep
+
+    def conjugate_gradient_jacobi(self, b, epsilon=1e-16, max_iteration=180):
+        """SparseMatrix::conjugateGradientEigen: Jacobi-preconditioned, from x0 = 0."""
+        b = _f64(b)
+        x = np.empty(self.n_cols, dtype=np.float64)
+        rep = Report()
+        check(self.L.ccp_csr_conjugate_gradient_jacobi(self.h, _ptr(b), _ptr(x), epsilon, max_iteration, C.byref(rep)),
+              "ccp_csr_conjugate_gradient_jacobi")
         return x, rep
 
     def apply_to_vector(self, v):

@@ -187,4 +187,136 @@ int cg_solve(Spmv &&spmv, SpmvDot &&spmv_dot, const double *b, double *x, double
     return CCP_OK;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Jacobi-preconditioned variant: SparseMatrix::conjugateGradientEigen (sparse-matrix.h:494-535, used by
+// RunTest, utils.cc:99).  x0 = 0, invdiag = extractDiagnolColInv() (:472-491: 1/a_ii, 1 where the
+// diagonal is absent or 0):  p = r.*invdiag, dist = p'r;  per iteration alpha = dist / p'Ap,
+// x += alpha p, r -= alpha Ap, stop when sqrt(r'r) < epsilon, z = r.*invdiag, beta = z'r / dist,
+// p = z + beta p.  Same device-side scalar scheme as cg_solve; CgState::rlen carries `olddist`.
+
+// p := r .* inv (:503), partial sums of p'r (:508).  r holds b on entry (x0 = 0: r = b - A 0, :500-501).
+static __global__ void __launch_bounds__(kBlock)
+k_pcg_init(const double *__restrict__ r, const double *__restrict__ inv, double *__restrict__ p, long n,
+           double *__restrict__ partial)
+{
+    __shared__ double scratch[kBlock / kWave];
+    double acc = 0.0;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        const double v = r[i] * inv[i];
+        p[i] = v;
+        acc += v * r[i];
+    }
+    const double t = block_sum(acc, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// x += alpha p (:518); r += (-alpha) Ap (:519); partial sums of r'r (:520) and of (r.*inv)'r (:522-523)
+static __global__ void __launch_bounds__(kBlock)
+k_pcg_update(double *__restrict__ x, const double *__restrict__ p, double *__restrict__ r, const double *__restrict__ ap,
+             const double *__restrict__ inv, long n, double *__restrict__ partial_rr, double *__restrict__ partial_zr,
+             const CgState *__restrict__ st)
+{
+    __shared__ double scratch[kBlock / kWave];
+    double rr = 0.0, zr = 0.0;
+    if (st->active) {
+        const double alpha = st->alpha;
+        const double nalpha = -alpha;
+        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+            x[i] = x[i] + alpha * p[i];
+            const double v = r[i] + nalpha * ap[i];
+            r[i] = v;
+            rr += v * v;
+            const double z = v * inv[i];
+            zr += z * v;
+        }
+    }
+    const double t0 = block_sum(rr, scratch);
+    if (threadIdx.x == 0) partial_rr[blockIdx.x] = t0;
+    const double t1 = block_sum(zr, scratch);
+    if (threadIdx.x == 0) partial_zr[blockIdx.x] = t1;
+}
+
+// error = r'r; `if (sqrt(error) < epsilon) break;` (:520-521); beta = newdist / olddist (:524-525); ++cnt (:528)
+static __global__ void __launch_bounds__(kBlock)
+k_pcg_beta(const double *__restrict__ partial_rr, const double *__restrict__ partial_zr, int count, double epsilon,
+           CgState *__restrict__ st)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const double error = reduce_partials(partial_rr, count, scratch);
+    const double newdist = reduce_partials(partial_zr, count, scratch);
+    if (threadIdx.x == 0 && st->active) {
+        st->r1norm = sqrt(error);
+        if (st->r1norm < epsilon) {
+            st->active = 0;
+            st->converged = 1;
+        } else {
+            st->beta = newdist / st->rlen;
+            st->rlen = newdist;
+            st->iterations += 1;
+        }
+    }
+}
+
+// p := r .* inv + beta p (:522,526)
+static __global__ void __launch_bounds__(kBlock)
+k_pcg_direction(double *__restrict__ p, const double *__restrict__ r, const double *__restrict__ inv, long n,
+                const CgState *__restrict__ st)
+{
+    if (!st->active) return;
+    const double beta = st->beta;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock)
+        p[i] = r[i] * inv[i] + beta * p[i];
+}
+
+// x: zeroed by the caller; r: holds b on entry.  partial: 2 * 2048 doubles at least (beyond what spmv_dot uses).
+template <typename SpmvDot>
+int pcg_solve(SpmvDot &&spmv_dot, double *x, double *r, double *p, double *ap, const double *inv, long n, double epsilon,
+              int max_iteration, CgState *st_dev, double *partial, double *partial2, hipStream_t stream, hipEvent_t ev0,
+              hipEvent_t ev1, ccp_gs_report *report)
+{
+    const int blocks = (int)std::max<long>(1, std::min<long>(2048, (n + kBlock - 1) / kBlock));
+    CgState host{};
+    host.active = 1;
+    CCP_HIP(hipMemcpyAsync(st_dev, &host, sizeof(host), hipMemcpyHostToDevice, stream));
+    CCP_HIP(hipEventRecord(ev0, stream));
+    hipLaunchKernelGGL(k_pcg_init, dim3(blocks), dim3(kBlock), 0, stream, r, inv, p, n, partial);
+    hipLaunchKernelGGL(k_cg_set_rlen, dim3(1), dim3(kBlock), 0, stream, partial, blocks, st_dev);      // olddist = p'r
+    CCP_HIP(hipGetLastError());
+    int issued = 0;
+    bool active = max_iteration > 0 && n > 0;
+    while (active && issued < max_iteration) {
+        const int batch = std::min(16, max_iteration - issued);
+        for (int k = 0; k < batch; ++k) {
+            int dot_blocks = 0;
+            CCP_TRY(spmv_dot(p, ap, &dot_blocks));                            // Ap = A p (:516) [+ p'Ap partials]
+            if (dot_blocks == 0) {
+                hipLaunchKernelGGL(k_cg_dot, dim3(blocks), dim3(kBlock), 0, stream, p, ap, n, partial, st_dev);
+                dot_blocks = blocks;
+            }
+            hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kBlock), 0, stream, partial, dot_blocks, st_dev);   // olddist / p'Ap (:517)
+            hipLaunchKernelGGL(k_pcg_update, dim3(blocks), dim3(kBlock), 0, stream, x, p, r, ap, inv, n, partial2, partial2 + 2048,
+                               st_dev);
+            hipLaunchKernelGGL(k_pcg_beta, dim3(1), dim3(kBlock), 0, stream, partial2, partial2 + 2048, blocks, epsilon, st_dev);
+            hipLaunchKernelGGL(k_pcg_direction, dim3(blocks), dim3(kBlock), 0, stream, p, r, inv, n, st_dev);
+        }
+        CCP_HIP(hipGetLastError());
+        issued += batch;
+        CCP_HIP(hipMemcpyAsync(&host, st_dev, sizeof(host), hipMemcpyDeviceToHost, stream));
+        CCP_HIP(hipStreamSynchronize(stream));
+        active = host.active != 0;
+    }
+    CCP_HIP(hipEventRecord(ev1, stream));
+    CCP_HIP(hipMemcpyAsync(&host, st_dev, sizeof(host), hipMemcpyDeviceToHost, stream));
+    CCP_HIP(hipStreamSynchronize(stream));
+    if (report) {
+        float ms = 0.f;
+        CCP_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        report->iterations = host.iterations;
+        report->converged = host.converged;
+        report->last_l1_step = host.r1norm;
+        report->seconds = ms * 1e-3;
+    }
+    return CCP_OK;
+}
+
 }  // namespace ccp

@@ -69,6 +69,7 @@ struct ccp_csr {
     DevBuf<double> pipe_partial, pipe_eps, pipe_snap;   // pipelined level schedule: step sums per sweep, snapshot
     bool allow_pipeline = true;            // CCP_GS_PIPELINE=0: one launch per level and sweep
     DevBuf<double> cg_p, cg_ap;            // conjugate-gradient work vectors (allocated on first use)
+    DevBuf<double> cg_inv, cg_partial2;    // Jacobi-preconditioned variant: 1/a_ii, second pair of partial-sum regions
     DevBuf<CgState> cg_state;
     DevBuf<CsrSolveState> state;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -814,6 +815,57 @@ int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, 
                      m->partial.p, s, m->ev0, m->ev1, report));
     if (n) CCP_HIP(hipMemcpyAsync(x_out, m->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
     CCP_HIP(hipStreamSynchronize(s));
+    return CCP_OK;
+}
+
+int ccp_csr_conjugate_gradient_jacobi(ccp_csr *m, const double *b, double *x_out, double epsilon, int32_t max_iteration,
+                                      ccp_gs_report *report)
+{
+    CCP_TRY(bind(m));
+    if (!m->uploaded) return CCP_ERR_STATE;
+    if (!b || !x_out) return CCP_ERR_BAD_ARG;
+    if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;
+    CCP_TRY(ensure_natural(m));
+    const long n = m->n_rows;
+    hipStream_t s = m->stream;
+    if (!m->cg_p.p || m->cg_p.n < (size_t)std::max<long>(n, 2)) {
+        CCP_TRY(m->cg_p.alloc((size_t)std::max<long>(n, 2)));
+        CCP_TRY(m->cg_ap.alloc((size_t)std::max<long>(n, 2)));
+        CCP_TRY(m->cg_state.alloc(1));
+    }
+    if (!m->cg_state.p) CCP_TRY(m->cg_state.alloc(1));
+    const unsigned spmv_blocks = (unsigned)((m->natural.n_slices + kBlock / kWave - 1) / (kBlock / kWave));
+    CCP_TRY(ensure_partial(m, std::max<long>(2048, spmv_blocks)));
+    if (m->cg_partial2.n != 4096) CCP_TRY(m->cg_partial2.alloc(4096));
+    // extractDiagnolColInv (sparse-matrix.h:472-491): 1/a_ii of the first stored diagonal entry, 1 if absent or 0
+    std::vector<double> inv((size_t)std::max<long>(n, 1), 1.0);
+    parallel_ranges(n, 1 << 16, [&](long lo, long hi) {
+        for (long i = lo; i < hi; ++i)
+            for (long k = m->row_ptr[i]; k < m->row_ptr[i + 1]; ++k)
+                if (m->col[k] == (int)i) {
+                    if (m->val[k] != 0.0) inv[(size_t)i] = 1.0 / m->val[k];
+                    break;
+                }
+    });
+    if (m->cg_inv.n != inv.size()) CCP_TRY(m->cg_inv.alloc(inv.size()));
+    if (n) {
+        CCP_HIP(hipMemcpyAsync(m->cg_inv.p, inv.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
+        CCP_HIP(hipMemcpyAsync(m->tmp.p, b, sizeof(double) * n, hipMemcpyHostToDevice, s));     // r = b - A 0 = b (:500-501)
+        CCP_HIP(hipMemsetAsync(m->x.p, 0, sizeof(double) * n, s));                               // :495
+    }
+    const SellView view = m->natural.view();
+    const int n_slices = m->natural.n_slices;
+    auto spmv_dot = [&](const double *in, double *out, int *n_partials) -> int {
+        *n_partials = 0;
+        if (n_slices == 0) return CCP_OK;
+        hipLaunchKernelGGL((k_sell_apply<2>), dim3(spmv_blocks), dim3(kBlock), 0, s, view, n_slices, in, out, in, m->partial.p);
+        *n_partials = (int)spmv_blocks;
+        return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
+    };
+    CCP_TRY(pcg_solve(spmv_dot, m->x.p, m->tmp.p, m->cg_p.p, m->cg_ap.p, m->cg_inv.p, n, epsilon, max_iteration, m->cg_state.p,
+                      m->partial.p, m->cg_partial2.p, s, m->ev0, m->ev1, report));
+    if (n) CCP_HIP(hipMemcpyAsync(x_out, m->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+    CCP_HIP(hipStreamSynchronize(s));        // `inv` lives on this stack frame
     return CCP_OK;
 }
 

@@ -19,7 +19,7 @@
 //     (explicit zeros and removed entries become free slots), different code.
 //
 // conjugateGradient (the solver the blend call sites use today) is provided too; its iterates
-// match the reference to rounding (tree-ordered reductions).  conjugateGradientEigen / Paper are not.
+// match the reference to rounding (tree-ordered reductions); so is conjugateGradientEigen.  conjugateGradientPaper is not.
 #pragma once
 
 #include <algorithm>
@@ -310,6 +310,18 @@ public:
         ccp::throw_on(ccp_csr_conjugate_gradient(dev_, b.data(), initialize.empty() ? nullptr : initialize.data(), x.data(),
                                                  epsilon, max_iteration, &rep),
                       "ccp_csr_conjugate_gradient");
+        last_report_ = rep;
+        return x;
+    }
+
+    // Reference: sparse-matrix.h:494-535 (Jacobi-preconditioned, x0 = 0; RunTest, utils.cc:99).
+    std::vector<double> conjugateGradientEigen(const std::vector<double> &b, double epsilon = 1e-16, int max_iteration = 180)
+    {
+        sync_device();
+        std::vector<double> x(b.size(), 0.0);
+        ccp_gs_report rep{};
+        ccp::throw_on(ccp_csr_conjugate_gradient_jacobi(dev_, b.data(), x.data(), epsilon, max_iteration, &rep),
+                      "ccp_csr_conjugate_gradient_jacobi");
         last_report_ = rep;
         return x;
     }

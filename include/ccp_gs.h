@@ -108,6 +108,12 @@ int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *
 int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, double *x_out,
                                double epsilon, int32_t max_iteration, ccp_gs_report *report);
 
+/* SparseMatrix::conjugateGradientEigen(b, epsilon, max_iteration) (sparse-matrix.h:494-535; RunTest,
+ * utils.cc:99): Jacobi-preconditioned conjugate gradient from x0 = 0 with extractDiagnolColInv()
+ * (:472-491) as the preconditioner.  report as for ccp_csr_conjugate_gradient. */
+int ccp_csr_conjugate_gradient_jacobi(ccp_csr *m, const double *b, double *x_out, double epsilon,
+                                      int32_t max_iteration, ccp_gs_report *report);
+
 /* SparseMatrix::applyToVector(in, out) (sparse-matrix.h:382-393). in: n_cols, out: n_rows. */
 int ccp_csr_apply_to_vector(ccp_csr *m, const double *in, double *out);
 

@@ -121,6 +121,15 @@ class OracleMatrix:
             raise MemoryError("orc_conjugate_gradient failed")
         return x, it.value
 
+    def conjugate_gradient_jacobi(self, b, epsilon: float = 1e-16, max_iteration: int = 180):
+        b = _f64(b)
+        x = np.empty(self.n_cols, dtype=np.float64)
+        it = C.c_int(0)
+        rc = self._lib.orc_conjugate_gradient_jacobi(C.byref(self._m), b, epsilon, max_iteration, x, C.byref(it))
+        if rc != 0:
+            raise MemoryError("orc_conjugate_gradient_jacobi failed")
+        return x, it.value
+
     def apply_to_vector(self, v) -> np.ndarray:
         v = _f64(v)
         out = np.zeros(self.n_rows, dtype=np.float64)
@@ -147,6 +156,8 @@ class Oracle:
         L.orc_gauss_seidel.argtypes = [MP, _f64p, C.c_void_p, C.c_double, C.c_int, _f64p,
                                        C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.orc_conjugate_gradient.argtypes = [MP, _f64p, C.c_void_p, C.c_double, C.c_int, _f64p, C.POINTER(C.c_int)]
+        L.orc_conjugate_gradient_jacobi.argtypes = [MP, _f64p, C.c_double, C.c_int, _f64p, C.POINTER(C.c_int)]
+        L.orc_conjugate_gradient_jacobi.restype = C.c_int
         L.orc_apply_to_vector.argtypes = [MP, _f64p, _f64p]
         L.orc_apply_to_vector.restype = None
         L.orc_rel_residual.argtypes = [MP, _f64p, _f64p]
@@ -316,6 +327,7 @@ class Ref:
         P.ref_spmv_eigen.argtypes = eig + [_f64p, _f64p]
         P.ref_dense_eigen.argtypes = eig + [_f64p, _i32p]
         P.ref_cg_eigen.argtypes = eig + [_f64p, C.c_double, C.c_int, C.c_void_p, _f64p]
+        P.ref_cg_jacobi.argtypes = eig + [_f64p, C.c_double, C.c_int, _f64p]
         P.ref_vector_insert_scenario.argtypes = [_i32p, _i32p, _f64p, C.c_int, _i32p, _i32p, _f64p,
                                                  C.c_int, C.c_int, C.c_int, _f64p]
         P.ref_gs_vector.argtypes = [_i32p, _i32p, _f64p, C.c_int, _f64p, C.c_int, C.c_double,
@@ -371,6 +383,13 @@ class Ref:
         x = np.empty(n, dtype=np.float64)
         ia = None if init is None else _f64(init)
         self.P.ref_cg_eigen(*args, _f64(b), epsilon, max_iteration, _opt(ia), x)
+        return x
+
+    def cg_jacobi_csr(self, values, col_offset, row_offset, b, epsilon=1e-16, max_iteration=180):
+        n = len(row_offset) - 1
+        args, keep = self._eig(values, col_offset, row_offset, n, n, None)
+        x = np.empty(n, dtype=np.float64)
+        self.P.ref_cg_jacobi(*args, _f64(b), epsilon, max_iteration, x)
         return x
 
     def vector_insert_scenario(self, rows, cols, vals, ops, n_rows, n_cols):

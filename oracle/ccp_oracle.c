@@ -260,6 +260,49 @@ int orc_conjugate_gradient(const orc_matrix *m, const double *b, const double *i
     return 0;
 }
 
+/* sparse-matrix.h:494-535 (conjugateGradientEigen) with extractDiagnolColInv (:472-491) */
+int orc_conjugate_gradient_jacobi(const orc_matrix *m, const double *b, double epsilon, int max_iteration,
+                                  double *x, int *iters_done)
+{
+    const int64_t n = m->n_cols;
+    const size_t bytes = sizeof(double) * (size_t)(n ? n : 1);
+    double *r = (double *)malloc(bytes), *z = (double *)malloc(bytes), *p = (double *)malloc(bytes);
+    double *ap = (double *)malloc(bytes), *inv = (double *)malloc(bytes);
+    if (!r || !z || !p || !ap || !inv) { free(r); free(z); free(p); free(ap); free(inv); return -1; }
+    for (int64_t i = 0; i < n; ++i) inv[i] = 1.0;                       /* :474 res(cols(), T(1)) */
+    for (int32_t i = 0; i < m->n_rows; ++i) {                           /* :476-489 */
+        int32_t idx = m->row_begin[i];
+        for (int32_t j = 0; j < m->row_num_nze[i]; ++j, ++idx)
+            if (m->col_offset[idx] == i) {
+                if (m->values[idx] != 0.0) inv[i] = 1.0 / m->values[idx];
+                break;
+            }
+    }
+    for (int64_t i = 0; i < n; ++i) x[i] = 0.0;                         /* :495 */
+    orc_apply_to_vector(m, x, r);                                       /* :500 */
+    orc_vecsub(b, r, r, n);                                             /* :501 */
+    for (int64_t i = 0; i < n; ++i) p[i] = r[i] * inv[i];               /* :503 vecmul */
+    double olddist = orc_dot_prod(p, r, n);                             /* :508 */
+    int cnt = 0;
+    while (cnt < max_iteration) {
+        orc_apply_to_vector(m, p, ap);                                  /* :516 */
+        const double alpha = olddist / orc_dot_prod(p, ap, n);          /* :517 */
+        orc_vecadd_scaled(x, p, alpha, x, n);                           /* :518 */
+        orc_vecadd_scaled(r, ap, -alpha, r, n);                         /* :519 */
+        const double error = orc_veclen2(r, n);                         /* :520 */
+        if (sqrt(error) < epsilon) break;                               /* :521 */
+        for (int64_t i = 0; i < n; ++i) z[i] = r[i] * inv[i];           /* :522 */
+        const double newdist = orc_dot_prod(z, r, n);                   /* :523 */
+        const double beta = newdist / olddist;                          /* :524 */
+        olddist = newdist;                                              /* :525 */
+        orc_vecadd_scaled(z, p, beta, p, n);                            /* :526 */
+        ++cnt;                                                          /* :528 */
+    }
+    free(r); free(z); free(p); free(ap); free(inv);
+    if (iters_done) *iters_done = cnt;
+    return 0;
+}
+
 double orc_rel_residual(const orc_matrix *m, const double *b, const double *x)
 {
     const int64_t n = m->n_rows;

@@ -69,6 +69,11 @@ int orc_gauss_seidel(const orc_matrix *m, const double *b, const double *x0,
 int orc_conjugate_gradient(const orc_matrix *m, const double *b, const double *init,
                            double epsilon, int max_iteration, double *x, int *iters_done);
 
+/* sparse-matrix.h:494-535 (conjugateGradientEigen: Jacobi-preconditioned, x0 = 0; used by RunTest,
+ * utils.cc:99) with extractDiagnolColInv (:472-491). */
+int orc_conjugate_gradient_jacobi(const orc_matrix *m, const double *b, double epsilon, int max_iteration,
+                                  double *x, int *iters_done);
+
 /* sparse-matrix.h:382-393 (applyToVector). */
 void orc_apply_to_vector(const orc_matrix *m, const double *in, double *out);
 

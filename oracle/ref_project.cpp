@@ -119,6 +119,18 @@ int ref_cg_eigen(const double *values, int n_values, const int *row_offset, int 
     return (int)x.size();
 }
 
+// conjugateGradientEigen (sparse-matrix.h:494-535), the Jacobi-preconditioned variant RunTest uses
+int ref_cg_jacobi(const double *values, int n_values, const int *row_offset, int n_rows,
+                  const int *col_offset, int n_cols, const int *non_zeros,
+                  const double *b, double epsilon, int max_iteration, double *x_out)
+{
+    Mat m = make_eigen(values, n_values, row_offset, n_rows, col_offset, n_cols, non_zeros);
+    std::vector<double> bv(b, b + n_cols);
+    std::vector<double> x = m.conjugateGradientEigen(bv, epsilon, max_iteration);
+    std::memcpy(x_out, x.data(), sizeof(double) * x.size());
+    return (int)x.size();
+}
+
 double ref_manhatton_dist(const double *a, const double *b, int n)
 {
     std::vector<double> av(a, a + n), bv(b, b + n);

@@ -238,12 +238,32 @@ def gen_cg(R):
     save("cg_17x13.npz", **arrays)
 
 
+def gen_cg_jacobi(R):
+    """conjugateGradientEigen (Jacobi-preconditioned, x0 = 0, sparse-matrix.h:494-535) on Poisson 17x13
+    and on the irregular mask matrix."""
+    W, H = 17, 13
+    v, c, r = synth.poisson_csr(W, H)
+    b, xt = synth.poisson_system(W, H, 1234)
+    arrays = dict(W=np.int32(W), H=np.int32(H), b=b, x_true=xt)
+    for k in (1, 5, 25, 180):
+        arrays[f"x_k{k}"] = R.cg_jacobi_csr(v, c, r, b, 1e-16, k)
+    mask = synth.disc_mask(61, 47, seed=11)
+    mv, mc, mr, _, ys, _ = synth.masked_laplacian_csr(mask)
+    mb = synth.csr_apply(mv, mc, mr, synth.x_true(len(ys), 3))
+    arrays.update(mask_b=mb, mask_x_k40=R.cg_jacobi_csr(mv, mc, mr, mb, 1e-16, 40),
+                  mask_x_converged=R.cg_jacobi_csr(mv, mc, mr, mb, 1e-9, 5000))
+    save("cg_jacobi_17x13.npz", **arrays)
+
+
 def main():
     oracle.build()
     R = oracle.Ref()
     O = oracle.Oracle()
     if len(sys.argv) > 1 and sys.argv[1] == "cg":
         gen_cg(R)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "cg_jacobi":
+        gen_cg_jacobi(R)
         return
     gen_known_answer(R)
     gen_insert_scenario(R)
@@ -253,6 +273,7 @@ def main():
     gen_slack_ingest(R)
     gen_assembly(O)
     gen_cg(R)
+    gen_cg_jacobi(R)
 
 
 if __name__ == "__main__":

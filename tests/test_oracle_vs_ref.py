@@ -72,3 +72,24 @@ def test_cg_reference_available(ref):
     b, xt = synth.poisson_system(6, 5, 2)
     x = ref.cg_csr(v, c, r, b, 1e-12, 200)
     assert np.allclose(x[:-1], xt[:-1], atol=1e-6)
+
+
+def test_cg_jacobi_oracle_equals_reference(ref, orc):
+    """conjugateGradientEigen (sparse-matrix.h:494-535) from the compiled reference against the oracle's
+    restatement on a seeded diagonally dominant system, bit for bit."""
+    g = np.random.Generator(np.random.MT19937(21))
+    n = 300
+    rows, cols, vals = [], [], []
+    for i in range(n):
+        for j in sorted(set(int(v) for v in g.choice(n, size=5, replace=False)) | {i}):
+            rows.append(i); cols.append(j)
+            vals.append(float(9.0 + g.uniform(0, 1)) if j == i else float(g.uniform(-1, 1)))
+    r = np.concatenate([[0], np.cumsum(np.bincount(np.array(rows), minlength=n))]).astype(np.int32)
+    v, c = np.array(vals), np.array(cols, dtype=np.int32)
+    # symmetrise values so CG is well defined: A := (A + A^T)/2 on the union pattern is overkill here —
+    # the comparison is of two implementations of the same recurrence, any matrix will do
+    b = g.uniform(-3, 3, n)
+    for k in (1, 7, 60):
+        want = ref.cg_jacobi_csr(v, c, r, b, 1e-16, k)
+        x, it = orc.from_csr(v, c, r).conjugate_gradient_jacobi(b, 1e-16, k)
+        assert np.array_equal(x, want)
