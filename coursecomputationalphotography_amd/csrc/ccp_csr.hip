@@ -782,6 +782,24 @@ int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, 
     if (!m->uploaded) return CCP_ERR_STATE;
     if (!b || !x_out) return CCP_ERR_BAD_ARG;
     if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;
+    if (m->allow_structured) {
+        // SolveChannel's matrix at the unchanged call site (PhotoMontage.cpp:613): matrix-free SpMV of the
+        // grid path (16 B per pixel instead of ~92 B per row of the sliced-ELL image); same row order in
+        // the products, reductions tree-ordered either way
+        detect_poisson(m);
+        if (m->poisson_w > 1 && m->poisson_h > 1) {
+            if (!m->grid) {
+                ccp_grid_desc d{m->poisson_w, m->poisson_h, 1, 0, m->poisson_h, 0, m->device, 0};
+                CCP_TRY(ccp_grid_create(&d, &m->grid));
+            }
+            CCP_TRY(ccp_grid_set_stream(m->grid, m->stream));
+            CCP_TRY(ccp_grid_set_b_host(m->grid, 0, b, 0, m->poisson_h));
+            if (init) CCP_TRY(ccp_grid_set_x_host(m->grid, 0, init, 0, m->poisson_h));
+            else CCP_TRY(ccp_grid_fill_x(m->grid, 0.0));                       // sparse-matrix.h:397
+            CCP_TRY(ccp_grid_conjugate_gradient(m->grid, epsilon, max_iteration, report));
+            return ccp_grid_get_x_host(m->grid, 0, x_out, 0, m->poisson_h);
+        }
+    }
     CCP_TRY(ensure_natural(m));
     const long n = m->n_rows;
     hipStream_t s = m->stream;
