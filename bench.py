@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--reference-order-iters", type=int, default=128)
     ap.add_argument("--converge-cap", type=int, default=6000)
     ap.add_argument("--cpu-sample", type=int, default=4096, help="edge of the CPU baseline sample grid")
-    ap.add_argument("--cpu-iters", type=int, default=24)
+    ap.add_argument("--cpu-iters", type=int, default=96, help="CPU baseline sweeps (about 15 s of host time at the default sample)")
     return ap.parse_args()
 
 
