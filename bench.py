@@ -181,6 +181,10 @@ def main():
                 "traffic_gbs": (traffic / avg_launch_s / 1e9) if (traffic and launches) else None,
                 "traffic_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and launches) else None,
                 "kernel": "k_fused_sweep (+ k_fused_border on a second stream, same pass)" if fused else "k_half_sweep",
+                # what streaming kernels reach on this pool (tools/hbm_calib.hip, profiles/r01_hbm_calib.txt): the
+                # practical ceiling for a pass that reads twice what it writes is the last figure, not 8 TB/s
+                "measured_stream_ceilings_gbs": {"read": 6400, "write": 4700, "copy": 4800, "two_reads_one_write": 5400,
+                                                 "source": "profiles/r01_hbm_calib.txt"},
                 "iterations_per_launch": iters_timed / max(launches, 1),
                 "avg_launch_ms": avg_launch_s * 1e3,
                 "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * updates_per_launch}
