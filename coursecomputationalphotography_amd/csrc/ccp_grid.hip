@@ -351,6 +351,16 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool
     // cost: measured per-depth launch times when the handle was tuned, otherwise "fewer, deeper
     // launches are cheaper".  f[i][p]: best cost for i iterations with launch-count parity p.
     const int tmax = g->fuse_tmax;
+    // depth-1 passes only (a handle tuned for one iteration per exchange, CCP_GS_TMAX=1) cannot cover an odd
+    // count in an even number of launches: the odd iteration goes through the in-place kernels
+    if (tmax == 1 && (iterations & 1)) {
+        if (l1_last) return CCP_ERR_STATE;
+        CCP_TRY(run_unchecked(g, iterations - 1, active, false, nullptr, 0));
+        CCP_TRY(one_iteration(g, false, active, nullptr));
+        if (edge_rows > 0)
+            for (int i = 0; i < 2; ++i) CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream));
+        return CCP_OK;
+    }
     auto cost = [&](int T) -> double { return g->tuned && g->tune_ms[T] > 0 ? (double)g->tune_ms[T] : 1.0 + 0.01 * T; };
     const double inf = 1e300;
     std::vector<double> f((size_t)(iterations + 1) * 2, inf);

@@ -134,6 +134,33 @@ def test_config1_size_red_black_against_oracle(capi, orc):
     g.close()
 
 
+@pytest.mark.parametrize("iters", [1, 2, 3, 7, 16, 21])
+def test_depth_one_passes_cover_any_count(capi, monkeypatch, iters):
+    """A handle limited to depth-1 passes (tuned for one iteration per halo exchange, or CCP_GS_TMAX=1) must
+    still run odd counts: an even number of launches plus the in-place kernels for the odd iteration."""
+    W, H = 700, 500
+    rng = np.random.Generator(np.random.MT19937(4))
+    b = rng.uniform(-3.0, 3.0, (H, W))
+    out = []
+    for tmax in ("1", "8"):
+        monkeypatch.setenv("CCP_GS_TMAX", tmax)
+        g = capi.Grid(W, H, 1)
+        g.set_b(b)
+        g.fill_x(1.0)
+        g.sweep(iters)
+        out.append(g.get_x().copy())
+        g.close()
+    assert np.array_equal(out[0], out[1])
+    monkeypatch.delenv("CCP_GS_TMAX")
+    g = capi.Grid(W, H, 1)                     # the same through the tuner (what bench.py does with a thin ghost zone)
+    g.set_b(b)
+    g.fill_x(1.0)
+    g.tune(1)
+    g.sweep(iters)
+    assert np.array_equal(g.get_x(), out[1])
+    g.close()
+
+
 def test_three_channel_4096_fused_equals_in_place(capi, monkeypatch):
     """configs[1]: 4096x4096 three-channel blend."""
     W = H = 4096

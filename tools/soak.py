@@ -1,0 +1,124 @@
+#!/usr/bin/env python3
+"""Randomised parity soak (GPU): the temporally blocked pass against the in-place kernels on random shapes,
+iteration counts, tilings and channel counts, every pixel; the reference-order sweep against the oracle on
+small random shapes; row-blocked runs against the single block.  Prints one line per failure, exit 1 if any."""
+import os
+import sys
+import threading
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from coursecomputationalphotography_amd import capi, rowblock, synth  # noqa: E402
+
+
+def run_grid(W, H, C, b, x0, iters, env):
+    for k in ("CCP_GS_FUSE", "CCP_GS_CHUNK", "CCP_GS_TMAX", "CCP_GS_SIDE_ROWS", "CCP_GS_SHORT_EDGES"):
+        os.environ.pop(k, None)
+    os.environ.update(env)
+    g = capi.Grid(W, H, C)
+    for ch in range(C):
+        g.set_b(b[ch], ch)
+        g.set_x(x0[ch], ch)
+    g.sweep(iters)
+    out = np.stack([g.get_x(ch) for ch in range(C)])
+    g.close()
+    return out
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.Generator(np.random.MT19937(int(sys.argv[2]) if len(sys.argv) > 2 else 2024))
+    bad = 0
+    for t in range(n):
+        W = int(rng.integers(2, 3000)) if rng.random() < 0.8 else int(rng.integers(3000, 9000))
+        H = int(rng.integers(2, 2000))
+        C = int(rng.choice([1, 1, 3]))
+        iters = int(rng.integers(1, 40))
+        env = {}
+        if rng.random() < 0.5:
+            env["CCP_GS_CHUNK"] = str(int(rng.integers(8, 400)))
+        if rng.random() < 0.3:
+            env["CCP_GS_TMAX"] = str(int(rng.integers(1, 9)))
+        if rng.random() < 0.2:
+            env["CCP_GS_SIDE_ROWS"] = str(int(rng.integers(2, 64)))
+        b = rng.uniform(-3, 3, (C, H, W))
+        x0 = rng.uniform(0, 255, (C, H, W))
+        try:
+            a = run_grid(W, H, C, b, x0, iters, {**env, "CCP_GS_FUSE": "1"})
+            r = run_grid(W, H, C, b, x0, iters, {"CCP_GS_FUSE": "0"})
+        except Exception as e:
+            bad += 1
+            print("ERROR fused/in-place", W, H, C, iters, env, repr(e), flush=True)
+            continue
+        if not np.array_equal(a, r):
+            bad += 1
+            print("MISMATCH fused/in-place", W, H, C, iters, env, float(np.abs(a - r).max()), flush=True)
+    # reference order against the oracle
+    import oracle
+    orc = oracle.Oracle()
+    for t in range(max(4, n // 4)):
+        W, H, iters = int(rng.integers(1, 700)), int(rng.integers(1, 500)), int(rng.integers(1, 12))
+        if W * H < 2:
+            continue
+        b, _ = synth.poisson_system(W, H, int(rng.integers(1, 1000)))
+        want, _, _ = orc.from_csr(*synth.poisson_csr(W, H)).gauss_seidel(b, 0.0, iters)
+        g = capi.Grid(W, H, 1)
+        g.set_b(b)
+        g.fill_x(1.0)
+        g.gauss_seidel_lexicographic(0.0, iters, 0)
+        got = g.get_x().ravel()
+        g.close()
+        if not np.array_equal(got, want):
+            bad += 1
+            print("MISMATCH reference order", W, H, iters, float(np.abs(got - want).max()), flush=True)
+    # row blocks against the single block
+    from test_gpu_fullsize import ThreadDist
+    for t in range(max(3, n // 8)):
+        W, world = int(rng.integers(100, 3000)), int(rng.integers(2, 5))
+        ghost = 2 * int(rng.integers(1, 12))
+        H = int(rng.integers(world * (ghost + 2), world * (ghost + 2) + 600))
+        iters = int(rng.integers(1, 50))
+        for k in ("CCP_GS_FUSE", "CCP_GS_CHUNK", "CCP_GS_TMAX", "CCP_GS_SIDE_ROWS"):
+            os.environ.pop(k, None)
+        whole = capi.Grid(W, H, 1)
+        whole.randomize_x(7, 0.0, 255.0)
+        whole.b_from_x()
+        whole.fill_x(1.0)
+        whole.sweep(iters)
+        want = whole.get_x()
+        whole.close()
+        parts = rowblock.partition_rows(H, world)
+        dist = ThreadDist(world)
+        out, errs = [None] * world, []
+        overlap = bool(rng.random() < 0.5)
+
+        def run(rank):
+            try:
+                dist.bind(rank)
+                rb, rc = parts[rank]
+                blk = rowblock.GridBlock(W, H, 1, rb, rc, ghost, 0)
+                blk.grid.randomize_x(7, 0.0, 255.0)
+                blk.grid.b_from_x()
+                blk.grid.fill_x(1.0)
+                solver = rowblock.RowBlockSolver(blk, rank, world, ghost, dist, overlap=overlap).set_partition(parts, H)
+                solver.exchange_halos()
+                solver.sweep(iters)
+                out[rank] = blk.grid.get_x_owned()
+                blk.grid.close()
+            except Exception as e:
+                errs.append(e)
+        ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(world)]
+        [x.start() for x in ts]
+        [x.join(120) for x in ts]
+        if errs or any(o is None for o in out) or not np.array_equal(np.concatenate(out), want):
+            bad += 1
+            print("MISMATCH row blocks", W, H, world, ghost, iters, overlap, errs[:1], flush=True)
+    print("soak done, failures:", bad, flush=True)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
