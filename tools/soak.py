@@ -74,6 +74,63 @@ def main():
         if not np.array_equal(got, want):
             bad += 1
             print("MISMATCH reference order", W, H, iters, float(np.abs(got - want).max()), flush=True)
+    nontrivial = 0
+    # the stop rule: fused passes against the in-place kernels (same stop sweep, same x), random check periods
+    for t in range(max(6, n // 4)):
+        W, H, C = int(rng.integers(2, 1500)), int(rng.integers(2, 900)), int(rng.choice([1, 3]))
+        every = int(rng.choice([1, 1, 2, 3, 8]))
+        b = rng.uniform(-3, 3, (C, H, W)) * 1e-8       # keeps the step sums below the start value 10
+        x0 = np.zeros((C, H, W))
+        stop_at = int(rng.integers(1, 60))
+        res = []
+        try:
+            for fuse in ("0", "1"):
+                os.environ["CCP_GS_FUSE"] = fuse
+                g = capi.Grid(W, H, C)
+                for ch in range(C):
+                    g.set_b(b[ch], ch)
+                    g.set_x(x0[ch], ch)
+                if fuse == "0":
+                    # epsilon just above the step of sweep `stop_at` of channel 0 (measured with the in-place kernels)
+                    g.sweep(stop_at - 1)
+                    eps = float(g.sweep_l1()[0]) * (1.0 + 1e-9)
+                    for ch in range(C):
+                        g.set_x(x0[ch], ch)
+                reps = g.gauss_seidel(eps, 200, every)
+                res.append(([(r.iterations, r.converged) for r in reps], np.stack([g.get_x(ch) for ch in range(C)])))
+                g.close()
+            nontrivial += int(res[0][0][0][0] == stop_at)
+            if res[0][0] != res[1][0] or not np.array_equal(res[0][1], res[1][1]):
+                bad += 1
+                print("MISMATCH stop rule", W, H, C, every, stop_at, res[0][0], res[1][0], flush=True)
+        except Exception as e:
+            bad += 1
+            print("ERROR stop rule", W, H, C, every, stop_at, repr(e), flush=True)
+    os.environ.pop("CCP_GS_FUSE", None)
+    print("stop-rule cases that stopped at the planted sweep:", nontrivial, flush=True)
+    # general matrices (irregular masks), both orders, against the oracle
+    for t in range(max(4, n // 8)):
+        Wm, Hm, iters = int(rng.integers(20, 400)), int(rng.integers(20, 300)), int(rng.integers(1, 15))
+        mask = synth.disc_mask(Wm, Hm, seed=int(rng.integers(1, 10000)), n_discs=int(rng.integers(1, 40)))
+        if mask.sum() < 4:
+            continue
+        v, c, r, colour, ys, xs = synth.masked_laplacian_csr(mask)
+        bb = synth.x_true(len(ys), int(rng.integers(1, 1000)))
+        om = orc.from_csr(v, c, r)
+        try:
+            m = capi.CsrMatrix().upload_compressed(v, c, r)
+            x, _ = m.gauss_seidel(bb, 0.0, iters, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+            want, _, _ = om.gauss_seidel(bb, 0.0, iters)
+            m.set_colouring(colour, 2)
+            x2, _ = m.gauss_seidel(bb, 0.0, iters, check_every=0, ordering=capi.ORDER_MULTICOLOUR)
+            want2, _, _ = orc.multicolour_gauss_seidel(v, c, r, colour, bb, 0.0, iters)
+            m.close()
+            if not np.array_equal(x, want) or not np.array_equal(x2, want2):
+                bad += 1
+                print("MISMATCH csr", Wm, Hm, iters, np.array_equal(x, want), np.array_equal(x2, want2), flush=True)
+        except Exception as e:
+            bad += 1
+            print("ERROR csr", Wm, Hm, iters, repr(e), flush=True)
     # row blocks against the single block
     from test_gpu_fullsize import ThreadDist
     for t in range(max(3, n // 8)):
