@@ -131,6 +131,36 @@ def main():
         except Exception as e:
             bad += 1
             print("ERROR csr", Wm, Hm, iters, repr(e), flush=True)
+    # the image side: gradient field + ATb + composite start + clamp, random images and label maps
+    for t in range(max(4, n // 8)):
+        W, H, K, iters = int(rng.integers(2, 700)), int(rng.integers(2, 500)), int(rng.integers(1, 6)), int(rng.integers(1, 20))
+        imgs = [rng.integers(0, 256, (H, W, 3)).astype(np.uint8) for _ in range(K)]
+        label = rng.integers(0, K, (H, W)).astype(np.uint8)
+        if rng.random() < 0.5:                       # blocky label maps (seams) instead of per-pixel noise
+            label = ((np.arange(W)[None, :] * K // W + np.arange(H)[:, None] * K // H) % K).astype(np.uint8)
+        try:
+            g = capi.Grid(W, H, 3)
+            g.assemble_from_images(imgs, label, init_x=True)
+            gx, gy = orc.gradient_field(imgs, label)
+            v, c, r = synth.poisson_csr(W, H)
+            col = oracle.grid_colour(W, H)
+            want_img = np.zeros((H, W, 3), dtype=np.uint8)
+            ok = True
+            for ch in range(3):
+                atb = orc.poisson_rhs(gx, gy, ch, int(imgs[0][0, 0, ch]))
+                init = orc.composite_init(imgs, label, ch)
+                ok &= np.array_equal(g.get_b(ch).ravel(), atb) and np.array_equal(g.get_x(ch).ravel(), init)
+                want, _, _ = orc.multicolour_gauss_seidel(v, c, r, col, atb, 0.0, iters, x0=init)
+                orc.clamp_store_u8(want, want_img, ch)
+            g.sweep(iters)
+            ok &= np.array_equal(g.store_u8(), want_img)
+            g.close()
+            if not ok:
+                bad += 1
+                print("MISMATCH image side", W, H, K, iters, flush=True)
+        except Exception as e:
+            bad += 1
+            print("ERROR image side", W, H, K, iters, repr(e), flush=True)
     # row blocks against the single block
     from test_gpu_fullsize import ThreadDist
     for t in range(max(3, n // 8)):
