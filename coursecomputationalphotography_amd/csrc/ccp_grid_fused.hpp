@@ -236,9 +236,10 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
             const double t = bv + ((((mr ? up : 0.0) + (ml ? left : 0.0)) + (mr ? right : 0.0)) + (mr ? dn : 0.0));
             double q = t * (ml && mr ? 0.25 : 1.0);
             if (p == 0 && cx.has_first) {
-                if (cx.px_first[0]) q = t / 3.0;
+                if (cx.px_first[0] && mr) q = t / 3.0;
             }
-            nv = cx.px_ok[p] ? q : old;
+            // a_ii = 0 (a one-pixel-wide image: no cell left or right of the column) is an empty row: skipped
+            nv = (cx.px_ok[p] && (mr || ml)) ? q : old;
         } else {
             // Most rows of a border trip are still ordinary: an image row with both neighbour
             // rows present, in a strip away from the left/right image edge, takes the plain

@@ -161,6 +161,40 @@ def main():
         except Exception as e:
             bad += 1
             print("ERROR image side", W, H, K, iters, repr(e), flush=True)
+    # tiny and degenerate shapes, both orders, stop rule in the reference order, against the oracle
+    for t in range(max(8, n // 4)):
+        W, H = int(rng.integers(1, 40)), int(rng.integers(1, 40))
+        if rng.random() < 0.3:
+            W = int(rng.choice([1, 2, 3]))
+        if rng.random() < 0.3:
+            H = int(rng.choice([1, 2, 3]))
+        if W * H < 2:
+            continue
+        iters = int(rng.integers(1, 80))
+        b, _ = synth.poisson_system(W, H, int(rng.integers(1, 1000)))
+        b = b * 1e-3
+        v, c, r = synth.poisson_csr(W, H)
+        om = orc.from_csr(v, c, r)
+        try:
+            g = capi.Grid(W, H, 1)
+            g.set_b(b)
+            g.fill_x(1.0)
+            g.sweep(iters)
+            rb = g.get_x().ravel().copy()
+            want_rb, _, _ = orc.multicolour_gauss_seidel(v, c, r, oracle.grid_colour(W, H), b, 0.0, iters)
+            _, _, eps_k = om.gauss_seidel(b, 0.0, iters)
+            epsilon = eps_k * (1.0 + 1e-9)
+            want, it, _ = om.gauss_seidel(b, epsilon, 500)
+            g.fill_x(1.0)
+            rep = g.gauss_seidel_lexicographic(epsilon, 500, 1)[0]
+            lx = g.get_x().ravel()
+            g.close()
+            if not np.array_equal(rb, want_rb) or rep.iterations != it or not np.array_equal(lx, want):
+                bad += 1
+                print("MISMATCH tiny", W, H, iters, np.array_equal(rb, want_rb), rep.iterations, it, np.array_equal(lx, want), flush=True)
+        except Exception as e:
+            bad += 1
+            print("ERROR tiny", W, H, iters, repr(e), flush=True)
     # row blocks against the single block
     from test_gpu_fullsize import ThreadDist
     for t in range(max(3, n // 8)):
