@@ -134,6 +134,12 @@ def main():
     # the image side: gradient field + ATb + composite start + clamp, random images and label maps
     for t in range(max(4, n // 8)):
         W, H, K, iters = int(rng.integers(2, 700)), int(rng.integers(2, 500)), int(rng.integers(1, 6)), int(rng.integers(1, 20))
+        if rng.random() < 0.15:
+            W = int(rng.choice([1, 2]))
+        if rng.random() < 0.15:
+            H = int(rng.choice([1, 2]))
+        if W * H < 2:
+            continue
         imgs = [rng.integers(0, 256, (H, W, 3)).astype(np.uint8) for _ in range(K)]
         label = rng.integers(0, K, (H, W)).astype(np.uint8)
         if rng.random() < 0.5:                       # blocky label maps (seams) instead of per-pixel noise
