@@ -22,6 +22,8 @@ def run_grid(W, H, C, b, x0, iters, env):
     for ch in range(C):
         g.set_b(b[ch], ch)
         g.set_x(x0[ch], ch)
+    if env.get("SOAK_TUNE"):
+        g.tune(int(env["SOAK_TUNE"]))
     g.sweep(iters)
     out = np.stack([g.get_x(ch) for ch in range(C)])
     g.close()
@@ -44,6 +46,8 @@ def main():
             env["CCP_GS_TMAX"] = str(int(rng.integers(1, 9)))
         if rng.random() < 0.2:
             env["CCP_GS_SIDE_ROWS"] = str(int(rng.integers(2, 64)))
+        if rng.random() < 0.3 and "CCP_GS_CHUNK" not in env:
+            env["SOAK_TUNE"] = str(int(rng.integers(1, 9)))       # tuned (depth, chunk height) tables
         b = rng.uniform(-3, 3, (C, H, W))
         x0 = rng.uniform(0, 255, (C, H, W))
         try:
@@ -201,6 +205,28 @@ def main():
         except Exception as e:
             bad += 1
             print("ERROR tiny", W, H, iters, repr(e), flush=True)
+    # conjugate gradient (plain, from a start vector, Jacobi-preconditioned) against the oracle, to reduction rounding
+    for t in range(max(3, n // 12)):
+        W, H, iters = int(rng.integers(3, 300)), int(rng.integers(3, 200)), int(rng.integers(1, 60))
+        v, c, r = synth.poisson_csr(W, H)
+        b, xt = synth.poisson_system(W, H, int(rng.integers(1, 1000)))
+        om = orc.from_csr(v, c, r)
+        try:
+            m = capi.CsrMatrix().upload_compressed(v, c, r)
+            init = xt * 0.9
+            x, rep = m.conjugate_gradient(b, 1e-300, iters, init=init)
+            want, it = om.conjugate_gradient(b, 1e-300, iters, init)
+            xj, repj = m.conjugate_gradient_jacobi(b, 1e-300, iters)
+            wantj, itj = om.conjugate_gradient_jacobi(b, 1e-300, iters)
+            m.close()
+            e1 = np.linalg.norm(x - want) / np.linalg.norm(want)
+            e2 = np.linalg.norm(xj - wantj) / np.linalg.norm(wantj)
+            if rep.iterations != it or repj.iterations != itj or e1 > 1e-8 or e2 > 1e-8:
+                bad += 1
+                print("MISMATCH cg", W, H, iters, rep.iterations, it, repj.iterations, itj, e1, e2, flush=True)
+        except Exception as e:
+            bad += 1
+            print("ERROR cg", W, H, iters, repr(e), flush=True)
     # row blocks against the single block
     from test_gpu_fullsize import ThreadDist
     for t in range(max(3, n // 8)):
