@@ -227,6 +227,35 @@ def main():
         except Exception as e:
             bad += 1
             print("ERROR cg", W, H, iters, repr(e), flush=True)
+    # ccp_grid_sweep_edges_first directly: any iteration count within the ghost depth, any band height
+    for t in range(max(4, n // 10)):
+        W, H = int(rng.integers(50, 2500)), int(rng.integers(200, 1500))
+        ghost = 2 * int(rng.integers(1, 20))
+        rb = int(rng.integers(0, H - 60))
+        rc = int(rng.integers(max(ghost, 20), H - rb + 1)) if H - rb > max(ghost, 20) else H - rb
+        j = int(rng.integers(1, ghost // 2 + 1))
+        edge = int(rng.integers(1, 2 * ghost + 4))
+        try:
+            whole = capi.Grid(W, H, 1)
+            whole.randomize_x(5, 0.0, 255.0)
+            whole.b_from_x()
+            whole.fill_x(1.0)
+            whole.sweep(j)
+            want = whole.get_x()[rb:rb + rc]
+            whole.close()
+            blk = capi.Grid(W, H, 1, rb, rc, ghost, 0)
+            blk.randomize_x(5, 0.0, 255.0)
+            blk.b_from_x()
+            blk.fill_x(1.0)
+            blk.sweep_edges_first(j, edge)
+            got = blk.get_x_owned()
+            blk.close()
+            if not np.array_equal(got, want):
+                bad += 1
+                print("MISMATCH edges_first", W, H, rb, rc, ghost, j, edge, flush=True)
+        except Exception as e:
+            bad += 1
+            print("ERROR edges_first", W, H, rb, rc, ghost, j, edge, repr(e), flush=True)
     # row blocks against the single block
     from test_gpu_fullsize import ThreadDist
     for t in range(max(3, n // 8)):
