@@ -19,7 +19,7 @@
 //     (explicit zeros and removed entries become free slots), different code.
 //
 // conjugateGradient (the solver the blend call sites use today) is provided too; its iterates
-// match the reference to rounding (tree-ordered reductions); so is conjugateGradientEigen.  conjugateGradientPaper is not.
+// match the reference to rounding (tree-ordered reductions); so are conjugateGradientEigen and conjugateGradientPaper.
 #pragma once
 
 #include <algorithm>
@@ -312,6 +312,12 @@ public:
                       "ccp_csr_conjugate_gradient");
         last_report_ = rep;
         return x;
+    }
+
+    // Reference: sparse-matrix.h:436-470 — the same recurrence as conjugateGradient from x0 = 0.
+    std::vector<double> conjugateGradientPaper(const std::vector<double> &b, double epsilon = 1e-16, int max_iteration = 1000)
+    {
+        return conjugateGradient(b, epsilon, max_iteration);
     }
 
     // Reference: sparse-matrix.h:494-535 (Jacobi-preconditioned, x0 = 0; RunTest, utils.cc:99).
