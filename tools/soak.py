@@ -30,9 +30,9 @@ def run_grid(W, H, C, b, x0, iters, env):
     return out
 
 
-def main():
-    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = np.random.Generator(np.random.MT19937(int(sys.argv[2]) if len(sys.argv) > 2 else 2024))
+def run(n, seed):
+    """Returns the number of failing cases (each printed)."""
+    rng = np.random.Generator(np.random.MT19937(seed))
     bad = 0
     for t in range(n):
         W = int(rng.integers(2, 3000)) if rng.random() < 0.8 else int(rng.integers(3000, 9000))
@@ -298,8 +298,16 @@ def main():
         if errs or any(o is None for o in out) or not np.array_equal(np.concatenate(out), want):
             bad += 1
             print("MISMATCH row blocks", W, H, world, ghost, iters, overlap, errs[:1], flush=True)
+    for k in ("CCP_GS_FUSE", "CCP_GS_CHUNK", "CCP_GS_TMAX", "CCP_GS_SIDE_ROWS", "CCP_GS_SHORT_EDGES", "SOAK_TUNE"):
+        os.environ.pop(k, None)
     print("soak done, failures:", bad, flush=True)
-    sys.exit(1 if bad else 0)
+    return bad
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2024
+    sys.exit(1 if run(n, seed) else 0)
 
 
 if __name__ == "__main__":
