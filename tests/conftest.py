@@ -23,7 +23,7 @@ def pytest_collection_modifyitems(config, items):
         return
     for item in items:
         if item.get_closest_marker("gpu") and not item.get_closest_marker("timeout"):
-            item.add_marker(pytest.mark.timeout(240))
+            item.add_marker(pytest.mark.timeout(480))     # the first import of torch on a cold box alone can take 1-2 min
 
 
 @pytest.fixture(scope="session")
