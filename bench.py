@@ -12,16 +12,26 @@ SolveChannel (closed form), b = A x_true with x_true ~ U[0,255) generated ON DEV
 before the timed region), x0 = 1.0 as the reference.  N>1 row-blocks the SAME grid across the
 ranks (strong scaling) with ghost-row exchange over RCCL every ghost/2 iterations.
 
-Extra objects in the JSON line:
-  roofline     — dominant kernel (k_fused_sweep: T red-black iterations per pass over the grid):
-                 algorithmic bytes per launch = 24 B per pixel update x the
-                 W*H*T updates one launch performs, / the average launch duration measured with
-                 HIP events on the launch stream inside the timed region; peak 8 TB/s.  Because
-                 the kernel keeps rows in registers across T iterations its HBM traffic
-                 (`traffic`, from the committed rocprofv3 PMC pass) is far BELOW the algorithmic
-                 bytes, so `frac` exceeds 1: the path runs above the 24 B/update HBM roofline.
-                 `traffic_gbs` / `traffic_frac_of_peak` price the measured bytes instead: how
-                 close the pass runs to what the memory system can move.
+Objects in the JSON line beyond the contract keys:
+  roofline     — dominant kernel k_fused_sweep<T> (one PASS = T red-black iterations over the grid,
+                 one HBM round trip).  Bytes model per launch: 24 B per pixel per pass (x read 8 +
+                 b read 8 + x write 8; SURVEY §8d's 24 B/update re-based to the pass, i.e. 24/T B per
+                 update) x the pixels of the local block.  achieved = that / the average launch
+                 duration, measured with HIP events on the launch stream over exactly the timed
+                 steps (ccp_grid_region_begin/_end); peak 8 TB/s; frac = achieved / peak <= 1.
+                 `traffic` = HBM bytes per launch from the committed rocprofv3 PMC passes
+                 (FETCH_SIZE doubled per the gfx950 correction, WRITE_SIZE as is) of the SAME shape and
+                 tiling (profiles/r02_traffic.json, keyed WxHxC_T<depth>_R<rows>) — null when this
+                 run's tiling has no committed profile.  `x_over_streaming_roofline` is the old
+                 headline: value x 24 B / 8 TB/s, how far above the one-iteration-per-round-trip
+                 roofline the temporal blocking runs.
+  parity_check — the timed tiling re-checked in this very run: the same iteration count through the
+                 independent in-place half-sweep kernels (ccp_grid_set_fused(0)) must give the same
+                 |x| checksum, residual sums and row bands, bit for bit.
+  iters_to_1e-5 — FIRST k with ||b - A x_k||_2 / ||b||_2 <= 1e-5 from x0 = 1 (own untimed solve,
+                 independent of --steps/--warmup).
+  configs      — BASELINE.json configs[0], [1], [4] measured in the same run (N=1), each with its own
+                 bytes model, roofline fraction and CPU baseline.
   cpu_baseline — the compiled reference header (oracle/_ref, kind "reference") or the C oracle
                  (kind "port") timed on ONE host core on a bounded sample (N=1, rank 0 only).
 """
@@ -36,6 +46,13 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 BYTES_PER_UPDATE = 24.0        # b read 8 + neighbour-plane read 8 + x write 8
+BYTES_PER_PIXEL_PASS = 24.0    # the same three streams, once per PASS of the temporally blocked kernel
+MIN_BYTES_PER_PIXEL_PASS = 20.0  # what an unchecked pass must move: black x 4 + b 8 + x write 8 (its first half-sweep overwrites red)
+# Fixed tiling of the headline shape (depth T, rows a wave finalises per pass): what ccp_grid_tune picks on
+# MI355X for this shape, pinned so that every run uses the tiling the committed PMC traffic profile and the
+# full-width oracle test (tests/test_gpu_fullsize.py) were made with.  --tune re-times it on the box.
+DEFAULT_TILING = {(16384, 16384, 1): (8, 448)}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
 def parse():
@@ -50,12 +67,19 @@ def parse():
     ap.add_argument("--ghost", type=int, default=64, help="ghost rows per side (N>1); exchange every ghost/2 iterations")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo stages halos through the host (several ranks on one GPU, testing only)")
-    ap.add_argument("--overlap", action="store_true", help="N>1: finish the edge rows first and exchange halos beside the rest of the pass (measured slower, see DESIGN.md)")
+    ap.add_argument("--halo", default="abi", choices=["abi", "torch"],
+                    help="N>1: abi = halo exchange + norms inside libccp_gs.so over its own RCCL communicator (default); "
+                         "torch = torch.distributed point-to-point (the only choice with --backend gloo)")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange halos after the pass instead of beside it")
     ap.add_argument("--same-device", action="store_true", help="all ranks use cuda:0 (testing with --backend gloo)")
-    ap.add_argument("--no-tune", action="store_true", help="skip ccp_grid_tune (use the built-in defaults)")
+    ap.add_argument("--tune", action="store_true", help="time depth / chunk-row candidates on this box instead of the pinned tiling")
+    ap.add_argument("--depth", type=int, default=0, help="fused depth T (with --rows-per-chunk: overrides the pinned tiling)")
+    ap.add_argument("--rows-per-chunk", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-converge", action="store_true", help="skip the untimed iterations-to-1e-5 run")
+    ap.add_argument("--no-converge", action="store_true", help="skip the untimed iterations-to-1e-5 solve")
+    ap.add_argument("--no-parity", action="store_true", help="skip the in-run parity check against the in-place kernels")
     ap.add_argument("--no-reference-order", action="store_true", help="skip the untimed lexicographic-order run (N=1)")
+    ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs[0], [1], [4] (N=1)")
     ap.add_argument("--reference-order-iters", type=int, default=128)
     ap.add_argument("--converge-cap", type=int, default=6000)
     ap.add_argument("--cpu-sample", type=int, default=4096, help="edge of the CPU baseline sample grid")
@@ -63,28 +87,207 @@ def parse():
     return ap.parse_args()
 
 
-def cpu_baseline(sample: int, iters: int):
-    """Reference gaussSeidel (lexicographic, single thread by construction) on a sample grid."""
-    import numpy as np
-    from coursecomputationalphotography_amd import synth
+def cpu_gs_timed(v, c, r, b, iters):
+    """Seconds inside the reference gaussSeidel (compiled header) or, without it, the C oracle; one core."""
     import oracle
-    v, c, r = synth.poisson_csr(sample, sample)
-    b, _ = synth.poisson_system(sample, sample, 1234)
-    kind = "reference"
     try:
-        ref = oracle.Ref()
-        secs = ref.gs_csr_timed(v, c, r, b, iters)
+        return "reference", oracle.Ref().gs_csr_timed(v, c, r, b, iters)
     except (FileNotFoundError, OSError):
-        kind = "port"
         m = oracle.Oracle().from_csr(v, c, r)
         t0 = time.perf_counter()
         m.gauss_seidel(b, 0.0, iters)
-        secs = time.perf_counter() - t0
-    ups = sample * sample * iters / secs
-    return {"value": ups, "unit": "pixel-updates/s", "cores": 1, "kind": kind,
+        return "port", time.perf_counter() - t0
+
+
+def cpu_baseline(sample: int, iters: int):
+    """Reference gaussSeidel (lexicographic, single thread by construction) on a sample grid."""
+    from coursecomputationalphotography_amd import synth
+    v, c, r = synth.poisson_csr(sample, sample)
+    b, _ = synth.poisson_system(sample, sample, 1234)
+    kind, secs = cpu_gs_timed(v, c, r, b, iters)
+    return {"value": sample * sample * iters / secs, "unit": "pixel-updates/s", "cores": 1, "kind": kind,
             "host_cores_available": os.cpu_count(),
             "sample": f"{sample}x{sample} single-channel Poisson, {iters} lexicographic iterations, "
                       f"{secs:.2f} s inside gaussSeidel (sweep is serial by construction)"}
+
+
+def load_traffic(key):
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            return json.load(fh).get(key)
+    except (OSError, ValueError):
+        return None
+
+
+def roofline_of_pass(W, rows, C, T, R, ms_per_launch, value, world):
+    """The roofline object of one k_fused_sweep launch over a W x rows x C block."""
+    pixels = float(W) * rows * C
+    model = BYTES_PER_PIXEL_PASS * pixels
+    s = ms_per_launch * 1e-3
+    achieved = model / s / 1e9
+    key = f"{W}x{rows}x{C}_T{T}_R{R}"
+    tr = load_traffic(key)
+    traffic = tr["hbm_bytes_per_launch"] if tr else None
+    return {"bound": "hbm", "kernel": f"k_fused_sweep<{T},0,2> (+ k_fused_border<{T},0,2> on a second stream, same pass)",
+            "model": f"{BYTES_PER_PIXEL_PASS:.0f} B per pixel per pass (x read 8 + b read 8 + x write 8); a pass = {T} iterations, "
+                     f"i.e. {BYTES_PER_PIXEL_PASS / T:.1f} B per pixel update",
+            "bytes_per_launch": model, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "min_bytes_per_launch": MIN_BYTES_PER_PIXEL_PASS * pixels,
+            "frac_of_min_bytes": MIN_BYTES_PER_PIXEL_PASS * pixels / s / 1e9 / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_key": key, "traffic_source": tr["source"] if tr else None,
+            "traffic_gbs": (traffic / s / 1e9) if traffic else None,
+            "traffic_frac_of_peak": (traffic / s / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "avg_launch_ms": ms_per_launch, "iterations_per_launch": T,
+            "x_over_streaming_roofline": value * BYTES_PER_UPDATE / 1e9 / (HBM_PEAK_GBS * world),
+            # what streaming kernels reach on this pool (tools/hbm_calib.hip, profiles/r01_hbm_calib.txt)
+            "measured_stream_ceilings_gbs": {"read": 6400, "write": 4700, "copy": 4800, "two_reads_one_write": 5400,
+                                             "source": "profiles/r01_hbm_calib.txt"}}
+
+
+def first_k_below(g, tol, cap, coarse=8):
+    """FIRST k with ||b - A x_k|| / ||b|| <= tol from x0 = 1: coarse search in steps of `coarse`, then the last
+    `coarse` iterations one by one from a fresh solve.  Returns (k or None, trace)."""
+    import numpy as np
+
+    def rel():
+        rr, bb = g.residual_norm2()
+        return float(np.sqrt(rr / bb).max())
+
+    g.fill_x(1.0)
+    k, r, trace = 0, rel(), []
+    while r > tol and k < cap:
+        g.sweep(coarse)
+        k += coarse
+        r = rel()
+        trace.append([k, r])
+    if r > tol:
+        return None, trace[-4:]
+    g.fill_x(1.0)
+    lo = k - coarse
+    if lo > 0:
+        g.sweep(lo)
+    k, r = lo, rel()
+    while r > tol:
+        g.sweep(1)
+        k += 1
+        r = rel()
+    trace.append([k, r])
+    return k, trace[-5:]
+
+
+def parity_against_in_place(g, W, H, iters):
+    """The state after `iters` fused iterations from x0 = 1 is in g; redo them with the in-place half-sweep
+    kernels on the same handle and compare checksums, residual sums and row bands bit for bit."""
+    import numpy as np
+    bands = [0, H // 2 - 2, H - 4]
+    s0 = g.abs_sum().copy()
+    rr0, bb0 = g.residual_norm2()
+    rows0 = [g.get_x(0, y, 4).copy() for y in bands]
+    g.fill_x(1.0)
+    g.set_fused(False)
+    g.sweep(iters)
+    g.set_fused(True)
+    s1 = g.abs_sum()
+    rr1, bb1 = g.residual_norm2()
+    rows1 = [g.get_x(0, y, 4) for y in bands]
+    return {"against": "in-place half-sweep kernels (k_half_sweep, ccp_grid_set_fused(0)), same handle, same b, x0 = 1",
+            "iterations": iters,
+            "abs_sum_equal": bool(np.array_equal(s0, s1)),
+            "residual_sums_equal": bool(np.array_equal(rr0, rr1) and np.array_equal(bb0, bb1)),
+            "bands_equal": bool(all(np.array_equal(a, b) for a, b in zip(rows0, rows1))),
+            "rel_residual": float(np.sqrt(rr1 / bb1).max())}
+
+
+def config0(capi):
+    """BASELINE configs[0]: 512x512 single channel, the reference's lexicographic order (plumbing case)."""
+    import numpy as np
+    from coursecomputationalphotography_amd import synth
+    W = H = 512
+    iters = 100
+    b, _ = synth.poisson_system(W, H, 1234)
+    v, c, r = synth.poisson_csr(W, H)
+    g = capi.Grid(W, H, 1)
+    g.set_b(b)
+    g.fill_x(1.0)
+    g.gauss_seidel_lexicographic(0.0, 4, 0)
+    g.fill_x(1.0)
+    rep = g.gauss_seidel_lexicographic(0.0, iters, 0)[0]
+    x = g.get_x().ravel()
+    g.close()
+    kind, secs = cpu_gs_timed(v, c, r, b, iters)
+    import oracle
+    want, _, _ = oracle.Oracle().from_csr(v, c, r).gauss_seidel(b, 0.0, iters)
+    ups = W * H * iters / rep.seconds
+    return {"workload": "512x512 single-channel Poisson, lexicographic Gauss-Seidel (reference order), 100 iterations",
+            "kernel": "k_lex_plane (one launch per hyperplane x + y + 2k)", "ms": rep.seconds * 1e3,
+            "pixel_updates_per_s": ups,
+            "bytes_model": "32 B per update (two neighbour diagonals 16 + b 8 + x write 8)",
+            "frac": ups * 32.0 / 1e9 / HBM_PEAK_GBS, "bound_note": "launch-rate bound at this size (W+H+2K launches of a few us)",
+            "bit_identical_to_oracle": bool(np.array_equal(x, want)),
+            "cpu_baseline": {"value": W * H * iters / secs, "unit": "pixel-updates/s", "cores": 1, "kind": kind,
+                             "sample": f"the same system and iteration count, {secs:.3f} s"}}
+
+
+def config1(capi, cpu):
+    """BASELINE configs[1]: 4096x4096 3-channel Poisson blend, red-black Gauss-Seidel."""
+    W = H = 4096
+    C, ips, steps = 3, 32, 10
+    g = capi.Grid(W, H, C)
+    g.randomize_x(1234, 0.0, 255.0)
+    g.b_from_x()
+    g.fill_x(1.0)
+    T, R, _ = g.tune(8)
+    g.sweep(ips)
+    g.region_begin()
+    for _ in range(steps):
+        g.sweep(ips)
+    ms, launches = g.region_end()
+    g.close()
+    ups = float(W) * H * C * ips * steps / (ms * 1e-3)
+    per_launch = ms / max(launches, 1)
+    model = BYTES_PER_PIXEL_PASS * W * H * C
+    return {"workload": "4096x4096 3-channel Poisson blend (one matrix, three right-hand sides), red-black Gauss-Seidel",
+            "kernel": f"k_fused_sweep<{T},0,2>", "tiling": {"fused_depth": T, "rows_per_chunk": R, "tuned": True},
+            "ms": ms / steps, "iters": ips, "pixel_updates_per_s": ups,
+            "bytes_model": f"{BYTES_PER_PIXEL_PASS:.0f} B per pixel and channel per pass of {T} iterations",
+            "avg_launch_ms": per_launch, "frac": model / (per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "frac_note": "x, b and the ping-pong buffer are 1.2 GB: past the 256 MiB Infinity Cache, HBM-bound",
+            "cpu_baseline": cpu}
+
+
+def config4(capi):
+    """BASELINE configs[4]: 8192x8192 canvas, photomontage-style irregular mask, general CSR path."""
+    import numpy as np
+    from coursecomputationalphotography_amd import synth
+    import oracle
+    canvas, iters = 8192, 50
+    mask = synth.disc_mask(canvas, canvas, seed=4321)
+    v, c, r, colour, ys, xs = synth.masked_laplacian_csr(mask)
+    n, nnz = len(ys), len(v)
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    m.set_colouring(colour, 2)
+    xt = synth.x_true(n, 4321)
+    b = m.apply_to_vector(xt)
+    m.gauss_seidel(b, 0.0, 2, check_every=0)                          # builds the schedule
+    x, rep = m.gauss_seidel(b, 0.0, iters, check_every=0)
+    rr, bb = m.residual_norm2(b, x)
+    path = m.last_path() if hasattr(m, "last_path") else "sliced ELL"
+    m.close()
+    csr_bytes = 12.0 * nnz + 32.0 * n
+    ups = n * iters / rep.seconds
+    om = oracle.Oracle().from_csr(v, c, r)
+    t0 = time.perf_counter()
+    om.gauss_seidel(b, 0.0, 8)
+    secs = time.perf_counter() - t0
+    return {"workload": f"{canvas}x{canvas} canvas, union-of-discs + brush mask: {n} unknowns, {nnz} non-zeros, "
+                        "5-point Laplacian restricted to the mask, 2-colour Gauss-Seidel",
+            "path": path, "ms_per_iteration": rep.seconds * 1e3 / iters, "iters": iters, "row_updates_per_s": ups,
+            "bytes_model": "SURVEY §8d CSR model: 12 B per stored entry + 32 B per row",
+            "bytes_per_iteration": csr_bytes, "frac": csr_bytes * iters / rep.seconds / 1e9 / HBM_PEAK_GBS,
+            "rel_residual_after": float(np.sqrt(rr / bb)),
+            "cpu_baseline": {"value": n * 8 / secs, "unit": "row-updates/s", "cores": 1, "kind": "port",
+                             "sample": f"the same matrix, 8 lexicographic sweeps of the C oracle, {secs:.2f} s"}}
 
 
 def main():
@@ -109,14 +312,15 @@ def main():
         else:
             dist.init_process_group("gloo")
 
-    from coursecomputationalphotography_amd import rowblock
+    from coursecomputationalphotography_amd import capi, rowblock
 
     W, H, C = args.width, args.height, args.channels
     parts = rowblock.partition_rows(H, world)
     row_begin, row_count = parts[rank]
     ghost = args.ghost if world > 1 else 0
     blk = rowblock.GridBlock(W, H, C, row_begin, row_count, ghost, local_rank)
-    solver = rowblock.RowBlockSolver(blk, rank, world, max(ghost, 2), dist, overlap=args.overlap).set_partition(parts, H)
+    halo = args.halo if (world > 1 and args.backend == "nccl") else "torch"
+    solver = rowblock.make_solver(blk, rank, world, max(ghost, 2), dist, parts, H, halo=halo, overlap=not args.no_overlap)
     g = blk.grid
 
     # synthetic system, generated on device: x_true -> b = A x_true -> x0 = 1.0
@@ -133,23 +337,28 @@ def main():
         torch.cuda.synchronize()
 
     ips = args.iters_per_step
-    tuned = None
-    if not args.no_tune:
+    per_call = ips if world == 1 else solver.iters_per_exchange
+    tuned = False
+    if args.depth > 0 and args.rows_per_chunk > 0:
+        g.set_tiling(args.depth, args.rows_per_chunk)
+    elif not args.tune and world == 1 and (W, H, C) in DEFAULT_TILING:
+        g.set_tiling(*DEFAULT_TILING[(W, H, C)])
+    else:
         # untimed: choose fused depth / chunk rows for this shape (speed only, results identical)
-        tuned = g.tune(min(16, max(1, (ips if world == 1 else solver.iters_per_exchange) // 2)))
+        g.tune(min(8, max(1, per_call // 2)))
+        tuned = True
         g.synchronize()
+    T, R, _ = g.get_tiling()
     for _ in range(args.warmup):
         solver.sweep(ips)
     barrier()
-    kernel_ms, launches = 0.0, 0
+    g.region_begin()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         solver.sweep(ips)
     barrier()
     elapsed = time.perf_counter() - t0
-    # HIP-event time of the LAST sweep call (one exchange interval at N>1, one step at N=1)
-    ms, n_launch = g.last_timing()
-    kernel_ms, launches = ms, n_launch
+    region_ms, region_launches = g.region_end()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -158,54 +367,44 @@ def main():
     updates = float(W) * H * C * ips * args.steps
     value = updates / elapsed
 
-    # roofline of the dominant kernel.  The timed sweep call issued `launches` kernel launches
-    # for `iters_timed` iterations over the local rows.
-    iters_timed = ips if world == 1 else solver.iters_per_exchange
-    fused = os.environ.get("CCP_GS_FUSE", "1") != "0" and iters_timed >= 2
-    updates_per_launch = float(W) * blk.local_rows * C * iters_timed / max(launches, 1)
-    avg_launch_s = (kernel_ms * 1e-3) / max(launches, 1)
-    achieved = BYTES_PER_UPDATE * updates_per_launch / avg_launch_s / 1e9 if launches else None
-    traffic, traffic_src = None, None
-    try:   # HBM bytes per launch from the committed PMC pass of this exact configuration
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as fh:
-            tj = json.load(fh)
-        key = f"{W}x{H}x{C}_n{world}_ips{ips}"
-        if key in tj and fused:
-            traffic, traffic_src = tj[key]["hbm_bytes_per_launch"], tj[key]["source"]
-    except (OSError, ValueError, KeyError):
-        pass
-    roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": (achieved / HBM_PEAK_GBS) if achieved else None, "traffic": traffic,
-                "traffic_source": traffic_src,
-                # what the memory system really moved (PMC pass) over the same launch duration
-                "traffic_gbs": (traffic / avg_launch_s / 1e9) if (traffic and launches) else None,
-                "traffic_frac_of_peak": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBS) if (traffic and launches) else None,
-                "kernel": "k_fused_sweep (+ k_fused_border on a second stream, same pass)" if fused else "k_half_sweep",
-                # what streaming kernels reach on this pool (tools/hbm_calib.hip, profiles/r01_hbm_calib.txt): the
-                # practical ceiling for a pass that reads twice what it writes is the last figure, not 8 TB/s
-                "measured_stream_ceilings_gbs": {"read": 6400, "write": 4700, "copy": 4800, "two_reads_one_write": 5400,
-                                                 "source": "profiles/r01_hbm_calib.txt"},
-                "iterations_per_launch": iters_timed / max(launches, 1),
-                "avg_launch_ms": avg_launch_s * 1e3,
-                "algorithmic_bytes_per_launch": BYTES_PER_UPDATE * updates_per_launch}
+    # roofline of the dominant kernel: HIP-event time of the timed region / the passes launched in it
+    # (at N>1 the region also holds the halo exchanges; the last sweep call's own event pair is used instead)
+    if world == 1:
+        ms_per_launch = region_ms / max(region_launches, 1)
+    else:
+        ms, n_launch = g.last_timing()
+        ms_per_launch = ms / max(n_launch, 1)
+    roofline = roofline_of_pass(W, blk.local_rows, C, T, R, ms_per_launch, value, world)
+    roofline["launches_timed"] = int(region_launches)
+    roofline["region_ms"] = region_ms
 
     extra = {}
+    total_iters = (args.warmup + args.steps) * ips
+    extra["rel_residual_after_timed"] = [total_iters, float(solver.rel_residual().max())]
+    if world == 1 and not args.no_parity:
+        extra["parity_check"] = parity_against_in_place(g, W, H, total_iters)
+        extra["parity_check"]["tiling_checked"] = {"fused_depth": T, "rows_per_chunk": R}
     if not args.no_converge:
-        # untimed: iterations until ||b - A x||_2 / ||b||_2 <= 1e-5 (continuing from the timed state)
-        done = (args.warmup + args.steps) * ips
-        rel = float(solver.rel_residual().max())
-        trace = [[done, rel]]
-        chunk = 64
-        while rel > 1e-5 and done < args.converge_cap:
-            solver.sweep(chunk)
-            done += chunk
-            rel = float(solver.rel_residual().max())
-            trace.append([done, rel])
-        extra["iters_to_1e-5"] = done if rel <= 1e-5 else None
-        extra["rel_residual_trace"] = trace[-4:]
-        extra["rel_residual_final"] = rel
-        # the reference's own stop quantity, sum|x_k - x_{k-1}| (sparse-matrix.h:376), one more sweep
-        extra["l1_step_after"] = [done + 1, float(solver.sweep_l1().max())]
+        if world == 1:
+            k, trace = first_k_below(g, 1e-5, args.converge_cap)
+            extra["iters_to_1e-5"] = k
+            extra["rel_residual_trace"] = trace
+            if k is not None:
+                # the reference's own stop quantity, sum|x_k - x_{k-1}| (sparse-matrix.h:376), one more sweep
+                extra["l1_step_after"] = [k + 1, float(g.sweep_l1().max())]
+        else:
+            # row-blocked: whole exchange intervals from a fresh start (granularity = one interval)
+            g.fill_x(1.0)
+            solver.exchange_halos()
+            done, rel, trace = 0, float(solver.rel_residual().max()), []
+            while rel > 1e-5 and done < args.converge_cap:
+                solver.sweep(solver.iters_per_exchange)
+                done += solver.iters_per_exchange
+                rel = float(solver.rel_residual().max())
+                trace.append([done, rel])
+            extra["iters_to_1e-5"] = done if rel <= 1e-5 else None
+            extra["iters_to_1e-5_granularity"] = solver.iters_per_exchange
+            extra["rel_residual_trace"] = trace[-4:]
 
     if world == 1 and not args.no_reference_order:
         # untimed extra: the reference's OWN sweep order (lexicographic), bit-identical iterates, on the
@@ -228,21 +427,34 @@ def main():
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{W}x{H} single-channel 5-point Poisson (SolveChannel closed form), "
-                                   f"red-black Gauss-Seidel, fixed iteration count" if C == 1 else
-                                   f"{W}x{H} {C}-channel Poisson blend, red-black Gauss-Seidel",
+            "config": {"workload": (f"{W}x{H} single-channel 5-point Poisson (SolveChannel closed form), "
+                                    f"red-black Gauss-Seidel, fixed iteration count" if C == 1 else
+                                    f"{W}x{H} {C}-channel Poisson blend, red-black Gauss-Seidel"),
                        "iters_per_step": ips, "channels": C,
-                       "tuned": None if tuned is None else {"fused_depth": tuned[0], "rows_per_chunk": tuned[1], "ms_per_iteration": tuned[2]},
-                       "partition": "single block" if world == 1 else f"{world} row blocks, ghost {ghost}, halo exchange every {ghost // 2} iterations over " + ("RCCL" if args.backend == "nccl" else "gloo (host-staged, test only)") + (", exchange beside the last pass of each interval" if solver.overlap else "")},
-            "roofline_frac_of_value": value * BYTES_PER_UPDATE / 1e9 / (HBM_PEAK_GBS * world),
+                       "tiling": {"fused_depth": T, "rows_per_chunk": R, "tuned": tuned},
+                       "partition": "single block" if world == 1 else solver.describe()},
             "roofline": roofline,
         }
         out.update(extra)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample, args.cpu_iters)
+            cpu = cpu_baseline(args.cpu_sample, args.cpu_iters)
+            out["cpu_baseline"] = cpu
+            out["vs_cpu_baseline"] = value / cpu["value"]
+        if world == 1 and not args.no_configs:
+            blk.close()
+            cfg = {}
+            for name, fn in (("configs[0]", lambda: config0(capi)),
+                             ("configs[1]", lambda: config1(capi, out.get("cpu_baseline"))),
+                             ("configs[4]", lambda: config4(capi))):
+                try:
+                    cfg[name] = fn()
+                except Exception as e:                                # an extra must never cost the contract line
+                    cfg[name] = {"error": f"{type(e).__name__}: {e}"}
+            out["configs"] = cfg
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
+        solver.close()
         dist.destroy_process_group()
 
 

@@ -23,14 +23,14 @@ ORDER_MULTICOLOUR = 1
 # every symbol include/ccp_gs.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "ccp_status_string", "ccp_abi_version", "ccp_device_count",
-    "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_set_colouring",
+    "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_set_colouring", "ccp_csr_get_colouring",
     "ccp_csr_gauss_seidel", "ccp_csr_conjugate_gradient", "ccp_csr_conjugate_gradient_jacobi", "ccp_csr_apply_to_vector", "ccp_csr_residual_norm2",
     "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
     "ccp_grid_get_b_host", "ccp_grid_fill_x", "ccp_grid_b_from_x", "ccp_grid_randomize_x",
-    "ccp_grid_sweep", "ccp_grid_sweep_edges_first", "ccp_grid_stream_wait_edges", "ccp_grid_tune", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_gauss_seidel_lexicographic", "ccp_grid_conjugate_gradient",
+    "ccp_grid_sweep", "ccp_grid_sweep_edges_first", "ccp_grid_stream_wait_edges", "ccp_grid_tune", "ccp_grid_set_fused", "ccp_grid_set_tiling", "ccp_grid_get_tiling", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_gauss_seidel_lexicographic", "ccp_grid_conjugate_gradient",
     "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_assemble_from_images", "ccp_grid_store_u8",
-    "ccp_grid_set_x_u8", "ccp_grid_last_timing",
+    "ccp_grid_set_x_u8", "ccp_grid_last_timing", "ccp_grid_region_begin", "ccp_grid_region_end",
 )
 
 
@@ -100,6 +100,7 @@ def load() -> C.CDLL:
     L.ccp_csr_destroy.argtypes = [vp]
     L.ccp_csr_upload.argtypes = [vp, i32, i32, i64, vp, vp, vp, vp]
     L.ccp_csr_set_colouring.argtypes = [vp, vp, i32]
+    L.ccp_csr_get_colouring.argtypes = [vp, vp, C.POINTER(i32)]
     L.ccp_csr_gauss_seidel.argtypes = [vp, vp, vp, vp, dbl, i32, i32, i32, C.POINTER(Report)]
     L.ccp_csr_conjugate_gradient.argtypes = [vp, vp, vp, vp, dbl, i32, C.POINTER(Report)]
     L.ccp_csr_conjugate_gradient_jacobi.argtypes = [vp, vp, vp, dbl, i32, C.POINTER(Report)]
@@ -121,6 +122,9 @@ def load() -> C.CDLL:
     L.ccp_grid_stream_wait_edges.argtypes = [vp, vp]
     L.ccp_grid_sweep_l1.argtypes = [vp, vp]
     L.ccp_grid_tune.argtypes = [vp, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(C.c_float)]
+    L.ccp_grid_set_fused.argtypes = [vp, i32]
+    L.ccp_grid_set_tiling.argtypes = [vp, i32, i32]
+    L.ccp_grid_get_tiling.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.ccp_grid_halo_refreshed.argtypes = [vp]
     L.ccp_grid_gauss_seidel.argtypes = [vp, dbl, i32, i32, C.POINTER(Report)]
     L.ccp_grid_gauss_seidel_lexicographic.argtypes = [vp, dbl, i32, i32, C.POINTER(Report)]
@@ -131,6 +135,8 @@ def load() -> C.CDLL:
     L.ccp_grid_store_u8.argtypes = [vp, vp, i64]
     L.ccp_grid_set_x_u8.argtypes = [vp, vp, i64]
     L.ccp_grid_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
+    L.ccp_grid_region_begin.argtypes = [vp]
+    L.ccp_grid_region_end.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i64)]
     _lib = L
     return L
 
@@ -206,6 +212,13 @@ class CsrMatrix:
         nc = int(colour.max()) + 1 if n_colours is None else n_colours
         check(self.L.ccp_csr_set_colouring(self.h, _ptr(colour), nc), "ccp_csr_set_colouring")
         return self
+
+    def get_colouring(self):
+        """(colour[n_rows], n_colours) the multi-colour sweep uses (caller's or the library's greedy one)."""
+        colour = np.empty(max(self.n_rows, 1), dtype=np.int32)
+        nc = C.c_int32()
+        check(self.L.ccp_csr_get_colouring(self.h, _ptr(colour), C.byref(nc)), "ccp_csr_get_colouring")
+        return colour[:self.n_rows], nc.value
 
     def gauss_seidel(self, b, epsilon=1e-6, max_iteration=1000, x0=None, check_every=1,
                      ordering=ORDER_MULTICOLOUR):
@@ -339,6 +352,19 @@ class Grid:
         check(self.L.ccp_grid_tune(self.h, max_t, C.byref(t), C.byref(r), C.byref(ms)), "ccp_grid_tune")
         return t.value, r.value, ms.value
 
+    def set_fused(self, on: bool):
+        """Temporally blocked pass (True, default) or the in-place half-sweep kernels (False)."""
+        check(self.L.ccp_grid_set_fused(self.h, 1 if on else 0), "ccp_grid_set_fused")
+
+    def set_tiling(self, max_t: int, rows_per_chunk: int):
+        check(self.L.ccp_grid_set_tiling(self.h, max_t, rows_per_chunk), "ccp_grid_set_tiling")
+
+    def get_tiling(self):
+        """(max depth, rows per chunk at that depth, tuned?) of the next unchecked sweep."""
+        t, r, tuned = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.L.ccp_grid_get_tiling(self.h, C.byref(t), C.byref(r), C.byref(tuned)), "ccp_grid_get_tiling")
+        return t.value, r.value, bool(tuned.value)
+
     def sweep_l1(self) -> np.ndarray:
         out = np.empty(self.C, dtype=np.float64)
         check(self.L.ccp_grid_sweep_l1(self.h, _ptr(out)), "ccp_grid_sweep_l1")
@@ -396,6 +422,15 @@ class Grid:
     def set_x_u8(self, image: np.ndarray):
         image = np.ascontiguousarray(image, dtype=np.uint8)
         check(self.L.ccp_grid_set_x_u8(self.h, _ptr(image), image.strides[0]), "ccp_grid_set_x_u8")
+
+    def region_begin(self):
+        check(self.L.ccp_grid_region_begin(self.h), "ccp_grid_region_begin")
+
+    def region_end(self):
+        """(device ms, sweep launches) since region_begin — HIP events on the handle's stream."""
+        ms, n = C.c_float(), C.c_int64()
+        check(self.L.ccp_grid_region_end(self.h, C.byref(ms), C.byref(n)), "ccp_grid_region_end")
+        return ms.value, n.value
 
     def last_timing(self):
         ms, n = C.c_float(), C.c_int32()

@@ -39,6 +39,12 @@ inline int hip_fail(hipError_t e, const char *what, const char *file, int line)
         if (s_ != CCP_OK) return s_;     \
     } while (0)
 
+// No C++ exception may cross the extern "C" boundary: every entry point is a function-try-block
+// ending in this handler (host allocations of multi-GB schedules, std::thread construction, ...).
+#define CCP_ABI_CATCH                                          \
+    catch (const std::bad_alloc &) { return CCP_ERR_ALLOC; }   \
+    catch (...) { return CCP_ERR_STATE; }
+
 // Owning device buffer.
 template <typename T>
 struct DevBuf {

@@ -62,6 +62,8 @@ struct ccp_csr {
     std::vector<double> val;
     std::vector<int> user_colour;
     int user_n_colours = 0;
+    std::vector<int> used_colour;          // the colouring the multi-colour schedule was built from
+    int used_n_colours = 0;
     Schedule natural;        // identity order, one group: SpMV / residual
     Schedule multicolour;    // colour-major, columns sorted by permuted index (reference on P A P^T)
     Schedule lexicographic;  // level-major, original storage order kept inside a row
@@ -435,7 +437,10 @@ int ensure_multicolour(ccp_csr *m)
         nc = greedy_colouring(lptr, lidx, m->n_rows, colour);
     }
     if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] colouring (%d colours) in %.3f s\n", nc, now_s() - t0);
-    return build_schedule(m, m->multicolour, colour, nc, true);
+    CCP_TRY(build_schedule(m, m->multicolour, colour, nc, true));
+    m->used_colour.swap(colour);
+    m->used_n_colours = nc;
+    return CCP_OK;
 }
 
 int ensure_lexicographic(ccp_csr *m)
@@ -474,7 +479,7 @@ unsigned blocks_for(long n) { return (unsigned)std::max<long>(1, std::min<long>(
 extern "C" {
 
 int ccp_csr_create(int device, ccp_csr **out)
-{
+try {
     if (!out) return CCP_ERR_BAD_ARG;
     *out = nullptr;
     CCP_TRY(select_device(device));
@@ -487,10 +492,10 @@ int ccp_csr_create(int device, ccp_csr **out)
     }
     *out = m;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_csr_destroy(ccp_csr *m)
-{
+try {
     if (!m) return CCP_OK;
     (void)hipSetDevice(m->device);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
@@ -498,15 +503,20 @@ int ccp_csr_destroy(ccp_csr *m)
     if (m->grid) ccp_grid_destroy(m->grid);
     delete m;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values, const double *values,
                    const int32_t *col_offset, const int32_t *row_begin, const int32_t *row_num_nze)
-{
+try {
     CCP_TRY(bind(m));
     if (n_rows < 0 || n_cols < 0 || n_values < 0) return CCP_ERR_BAD_ARG;
     if (n_rows > 0 && (!row_begin || !row_num_nze)) return CCP_ERR_BAD_ARG;
     if (n_values > 0 && (!values || !col_offset)) return CCP_ERR_BAD_ARG;
+    // a failed upload must not leave the previous matrix half overwritten but still "uploaded"
+    m->uploaded = false;
+    m->natural.reset();
+    m->multicolour.reset();
+    m->lexicographic.reset();
     try {
         m->row_ptr.assign((size_t)n_rows + 1, 0);
         for (int i = 0; i < n_rows; ++i) {
@@ -539,6 +549,8 @@ int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values,
     m->lexicographic.reset();
     m->user_colour.clear();
     m->user_n_colours = 0;
+    m->used_colour.clear();
+    m->used_n_colours = 0;
     m->poisson_w = -1;
     m->poisson_h = 0;
     if (m->grid) ccp_grid_destroy(m->grid);
@@ -553,15 +565,17 @@ int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values,
     CCP_TRY(m->state.alloc(1));
     m->uploaded = true;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours)
-{
+try {
     if (!m) return CCP_ERR_BAD_ARG;
     if (!m->uploaded) return CCP_ERR_STATE;
     m->multicolour.reset();
     m->user_colour.clear();
     m->user_n_colours = 0;
+    m->used_colour.clear();
+    m->used_n_colours = 0;
     if (!colour) return CCP_OK;
     if (n_colours < 1) return CCP_ERR_BAD_ARG;
     for (int i = 0; i < m->n_rows; ++i)
@@ -569,11 +583,22 @@ int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours)
     m->user_colour.assign(colour, colour + m->n_rows);
     m->user_n_colours = n_colours;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
+
+int ccp_csr_get_colouring(ccp_csr *m, int32_t *colour, int32_t *n_colours)
+try {
+    CCP_TRY(bind(m));
+    if (!m->uploaded) return CCP_ERR_STATE;
+    if (!n_colours) return CCP_ERR_BAD_ARG;
+    CCP_TRY(ensure_multicolour(m));          // colours the rows now if no solve has done so yet
+    *n_colours = m->used_n_colours;
+    if (colour && m->n_rows) std::memcpy(colour, m->used_colour.data(), sizeof(int32_t) * (size_t)m->n_rows);
+    return CCP_OK;
+} CCP_ABI_CATCH
 
 int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *x_out, double epsilon,
                          int32_t max_iteration, int32_t check_every, int32_t ordering, ccp_gs_report *report)
-{
+try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
     if (!b || !x_out || check_every < 0) return CCP_ERR_BAD_ARG;
@@ -773,11 +798,11 @@ int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *
         report->seconds = ms * 1e-3;
     }
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, double *x_out, double epsilon,
                                int32_t max_iteration, ccp_gs_report *report)
-{
+try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
     if (!b || !x_out) return CCP_ERR_BAD_ARG;
@@ -834,11 +859,11 @@ int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, 
     if (n) CCP_HIP(hipMemcpyAsync(x_out, m->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
     CCP_HIP(hipStreamSynchronize(s));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_csr_conjugate_gradient_jacobi(ccp_csr *m, const double *b, double *x_out, double epsilon, int32_t max_iteration,
                                       ccp_gs_report *report)
-{
+try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
     if (!b || !x_out) return CCP_ERR_BAD_ARG;
@@ -885,10 +910,10 @@ int ccp_csr_conjugate_gradient_jacobi(ccp_csr *m, const double *b, double *x_out
     if (n) CCP_HIP(hipMemcpyAsync(x_out, m->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
     CCP_HIP(hipStreamSynchronize(s));        // `inv` lives on this stack frame
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_csr_apply_to_vector(ccp_csr *m, const double *in, double *out)
-{
+try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
     if ((m->n_cols && !in) || (m->n_rows && !out)) return CCP_ERR_BAD_ARG;
@@ -905,10 +930,10 @@ int ccp_csr_apply_to_vector(ccp_csr *m, const double *in, double *out)
     }
     CCP_HIP(hipStreamSynchronize(s));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_csr_residual_norm2(ccp_csr *m, const double *b, const double *x, double *rr, double *bb)
-{
+try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
     if (!b || !x || !rr || !bb) return CCP_ERR_BAD_ARG;
@@ -933,6 +958,6 @@ int ccp_csr_residual_norm2(ccp_csr *m, const double *b, const double *x, double 
     *rr = host[0];
     *bb = host[1];
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 }  // extern "C"

@@ -56,6 +56,8 @@ struct ccp_grid {
     long stage_rows = 0;
     int half_sweeps_since_refresh = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;   // ccp_grid_region_begin / _end (created on first use)
+    long region_launches = 0;    // passes / half-sweep launches since ccp_grid_region_begin
     float last_ms = 0.f;
     int last_launches = 0;
     bool timing_pending = false;
@@ -106,6 +108,7 @@ int launch_half_sweep(ccp_grid *g, int c, int l_lo, int l_hi, const int *active)
 #undef CCP_LAUNCH_SWEEP
     CCP_HIP(hipGetLastError());
     g->last_launches++;
+    g->region_launches++;
     return CCP_OK;
 }
 
@@ -249,6 +252,7 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     }
     CCP_HIP(hipGetLastError());
     g->last_launches++;
+    g->region_launches++;
     return CCP_OK;
 }
 
@@ -292,6 +296,7 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int 
                 for (int i = 0; i < 2; ++i) CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream));
         } else {
             const int before = g->last_launches;
+            const long region_before = g->region_launches;
             hipStream_t main_stream = g->stream;
             CCP_HIP(hipEventRecord(g->ev_prev, main_stream));
             const int mode = g->edge_mode;
@@ -323,6 +328,7 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int 
             CCP_TRY(FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, top_end, bot_begin, active, 0, nullptr, std::max(R, r_mid)));
             for (int i = 0; i < 2; ++i) CCP_HIP(hipStreamWaitEvent(main_stream, g->ev_edge[i], 0));
             g->last_launches = before + 1;            // one pass
+            g->region_launches = region_before + 1;
         }
     }
     if (shrinking) g->half_sweeps_since_refresh += 2 * T;
@@ -393,16 +399,19 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool
     return CCP_OK;
 }
 
-void begin_timing(ccp_grid *g)
+int begin_timing(ccp_grid *g)
 {
     g->last_launches = 0;
-    (void)hipEventRecord(g->ev0, g->stream);
+    g->timing_pending = false;
+    CCP_HIP(hipEventRecord(g->ev0, g->stream));
+    return CCP_OK;
 }
 
-void end_timing(ccp_grid *g)
+int end_timing(ccp_grid *g)
 {
-    (void)hipEventRecord(g->ev1, g->stream);
+    CCP_HIP(hipEventRecord(g->ev1, g->stream));
     g->timing_pending = true;
+    return CCP_OK;
 }
 
 // Host <-> device rows in natural order through the staging buffer.
@@ -443,7 +452,7 @@ int transfer_rows(ccp_grid *g, double *dev_base, int channel, double *rows, int 
 extern "C" {
 
 int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
-{
+try {
     if (!d || !out) return CCP_ERR_BAD_ARG;
     *out = nullptr;
     if (d->width < 1 || d->height < 1 || d->channels < 1 || d->channels > kMaxChannels) return CCP_ERR_BAD_ARG;
@@ -519,14 +528,16 @@ int ccp_grid_create(const ccp_grid_desc *d, ccp_grid **out)
     }
     *out = g;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_destroy(ccp_grid *g)
-{
+try {
     if (!g) return CCP_OK;
     (void)hipSetDevice(g->device);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->ev_r0) (void)hipEventDestroy(g->ev_r0);
+    if (g->ev_r1) (void)hipEventDestroy(g->ev_r1);
     if (g->ev_main) (void)hipEventDestroy(g->ev_main);
     if (g->ev_side) (void)hipEventDestroy(g->ev_side);
     if (g->stream2) {
@@ -549,10 +560,10 @@ int ccp_grid_destroy(ccp_grid *g)
     if (g->ev_prev) (void)hipEventDestroy(g->ev_prev);
     delete g;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_get_layout(ccp_grid *g, ccp_grid_layout *out)
-{
+try {
     if (!g || !out) return CCP_ERR_BAD_ARG;
     out->x_dev = g->x.p;
     out->b_dev = g->b.p;
@@ -562,68 +573,68 @@ int ccp_grid_get_layout(ccp_grid *g, ccp_grid_layout *out)
     out->ghost_bottom = g->ghost_bottom;
     out->channels = g->desc.channels;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_set_stream(ccp_grid *g, void *hip_stream)
-{
+try {
     if (!g) return CCP_ERR_BAD_ARG;
     g->stream = reinterpret_cast<hipStream_t>(hip_stream);
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_synchronize(ccp_grid *g)
-{
+try {
     CCP_TRY(bind(g));
     CCP_HIP(hipStreamSynchronize(g->stream));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_set_b_host(ccp_grid *g, int32_t channel, const double *rows, int32_t first_row, int32_t n_rows)
-{
+try {
     if (!g) return CCP_ERR_BAD_ARG;
     return transfer_rows<true>(g, g->b.p, channel, const_cast<double *>(rows), first_row, n_rows);
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_set_x_host(ccp_grid *g, int32_t channel, const double *rows, int32_t first_row, int32_t n_rows)
-{
+try {
     if (!g) return CCP_ERR_BAD_ARG;
     return transfer_rows<true>(g, g->x.p, channel, const_cast<double *>(rows), first_row, n_rows);
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_get_x_host(ccp_grid *g, int32_t channel, double *rows, int32_t first_row, int32_t n_rows)
-{
+try {
     if (!g) return CCP_ERR_BAD_ARG;
     return transfer_rows<false>(g, g->x.p, channel, rows, first_row, n_rows);
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_get_b_host(ccp_grid *g, int32_t channel, double *rows, int32_t first_row, int32_t n_rows)
-{
+try {
     if (!g) return CCP_ERR_BAD_ARG;
     return transfer_rows<false>(g, g->b.p, channel, rows, first_row, n_rows);
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_fill_x(ccp_grid *g, double value)
-{
+try {
     CCP_TRY(bind(g));
     const long n = g->geom.ch_stride * g->desc.channels;
     hipLaunchKernelGGL(k_fill, dim3(2048), dim3(kBlock), 0, g->stream, g->x.p, n, value);
     CCP_HIP(hipGetLastError());
     g->half_sweeps_since_refresh = 0;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_randomize_x(ccp_grid *g, uint64_t seed, double lo, double hi)
-{
+try {
     CCP_TRY(bind(g));
     dim3 grid((unsigned)((g->geom.pitch + kBlock - 1) / kBlock), (unsigned)g->geom.local_rows, (unsigned)g->desc.channels * 2);
     hipLaunchKernelGGL(k_randomize, grid, dim3(kBlock), 0, g->stream, g->x.p, g->geom, seed, lo, hi);
     CCP_HIP(hipGetLastError());
     g->half_sweeps_since_refresh = 0;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_b_from_x(ccp_grid *g)
-{
+try {
     CCP_TRY(bind(g));
     if ((g->shrink_top || g->shrink_bottom) && g->half_sweeps_since_refresh >= g->desc.ghost) return CCP_ERR_STATE;
     const Geom &geo = g->geom;
@@ -635,48 +646,48 @@ int ccp_grid_b_from_x(ccp_grid *g)
     hipLaunchKernelGGL((k_apply<2, 0>), grid, dim3(kBlock), 0, g->stream, g->x.p, g->b.p, g->b.p, geo, l_lo, g->partial.p);
     CCP_HIP(hipGetLastError());
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_halo_refreshed(ccp_grid *g)
-{
+try {
     if (!g) return CCP_ERR_BAD_ARG;
     g->half_sweeps_since_refresh = 0;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_sweep(ccp_grid *g, int32_t iterations)
-{
+try {
     CCP_TRY(bind(g));
     if (iterations < 0) return CCP_ERR_BAD_ARG;
-    begin_timing(g);
+    CCP_TRY(begin_timing(g));
     CCP_TRY(run_unchecked(g, iterations));
-    end_timing(g);
+    CCP_TRY(end_timing(g));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_sweep_edges_first(ccp_grid *g, int32_t iterations, int32_t edge_rows)
-{
+try {
     CCP_TRY(bind(g));
     if (iterations < 0 || edge_rows < 0) return CCP_ERR_BAD_ARG;
     if (!g->stream_e[0]) return ccp_grid_sweep(g, iterations);          // no neighbour blocks: nothing to hand over early
-    begin_timing(g);
+    CCP_TRY(begin_timing(g));
     CCP_TRY(run_unchecked(g, iterations, nullptr, false, nullptr, std::max(1, edge_rows)));
     if (iterations == 0)
         for (int i = 0; i < 2; ++i) CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream));
-    end_timing(g);
+    CCP_TRY(end_timing(g));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_stream_wait_edges(ccp_grid *g, void *hip_stream)
-{
+try {
     CCP_TRY(bind(g));
     if (!g->stream_e[0]) return CCP_OK;
     for (int i = 0; i < 2; ++i) CCP_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(hip_stream), g->ev_edge[i], 0));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_tune(ccp_grid *g, int32_t max_t, int32_t *chosen_t, int32_t *chosen_rows_per_chunk, float *ms_per_iteration)
-{
+try {
     CCP_TRY(bind(g));
     if (max_t < 1) return CCP_ERR_BAD_ARG;
     max_t = std::min<int>(max_t, kFusedMaxT);
@@ -769,27 +780,53 @@ int ccp_grid_tune(ccp_grid *g, int32_t max_t, int32_t *chosen_t, int32_t *chosen
     if (chosen_rows_per_chunk) *chosen_rows_per_chunk = best_r;
     if (ms_per_iteration) *ms_per_iteration = best;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
+
+int ccp_grid_set_fused(ccp_grid *g, int32_t on)
+try {
+    if (!g) return CCP_ERR_BAD_ARG;
+    g->fuse = on != 0;
+    return CCP_OK;
+} CCP_ABI_CATCH
+
+int ccp_grid_set_tiling(ccp_grid *g, int32_t max_t, int32_t rows_per_chunk)
+try {
+    if (!g || max_t < 1 || rows_per_chunk < 2) return CCP_ERR_BAD_ARG;
+    g->fuse_tmax = std::min<int>(max_t, kFusedMaxT);
+    g->rows_per_chunk = rows_per_chunk + (rows_per_chunk & 1);       // the march advances two rows per trip
+    g->tuned = false;                                                // a tuning table would override the request
+    return CCP_OK;
+} CCP_ABI_CATCH
+
+int ccp_grid_get_tiling(ccp_grid *g, int32_t *max_t, int32_t *rows_per_chunk, int32_t *tuned)
+try {
+    if (!g) return CCP_ERR_BAD_ARG;
+    const int T = g->fuse_tmax;
+    if (max_t) *max_t = T;
+    if (rows_per_chunk) *rows_per_chunk = (g->tuned && g->tune_rows[T] > 0) ? g->tune_rows[T] : g->rows_per_chunk;
+    if (tuned) *tuned = g->tuned ? 1 : 0;
+    return CCP_OK;
+} CCP_ABI_CATCH
 
 int ccp_grid_sweep_l1(ccp_grid *g, double *l1_per_channel)
-{
+try {
     CCP_TRY(bind(g));
     if (!l1_per_channel) return CCP_ERR_BAD_ARG;
     const int C = g->desc.channels;
-    begin_timing(g);
+    CCP_TRY(begin_timing(g));
     long blocks[2] = {0, 0};
     CCP_TRY(one_iteration(g, true, nullptr, blocks));
     hipLaunchKernelGGL(k_check, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
                        g->partial.p + g->partial_region, blocks[1], 0.0, 0, static_cast<SolveState *>(nullptr), g->small.p);
     CCP_HIP(hipGetLastError());
-    end_timing(g);
+    CCP_TRY(end_timing(g));
     CCP_HIP(hipMemcpyAsync(l1_per_channel, g->small.p, sizeof(double) * C, hipMemcpyDeviceToHost, g->stream));
     CCP_HIP(hipStreamSynchronize(g->stream));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, int32_t check_every, ccp_gs_report *report)
-{
+try {
     CCP_TRY(bind(g));
     if (g->ghost_top || g->ghost_bottom) return CCP_ERR_STATE;   // row blocks are driven by the caller (halo exchange)
     if (check_every < 0) return CCP_ERR_BAD_ARG;
@@ -801,7 +838,7 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
     }
     CCP_HIP(hipMemcpyAsync(g->state.p, &host, sizeof(host), hipMemcpyHostToDevice, g->stream));
     CCP_HIP(hipStreamSynchronize(g->stream));
-    begin_timing(g);
+    CCP_TRY(begin_timing(g));
     int issued = 0;
     // `while (eps > epsilon && cnt < max_iteration)`: eps starts at 10
     const bool enter = (10.0 > epsilon);
@@ -912,7 +949,7 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
         any_active = false;
         for (int ch = 0; ch < C; ++ch) any_active |= host.active[ch] != 0;
     }
-    end_timing(g);
+    CCP_TRY(end_timing(g));
     CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));
     CCP_HIP(hipStreamSynchronize(g->stream));
     float ms = 0.f;
@@ -928,7 +965,7 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration, in
         }
     }
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 namespace {
 
@@ -959,7 +996,7 @@ int lex_run(ccp_grid *g, int iterations, unsigned mask, double *partial)
 
 int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max_iteration, int32_t check_every,
                                         ccp_gs_report *report)
-{
+try {
     CCP_TRY(bind(g));
     if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;   // whole image only
     if (max_iteration < 0 || check_every < 0) return CCP_ERR_BAD_ARG;
@@ -976,7 +1013,7 @@ int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max
         CCP_TRY(g->lex_x.alloc(elems));
         CCP_TRY(g->lex_b.alloc(elems));
     }
-    begin_timing(g);
+    CCP_TRY(begin_timing(g));
     dim3 cgrid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, (unsigned)C);
     hipLaunchKernelGGL((k_lex_convert<true>), cgrid, dim3(kBlock), 0, g->stream, g->x.p, g->lex_x.p, g->geom, lg);
     hipLaunchKernelGGL((k_lex_convert<true>), cgrid, dim3(kBlock), 0, g->stream, g->b.p, g->lex_b.p, g->geom, lg);
@@ -1047,7 +1084,7 @@ int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max
     }
     hipLaunchKernelGGL((k_lex_convert<false>), cgrid, dim3(kBlock), 0, g->stream, g->x.p, g->lex_x.p, g->geom, lg);
     CCP_HIP(hipGetLastError());
-    end_timing(g);
+    CCP_TRY(end_timing(g));
     CCP_HIP(hipStreamSynchronize(g->stream));
     float ms = 0.f;
     CCP_HIP(hipEventElapsedTime(&ms, g->ev0, g->ev1));
@@ -1062,10 +1099,10 @@ int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max
         }
     }
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_conjugate_gradient(ccp_grid *g, double epsilon, int32_t max_iteration, ccp_gs_report *report)
-{
+try {
     CCP_TRY(bind(g));
     if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;
     const Geom &geo = g->geom;
@@ -1095,10 +1132,10 @@ int ccp_grid_conjugate_gradient(ccp_grid *g, double epsilon, int32_t max_iterati
                          max_iteration, g->cg_state.p, g->partial.p, s, g->ev0, g->ev1, report ? report + ch : nullptr));
     }
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_residual_norm2(ccp_grid *g, double *rr_bb)
-{
+try {
     CCP_TRY(bind(g));
     if (!rr_bb) return CCP_ERR_BAD_ARG;
     if ((g->shrink_top || g->shrink_bottom) && g->half_sweeps_since_refresh >= g->desc.ghost) return CCP_ERR_STATE;
@@ -1117,10 +1154,10 @@ int ccp_grid_residual_norm2(ccp_grid *g, double *rr_bb)
         rr_bb[C + ch] = host[2 * ch + 1];
     }
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_abs_sum(ccp_grid *g, double *per_channel)
-{
+try {
     CCP_TRY(bind(g));
     if (!per_channel) return CCP_ERR_BAD_ARG;
     const int C = g->desc.channels;
@@ -1132,10 +1169,10 @@ int ccp_grid_abs_sum(ccp_grid *g, double *per_channel)
     CCP_HIP(hipMemcpyAsync(per_channel, g->small.p, sizeof(double) * C, hipMemcpyDeviceToHost, g->stream));
     CCP_HIP(hipStreamSynchronize(g->stream));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_assemble_rhs(ccp_grid *g, const float *gx, const float *gy, int64_t row_stride_bytes, const int32_t *constraint)
-{
+try {
     CCP_TRY(bind(g));
     if (!gx || !gy || !constraint) return CCP_ERR_BAD_ARG;
     if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;
@@ -1163,12 +1200,12 @@ int ccp_grid_assemble_rhs(ccp_grid *g, const float *gx, const float *gy, int64_t
     CCP_HIP(hipGetLastError());
     CCP_HIP(hipStreamSynchronize(g->stream));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_assemble_from_images(ccp_grid *g, const uint8_t *const *images, int32_t n_images,
                                   int64_t image_stride_bytes, const uint8_t *label, int64_t label_stride_bytes,
                                   int32_t init_x_from_composite)
-{
+try {
     CCP_TRY(bind(g));
     if (!images || !label || n_images < 1 || n_images > 256) return CCP_ERR_BAD_ARG;
     if (g->desc.channels != 3) return CCP_ERR_UNSUPPORTED;                   // BGR images
@@ -1198,10 +1235,10 @@ int ccp_grid_assemble_from_images(ccp_grid *g, const uint8_t *const *images, int
     CCP_HIP(hipGetLastError());
     CCP_HIP(hipStreamSynchronize(g->stream));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_store_u8(ccp_grid *g, uint8_t *out, int64_t row_stride_bytes)
-{
+try {
     CCP_TRY(bind(g));
     if (!out) return CCP_ERR_BAD_ARG;
     if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;
@@ -1215,10 +1252,10 @@ int ccp_grid_store_u8(ccp_grid *g, uint8_t *out, int64_t row_stride_bytes)
     CCP_HIP(hipMemcpy2DAsync(out, (size_t)row_stride_bytes, d.p, (size_t)W * C, (size_t)W * C, (size_t)H, hipMemcpyDeviceToHost, g->stream));
     CCP_HIP(hipStreamSynchronize(g->stream));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 int ccp_grid_set_x_u8(ccp_grid *g, const uint8_t *image, int64_t row_stride_bytes)
-{
+try {
     CCP_TRY(bind(g));
     if (!image) return CCP_ERR_BAD_ARG;
     if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;
@@ -1232,10 +1269,35 @@ int ccp_grid_set_x_u8(ccp_grid *g, const uint8_t *image, int64_t row_stride_byte
     CCP_HIP(hipGetLastError());
     CCP_HIP(hipStreamSynchronize(g->stream));
     return CCP_OK;
-}
+} CCP_ABI_CATCH
+
+int ccp_grid_region_begin(ccp_grid *g)
+try {
+    CCP_TRY(bind(g));
+    if (!g->ev_r0) {
+        CCP_HIP(hipEventCreate(&g->ev_r0));
+        CCP_HIP(hipEventCreate(&g->ev_r1));
+    }
+    g->region_launches = 0;
+    CCP_HIP(hipEventRecord(g->ev_r0, g->stream));
+    return CCP_OK;
+} CCP_ABI_CATCH
+
+int ccp_grid_region_end(ccp_grid *g, float *milliseconds, int64_t *sweep_launches)
+try {
+    CCP_TRY(bind(g));
+    if (!g->ev_r0) return CCP_ERR_STATE;
+    CCP_HIP(hipEventRecord(g->ev_r1, g->stream));
+    CCP_HIP(hipEventSynchronize(g->ev_r1));
+    float ms = 0.f;
+    CCP_HIP(hipEventElapsedTime(&ms, g->ev_r0, g->ev_r1));
+    if (milliseconds) *milliseconds = ms;
+    if (sweep_launches) *sweep_launches = g->region_launches;
+    return CCP_OK;
+} CCP_ABI_CATCH
 
 int ccp_grid_last_timing(ccp_grid *g, float *milliseconds, int32_t *kernel_launches)
-{
+try {
     CCP_TRY(bind(g));
     if (g->timing_pending) {
         CCP_HIP(hipEventSynchronize(g->ev1));
@@ -1247,6 +1309,6 @@ int ccp_grid_last_timing(ccp_grid *g, float *milliseconds, int32_t *kernel_launc
     if (milliseconds) *milliseconds = g->last_ms;
     if (kernel_launches) *kernel_launches = g->last_launches;
     return CCP_OK;
-}
+} CCP_ABI_CATCH
 
 }  // extern "C"

@@ -57,6 +57,10 @@ class GridBlock:
                                       device=torch.device("cuda", device_index))
         self._side = None
 
+    def close(self) -> None:
+        self.x_rows = None
+        self.grid.close()
+
     def sweep(self, iterations: int) -> None:
         self.grid.sweep(iterations)
 
@@ -101,6 +105,15 @@ class RowBlockSolver:
         self._views = None
         if world > 1 and block.row_count < ghost:
             raise ValueError(f"row block of {block.row_count} rows is thinner than the ghost depth {ghost}")
+
+    def describe(self) -> str:
+        be = self.dist.get_backend(self.group) if self.world > 1 else "none"
+        how = "RCCL point-to-point via torch.distributed" if be == "nccl" else f"{be} (host-staged, test only)"
+        return (f"{self.world} row blocks, ghost {self.ghost}, halo exchange every {self.iters_per_exchange} iterations over {how}"
+                + (", exchange beside the last pass of each interval" if self.overlap else ""))
+
+    def close(self) -> None:
+        pass
 
     # -- halo exchange ---------------------------------------------------------------------
     def exchange_halos(self, after_edges: bool = False) -> None:
@@ -229,3 +242,14 @@ class RowBlockSolver:
         v = t.numpy()
         C = len(rr)
         return np.sqrt(v[:C] / v[C:])
+
+
+def make_solver(block, rank: int, world: int, ghost: int, dist, parts, height: int, halo: str = "torch",
+                overlap: bool = False, group=None):
+    """The row-block driver of one rank: halo = "abi" moves halos and norms inside libccp_gs.so over its
+    own RCCL communicator (ccp_comm_*, ccp_grid_gauss_seidel_rowblocked); "torch" is the
+    torch.distributed point-to-point path (gloo tests, several ranks on one card)."""
+    if halo == "abi" and world > 1:
+        from .rowblock_abi import AbiRowBlockSolver
+        return AbiRowBlockSolver(block, rank, world, ghost, dist, parts, height, overlap=overlap)
+    return RowBlockSolver(block, rank, world, ghost, dist, group=group, overlap=False).set_partition(parts, height)

@@ -47,6 +47,13 @@ inline void throw_on(int status, const char *what)
     if (status != CCP_OK)
         throw std::runtime_error(std::string(what) + ": " + ccp_status_string(status));
 }
+
+// The C ABI reads rows()/cols() doubles through raw pointers: a short vector must fail here, not
+// overrun the heap (the reference at least asserts b.size() == n_cols in debug builds, :351).
+inline void need(bool ok, const char *what)
+{
+    if (!ok) throw std::invalid_argument(what);
+}
 }  // namespace ccp
 
 // ---- free vector helpers (reference: sparse-matrix.h:45-105), serial left-to-right ------------
@@ -132,7 +139,8 @@ public:
     // lab3 passes the matrix by value (main6.cc:20): copyable; the device handle is per object
     SparseMatrix(const SparseMatrix &o)
         : values_(o.values_), col_offset_(o.col_offset_), row_begin_(o.row_begin_),
-          row_num_nze_(o.row_num_nze_), row_space_left_(o.row_space_left_), n_rows_(o.n_rows_), n_cols_(o.n_cols_)
+          row_num_nze_(o.row_num_nze_), row_space_left_(o.row_space_left_), n_rows_(o.n_rows_), n_cols_(o.n_cols_),
+          device_(o.device_), colour_(o.colour_), n_colours_(o.n_colours_)
     {
     }
     SparseMatrix &operator=(const SparseMatrix &o)
@@ -290,6 +298,8 @@ public:
                                     const std::vector<double> &initialize = std::vector<double>(),
                                     ccp::Ordering ordering = ccp::Ordering::Lexicographic)
     {
+        ccp::need(static_cast<Index>(b.size()) == n_rows_, "gaussSeidel: b.size() != rows()");
+        ccp::need(initialize.empty() || static_cast<Index>(initialize.size()) == n_rows_, "gaussSeidel: initialize.size() != rows()");
         sync_device();
         std::vector<double> x(b.size(), 1.0);
         ccp_gs_report rep{};
@@ -304,6 +314,8 @@ public:
     std::vector<double> conjugateGradient(const std::vector<double> &b, double epsilon = 1e-16, int max_iteration = 1000,
                                           const std::vector<double> &initialize = std::vector<double>())
     {
+        ccp::need(static_cast<Index>(b.size()) == n_rows_, "conjugateGradient: b.size() != rows()");
+        ccp::need(initialize.empty() || static_cast<Index>(initialize.size()) == n_rows_, "conjugateGradient: initialize.size() != rows()");
         sync_device();
         std::vector<double> x(b.size(), 0.0);
         ccp_gs_report rep{};
@@ -323,6 +335,7 @@ public:
     // Reference: sparse-matrix.h:494-535 (Jacobi-preconditioned, x0 = 0; RunTest, utils.cc:99).
     std::vector<double> conjugateGradientEigen(const std::vector<double> &b, double epsilon = 1e-16, int max_iteration = 180)
     {
+        ccp::need(static_cast<Index>(b.size()) == n_rows_, "conjugateGradientEigen: b.size() != rows()");
         sync_device();
         std::vector<double> x(b.size(), 0.0);
         ccp_gs_report rep{};
@@ -335,6 +348,8 @@ public:
     // Reference: sparse-matrix.h:382-393.  `out` must be pre-sized to rows().
     void applyToVector(const std::vector<double> &in, std::vector<double> &out)
     {
+        ccp::need(static_cast<Index>(in.size()) >= n_cols_, "applyToVector: in.size() < cols()");
+        ccp::need(static_cast<Index>(out.size()) >= n_rows_, "applyToVector: out.size() < rows()");
         sync_device();
         ccp::throw_on(ccp_csr_apply_to_vector(dev_, in.data(), out.data()), "ccp_csr_apply_to_vector");
     }
@@ -342,6 +357,7 @@ public:
     // sqrt(sum (b - A x)^2 / sum b^2): the metric of SURVEY.md §8d (not in the reference).
     double relativeResidual(const std::vector<double> &b, const std::vector<double> &x)
     {
+        ccp::need(static_cast<Index>(b.size()) >= n_rows_ && static_cast<Index>(x.size()) >= n_cols_, "relativeResidual: vector too short");
         sync_device();
         double rr = 0, bb = 0;
         ccp::throw_on(ccp_csr_residual_norm2(dev_, b.data(), x.data(), &rr, &bb), "ccp_csr_residual_norm2");

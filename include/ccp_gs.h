@@ -88,6 +88,11 @@ int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values,
  * raster mask gets its checkerboard). */
 int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours);
 
+/* The colouring the multi-colour sweep uses (the caller's, or the library's greedy one): colour[i]
+ * for every row (n_rows entries; may be NULL to ask for the count only).  With it a caller can hand
+ * the reference gaussSeidel the same permuted matrix P A P^T and compare iterate for iterate. */
+int ccp_csr_get_colouring(ccp_csr *m, int32_t *colour, int32_t *n_colours);
+
 /* SparseMatrix::gaussSeidel(b, epsilon, max_iteration) (sparse-matrix.h:350-380).
  * x0 == NULL starts from all-ones as the reference does (:352); a non-NULL x0 is the `init`
  * extension mirroring conjugateGradient's 4th argument (:396).  b, x_out: n_cols entries.
@@ -200,6 +205,14 @@ int ccp_grid_stream_wait_edges(ccp_grid *g, void *hip_stream);
  * never depend on the choice — only speed does.  Outputs may be NULL.  Synchronises. */
 int ccp_grid_tune(ccp_grid *g, int32_t max_t, int32_t *chosen_t, int32_t *chosen_rows_per_chunk,
                   float *ms_per_iteration);
+/* Unchecked sweeps through the temporally blocked pass (on, the default) or the in-place half-sweep
+ * kernels (off): two independent implementations of the same arithmetic — results are bit-identical,
+ * which is what bench.py's in-run parity check compares. */
+int ccp_grid_set_fused(ccp_grid *g, int32_t on);
+/* Fix the temporal-blocking depth limit and the rows a wave finalises per pass instead of tuning
+ * (discards a tuning table); ccp_grid_get_tiling reports what the next sweep will use at depth max_t. */
+int ccp_grid_set_tiling(ccp_grid *g, int32_t max_t, int32_t rows_per_chunk);
+int ccp_grid_get_tiling(ccp_grid *g, int32_t *max_t, int32_t *rows_per_chunk, int32_t *tuned);
 /* One more sweep that also returns, per channel, sum|x_new - x_old| over the OWNED rows (the
  * local share of the reference's manhattonDist step, sparse-matrix.h:376) to a host array of
  * `channels` doubles; row-blocked callers all-reduce it.  Synchronises. */
@@ -263,6 +276,13 @@ int ccp_grid_set_x_u8(ccp_grid *g, const uint8_t *image, int64_t row_stride_byte
 /* Device time of the last ccp_grid_sweep / ccp_grid_gauss_seidel in milliseconds and the
  * number of half-sweep kernel launches it issued (HIP events on the handle's stream). */
 int ccp_grid_last_timing(ccp_grid *g, float *milliseconds, int32_t *kernel_launches);
+/* The same over a caller-chosen region spanning many calls: _begin records a HIP event on the handle's
+ * stream, _end records a second one, waits for it and returns the device time between them and the
+ * number of sweep launches issued in between (a temporally blocked pass — its ordinary and its border
+ * kernel run side by side — counts once; an in-place half-sweep counts once).  bench.py's roofline
+ * figure is this time / this count, over exactly the timed steps. */
+int ccp_grid_region_begin(ccp_grid *g);
+int ccp_grid_region_end(ccp_grid *g, float *milliseconds, int64_t *sweep_launches);
 
 #ifdef __cplusplus
 }

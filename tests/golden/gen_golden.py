@@ -93,7 +93,7 @@ def gen_insert_scenario(R):
     save("insert_scenarios.npz", rows=np.int32(rows), cols=np.int32(cols), vals=np.float64(vals),
          ops=np.float64(ops), dense_int=dense_int, dense_dbl=dense_dbl,
          rows2=rr.astype(np.int32), cols2=cc.astype(np.int32), vals2=vv, ops2=np.float64(ops2),
-         ref_steps_ok=np.array(ok), shape2=np.int32([nr, nc]))
+         ref_steps_ok=np.array(ok), shape2=np.int32([nr, nc]), dense2=dense2)
 
 
 def gen_poisson(R, O, W, H):
@@ -264,6 +264,9 @@ def main():
         return
     if len(sys.argv) > 1 and sys.argv[1] == "cg_jacobi":
         gen_cg_jacobi(R)
+        return
+    if len(sys.argv) > 1 and sys.argv[1] == "insert":
+        gen_insert_scenario(R)
         return
     gen_known_answer(R)
     gen_insert_scenario(R)

@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 SMALL = ["--width", "2048", "--height", "1536", "--steps", "2", "--warmup", "1", "--iters-per-step", "16",
-         "--no-cpu-baseline", "--converge-cap", "256"]
+         "--no-cpu-baseline", "--no-configs", "--converge-cap", "256"]
 
 
 def last_json(text):
@@ -31,7 +31,11 @@ def test_bench_contract_line_single_gpu():
     assert d["n_gpus"] == 1 and d["steps"] == 2 and d["dtype"] == "f64" and d["vs_baseline"] is None
     assert d["value"] > 1e10 and d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
     assert "workload" in d["config"]
-    assert d["roofline"]["frac"] > 0 and "traffic" in d["roofline"]
+    assert 0 < d["roofline"]["frac"] <= 1.0 and "traffic" in d["roofline"]       # a fraction of the 8 TB/s peak
+    assert d["roofline"]["launches_timed"] == 2 * 16 // d["config"]["tiling"]["fused_depth"]
+    pc = d["parity_check"]
+    assert pc["iterations"] == 48 and pc["abs_sum_equal"] and pc["residual_sums_equal"] and pc["bands_equal"]
+    assert "iters_to_1e-5" in d and d["rel_residual_after_timed"][0] == 48
     # the untimed reference-order run on the same system
     ro = d["reference_order"]
     assert ro["iterations"] == 128 and ro["pixel_updates_per_s"] > 1e8 and 0 < ro["rel_residual_after"] < 1.0
@@ -51,5 +55,5 @@ def test_bench_two_ranks_on_one_card_matches_single():
     d = last_json(out.stdout)
     assert d["n_gpus"] == 2 and d["scaling"] == "strong"
     # same iterates on the partitioned grid: the residual trace agrees to reduction rounding
-    assert abs(d["rel_residual_final"] - single["rel_residual_final"]) <= 1e-12 * single["rel_residual_final"] + 1e-18
-    assert abs(d["l1_step_after"][1] - single["l1_step_after"][1]) <= 1e-10 * single["l1_step_after"][1]
+    a, b = d["rel_residual_after_timed"], single["rel_residual_after_timed"]
+    assert a[0] == b[0] and abs(a[1] - b[1]) <= 1e-12 * b[1] + 1e-18
