@@ -51,7 +51,7 @@ MIN_BYTES_PER_PIXEL_PASS = 20.0  # what an unchecked pass must move: black x 4 +
 # Fixed tiling of the headline shape (depth T, rows a wave finalises per pass): what ccp_grid_tune picks on
 # MI355X for this shape, pinned so that every run uses the tiling the committed PMC traffic profile and the
 # full-width oracle test (tests/test_gpu_fullsize.py) were made with.  --tune re-times it on the box.
-DEFAULT_TILING = {(16384, 16384, 1): (8, 448)}
+DEFAULT_TILING = {(16384, 16384, 1): (8, 364)}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
 
 
@@ -242,7 +242,7 @@ def config1(capi, cpu):
     g.region_begin()
     for _ in range(steps):
         g.sweep(ips)
-    ms, launches = g.region_end()
+    ms, launches, _ = g.region_end()
     g.close()
     ups = float(W) * H * C * ips * steps / (ms * 1e-3)
     per_launch = ms / max(launches, 1)
@@ -358,7 +358,7 @@ def main():
         solver.sweep(ips)
     barrier()
     elapsed = time.perf_counter() - t0
-    region_ms, region_launches = g.region_end()
+    region_ms, region_launches, region_iters = g.region_end()
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -374,7 +374,9 @@ def main():
     else:
         ms, n_launch = g.last_timing()
         ms_per_launch = ms / max(n_launch, 1)
-    roofline = roofline_of_pass(W, blk.local_rows, C, T, R, ms_per_launch, value, world)
+    depth = region_iters / max(region_launches, 1)            # what the planner really launched (DP over measured depths)
+    roofline = roofline_of_pass(W, blk.local_rows, C, int(round(depth)), R, ms_per_launch, value, world)
+    roofline["iterations_per_launch"] = depth
     roofline["launches_timed"] = int(region_launches)
     roofline["region_ms"] = region_ms
 

@@ -31,6 +31,9 @@ ABI_SYMBOLS = (
     "ccp_grid_sweep", "ccp_grid_sweep_edges_first", "ccp_grid_stream_wait_edges", "ccp_grid_tune", "ccp_grid_set_fused", "ccp_grid_set_tiling", "ccp_grid_get_tiling", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_gauss_seidel_lexicographic", "ccp_grid_conjugate_gradient",
     "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_assemble_from_images", "ccp_grid_store_u8",
     "ccp_grid_set_x_u8", "ccp_grid_last_timing", "ccp_grid_region_begin", "ccp_grid_region_end",
+    "ccp_comm_unique_id", "ccp_comm_create", "ccp_comm_destroy", "ccp_comm_info", "ccp_comm_all_reduce_sum", "ccp_comm_all_reduce_max",
+    "ccp_grid_attach_comm", "ccp_grid_set_overlap", "ccp_grid_exchange_halos", "ccp_grid_sweep_rowblocked",
+    "ccp_grid_gauss_seidel_rowblocked", "ccp_grid_residual_norm2_global", "ccp_grid_comm_stats",
 )
 
 
@@ -58,6 +61,26 @@ class GridLayout(C.Structure):
 
 
 _lib: Optional[C.CDLL] = None
+
+
+def _share_rccl_with_torch() -> None:
+    """The same for RCCL, which libccp_gs.so binds at run time by soname (ccp_comm.hpp): inside a Python
+    process the HIP runtime is torch's, so the collective library must be the one torch ships with it.
+    Loading torch's copy first makes the soname lookup inside the library find that one."""
+    import importlib.util
+    if os.environ.get("CCP_GS_NO_TORCH_HIP") or os.environ.get("CCP_GS_RCCL_LIB"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+        if os.path.exists(cand):
+            try:
+                C.CDLL(cand, mode=C.RTLD_GLOBAL)
+            except OSError:
+                pass
 
 
 def _share_hip_runtime_with_torch() -> None:
@@ -136,7 +159,20 @@ def load() -> C.CDLL:
     L.ccp_grid_set_x_u8.argtypes = [vp, vp, i64]
     L.ccp_grid_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
     L.ccp_grid_region_begin.argtypes = [vp]
-    L.ccp_grid_region_end.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i64)]
+    L.ccp_grid_region_end.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64)]
+    L.ccp_comm_unique_id.argtypes = [vp]
+    L.ccp_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
+    L.ccp_comm_destroy.argtypes = [vp]
+    L.ccp_comm_info.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.ccp_comm_all_reduce_sum.argtypes = [vp, vp, i32]
+    L.ccp_comm_all_reduce_max.argtypes = [vp, vp, i32]
+    L.ccp_grid_attach_comm.argtypes = [vp, vp]
+    L.ccp_grid_set_overlap.argtypes = [vp, i32]
+    L.ccp_grid_exchange_halos.argtypes = [vp]
+    L.ccp_grid_sweep_rowblocked.argtypes = [vp, i32]
+    L.ccp_grid_gauss_seidel_rowblocked.argtypes = [vp, dbl, i32, i32, C.POINTER(Report)]
+    L.ccp_grid_residual_norm2_global.argtypes = [vp, vp]
+    L.ccp_grid_comm_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     _lib = L
     return L
 
@@ -167,6 +203,57 @@ def _f64(a) -> np.ndarray:
 
 def _i32(a) -> np.ndarray:
     return np.ascontiguousarray(a, dtype=np.int32)
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """ncclGetUniqueId through the C ABI (rank 0 calls this and hands the bytes to the other ranks)."""
+    _share_rccl_with_torch()
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    check(load().ccp_comm_unique_id(buf), "ccp_comm_unique_id")
+    return bytes(buf)
+
+
+class Comm:
+    """One rank of an RCCL communicator behind the C ABI (ccp_comm_*).  Creation is collective."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int, device: int = 0):
+        _share_rccl_with_torch()
+        self.L = load()
+        self.h = C.c_void_p()
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("unique id must be COMM_ID_BYTES long")
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        check(self.L.ccp_comm_create(buf, rank, world, device, C.byref(self.h)), "ccp_comm_create")
+        self.rank, self.world, self.device = rank, world, device
+
+    def info(self):
+        r, w, d, v = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.L.ccp_comm_info(self.h, C.byref(r), C.byref(w), C.byref(d), C.byref(v)), "ccp_comm_info")
+        return {"rank": r.value, "world": w.value, "device": d.value, "rccl_version": v.value}
+
+    def all_reduce_sum(self, values) -> np.ndarray:
+        a = _f64(values).copy()
+        check(self.L.ccp_comm_all_reduce_sum(self.h, _ptr(a), a.size), "ccp_comm_all_reduce_sum")
+        return a
+
+    def all_reduce_max(self, values) -> np.ndarray:
+        a = _f64(values).copy()
+        check(self.L.ccp_comm_all_reduce_max(self.h, _ptr(a), a.size), "ccp_comm_all_reduce_max")
+        return a
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h:
+            self.L.ccp_comm_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class CsrMatrix:
@@ -427,10 +514,42 @@ class Grid:
         check(self.L.ccp_grid_region_begin(self.h), "ccp_grid_region_begin")
 
     def region_end(self):
-        """(device ms, sweep launches) since region_begin — HIP events on the handle's stream."""
-        ms, n = C.c_float(), C.c_int64()
-        check(self.L.ccp_grid_region_end(self.h, C.byref(ms), C.byref(n)), "ccp_grid_region_end")
-        return ms.value, n.value
+        """(device ms, sweep launches, iterations of the fused passes) since region_begin — HIP events on
+        the handle's stream."""
+        ms, n, it = C.c_float(), C.c_int64(), C.c_int64()
+        check(self.L.ccp_grid_region_end(self.h, C.byref(ms), C.byref(n), C.byref(it)), "ccp_grid_region_end")
+        return ms.value, n.value, it.value
+
+    # ---- row blocks over RCCL (ccp_comm_*) ------------------------------------------------------
+    def attach_comm(self, comm: "Comm"):
+        check(self.L.ccp_grid_attach_comm(self.h, comm.h if comm is not None else None), "ccp_grid_attach_comm")
+        self._comm = comm                       # the communicator must outlive the attachment
+
+    def set_overlap(self, on: bool):
+        check(self.L.ccp_grid_set_overlap(self.h, 1 if on else 0), "ccp_grid_set_overlap")
+
+    def exchange_halos(self):
+        check(self.L.ccp_grid_exchange_halos(self.h), "ccp_grid_exchange_halos")
+
+    def sweep_rowblocked(self, iterations: int):
+        check(self.L.ccp_grid_sweep_rowblocked(self.h, iterations), "ccp_grid_sweep_rowblocked")
+
+    def gauss_seidel_rowblocked(self, epsilon=1e-6, max_iteration=1000, check_every=1):
+        reps = (Report * self.C)()
+        check(self.L.ccp_grid_gauss_seidel_rowblocked(self.h, epsilon, max_iteration, check_every, reps),
+              "ccp_grid_gauss_seidel_rowblocked")
+        return list(reps)
+
+    def residual_norm2_global(self):
+        out = np.empty(2 * self.C, dtype=np.float64)
+        check(self.L.ccp_grid_residual_norm2_global(self.h, _ptr(out)), "ccp_grid_residual_norm2_global")
+        return out[:self.C].copy(), out[self.C:].copy()
+
+    def comm_stats(self):
+        """(exchanges issued, wait mode: 0 hipStreamWaitValue64 / 1 polling kernel / -1 none, rows sent up, down)."""
+        n, mode, up, down = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.L.ccp_grid_comm_stats(self.h, C.byref(n), C.byref(mode), C.byref(up), C.byref(down)), "ccp_grid_comm_stats")
+        return n.value, mode.value, up.value, down.value
 
     def last_timing(self):
         ms, n = C.c_float(), C.c_int32()

@@ -13,6 +13,7 @@ const char *ccp_status_string(int status)
     case CCP_ERR_ALLOC: return "allocation failed";
     case CCP_ERR_STATE: return "invalid call sequence for this handle";
     case CCP_ERR_UNSUPPORTED: return "unsupported input";
+    case CCP_ERR_RCCL: return "RCCL unavailable or a collective call failed";
     default: return "unknown status";
     }
 }

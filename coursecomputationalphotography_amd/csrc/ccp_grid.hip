@@ -3,6 +3,7 @@
 #include "ccp_grid_fused.hpp"
 #include "ccp_grid_lex.hpp"
 #include "ccp_cg.hpp"
+#include "ccp_comm.hpp"
 
 #include <algorithm>
 #include <functional>
@@ -22,19 +23,30 @@ struct ccp_grid {
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;     // border tiles of a fused pass run here, beside the ordinary ones
     hipEvent_t ev_main = nullptr, ev_side = nullptr;
-    hipEvent_t ev_band[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // the same pair for each band launch
-    // ccp_grid_sweep_edges_first: the last pass finishes the rows a neighbour block needs (top /
-    // bottom band) on these two streams, beside the middle of the block on `stream`
-    hipStream_t stream_e[2] = {nullptr, nullptr};
-    hipStream_t stream_eb[2] = {nullptr, nullptr};   // border tiles of the two bands
-    hipEvent_t ev_prev = nullptr, ev_edge[2] = {nullptr, nullptr};
+    // Row blocks with neighbours.  The pass that uses up the ghost rows finishes the owned rows the
+    // neighbours need FIRST, inside the one launch (short edge chunks dispatched first): its waves count
+    // themselves in *edge_counter and the last one publishes edge_epoch in *edge_flag (signal memory),
+    // which the stream of the halo exchange waits for (ccp_grid_fused.hpp: fused_signal_edge).
+    unsigned long long *edge_counter = nullptr;   // device memory
+    unsigned long long *edge_flag = nullptr;      // hipMallocSignalMemory
+    unsigned long long edge_epoch = 0;
+    int wait_mode = 0;                   // 0: hipStreamWaitValue64, 1: a one-wave polling kernel (CCP_GS_EDGE_WAIT=spin, or no wait-value support)
+    bool edge_signal = true;             // CCP_GS_EDGE_SIGNAL=0: the flag is only published after the whole pass
+    // RCCL (ccp_grid_attach_comm): neighbour ranks, the rows their ghost zones take, the stream the
+    // messages are issued on and the event the sweeps wait for
+    ccp_comm *comm = nullptr;
+    int up_rank = -1, down_rank = -1;
+    int send_up = 0, send_down = 0;
+    hipStream_t stream_comm = nullptr;
+    hipEvent_t ev_comm = nullptr, ev_ready = nullptr;
+    bool overlap = true;                 // exchange beside the rest of the last pass (ccp_grid_set_overlap)
+    long exchanges = 0;                  // halo exchanges issued (statistics)
     DevBuf<double> x, b;
     DevBuf<double> cg_r, cg_p, cg_ap;   // conjugate-gradient work vectors, one channel each
     DevBuf<CgState> cg_state;
     DevBuf<double> x_alt;        // ping-pong partner of x for the temporally blocked sweep
     bool fuse = true;            // use k_fused_sweep for unchecked sweeps
     bool short_edges = true;     // chunk rows at an image edge are short (CCP_GS_SHORT_EDGES=0 turns it off)
-    int edge_mode = 2;           // CCP_GS_EDGE_MODE: where ccp_grid_sweep_edges_first issues the bands
     int side_rows_override = 0;  // CCP_GS_SIDE_ROWS
     int fuse_tmax = kFusedMaxT;  // iterations fused per launch (<= kFusedMaxT)
     int rows_per_chunk = 128;    // rows a fused wave finalises (plus 4T halo rows); default for every T
@@ -58,6 +70,7 @@ struct ccp_grid {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;   // ccp_grid_region_begin / _end (created on first use)
     long region_launches = 0;    // passes / half-sweep launches since ccp_grid_region_begin
+    long region_iterations = 0;  // iterations those passes performed (sum of their depths)
     float last_ms = 0.f;
     int last_launches = 0;
     bool timing_pending = false;
@@ -148,7 +161,10 @@ int one_iteration(ccp_grid *g, bool l1, const int *active, long *blocks_out)
 
 // Which tiles of a pass can touch a pixel with a missing neighbour (same predicates the kernels
 // used to evaluate per wave): leading / trailing chunks by rows, leading / trailing strips by columns.
-void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P)
+// edge_rows > 0 (row block with neighbours, the pass whose result is exchanged): chunk 0 / the last chunk
+// are cut to exactly the owned rows the upper / lower neighbour takes, so they finish — and are
+// signalled — early (FusedParams::first_edge / last_edge).
+void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P, int edge_rows = 0)
 {
     const Geom &geo = g->geom;
     const int HS = 2 * T, R = P.rows_per_chunk;
@@ -158,11 +174,29 @@ void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P)
     // A chunk row at an image edge is cut short: HS + 16 rows, enough for the chunk next to it to be
     // clear of the edge (its halo starts below image row 0 / ends above image row H-1).
     const int rows = P.st_hi - P.st_lo;
-    const int edge_rows = HS + 16;
+    const int edge_short = HS + 16;
     const bool at_top = geo.y0 + P.st_lo - HS <= 0, at_bot = geo.y0 + P.st_hi + HS >= geo.H - 1;
     const bool short_edges = g->short_edges;
-    P.first_rows = (short_edges && at_top && rows > 2 * edge_rows + R / 2 && R > edge_rows) ? edge_rows : 0;
-    P.last_rows = (short_edges && at_bot && rows > 2 * edge_rows + R / 2 && R > edge_rows) ? edge_rows : 0;
+    P.first_rows = (short_edges && at_top && rows > 2 * edge_short + R / 2 && R > edge_short) ? edge_short : 0;
+    P.last_rows = (short_edges && at_bot && rows > 2 * edge_short + R / 2 && R > edge_short) ? edge_short : 0;
+    P.first_edge = P.last_edge = 0;
+    if (edge_rows > 0) {
+        // rows from the first / last stored row that cover the neighbour's share of the owned rows
+        int want_top = (g->shrink_top && !at_top) ? geo.own_lo + std::min(edge_rows, g->send_up > 0 ? g->send_up : edge_rows) - P.st_lo : 0;
+        int want_bot = (g->shrink_bottom && !at_bot) ? P.st_hi - (geo.own_hi - std::min(edge_rows, g->send_down > 0 ? g->send_down : edge_rows)) : 0;
+        want_top += want_top & 1;
+        want_bot += want_bot & 1;
+        const int others = P.first_rows + P.last_rows;
+        if (want_top > 0 && want_bot > 0 && rows < want_top + want_bot + others + 2) want_top = want_bot = 0;   // too thin a block
+        if (want_top > 0 && rows >= want_top + others + 2 && P.first_rows == 0) {
+            P.first_rows = want_top;
+            P.first_edge = 1;
+        }
+        if (want_bot > 0 && rows >= want_bot + P.first_rows + 2 && P.last_rows == 0) {
+            P.last_rows = want_bot;
+            P.last_edge = 1;
+        }
+    }
     const int mid = rows - P.first_rows - P.last_rows;
     P.n_chunks = (mid + R - 1) / R + (P.first_rows > 0) + (P.last_rows > 0);
     auto top = [&](int c) { int ra, rb; fused_chunk_rows(P, c, ra, rb); return geo.y0 + ra - HS <= 0; };
@@ -186,9 +220,11 @@ void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P)
 
 // One pass of depth T.  l1: 0 none, 1 step of the last sweep, 2 step of every sweep of the pass;
 // l1_blocks[0/1]: block results per (sweep, channel) of the ordinary / the border launch.
+// edge_rows > 0: the EDGE kernels (edge chunks first, in-launch signal); *signalled tells the caller
+// whether the pass will publish g->edge_epoch itself.
 template <int T>
 int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi, const int *active,
-                   int l1 = 0, long *l1_blocks = nullptr, int rows_override = 0, hipStream_t border_stream = nullptr)
+                   int l1 = 0, long *l1_blocks = nullptr, int rows_override = 0, int edge_rows = 0, bool *signalled = nullptr)
 {
     FusedParams P;
     P.xin = xin;
@@ -203,7 +239,8 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     P.partial = g->partial.p;
     P.partial_border = g->partial.p + g->partial_region;
     P.active = active;
-    fused_tile_counts(g, T, P);
+    const bool want_edge = edge_rows > 0 && l1 == 0 && active == nullptr && g->edge_counter && g->edge_signal;
+    fused_tile_counts(g, T, P, want_edge ? edge_rows : 0);
     const int waves = kBlock / kWave;
     const int edge_chunks = std::min(P.nb_top + P.nb_bot, P.n_chunks);
     const int edge_strips = std::min(P.ns_left + P.ns_right, P.n_strips);
@@ -215,6 +252,8 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
         if (g->side_rows_override > 0) sr = std::max(2, g->side_rows_override);
         P.side_rows = std::min(sr, R);
         P.side_subs = (R + P.side_rows - 1) / P.side_rows;
+        // an edge chunk may be taller than R: its side strips still need enough sub-tiles
+        P.side_subs = std::max(P.side_subs, (std::max(P.first_rows, P.last_rows) + P.side_rows - 1) / P.side_rows);
     }
     const long n_border = (long)edge_chunks * (P.n_strips - edge_strips) + (long)P.n_chunks * edge_strips * P.side_subs;
     const bool any_plain = edge_chunks < P.n_chunks && edge_strips < P.n_strips;
@@ -225,34 +264,54 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
         l1_blocks[1] = n_border ? (long)bgrid.x : 0;
     }
     if (l1 == 2 && T > kFusedMaxCheckedT) return CCP_ERR_BAD_ARG;
+    // in-launch signal: every wave of an edge chunk (inner strips: one wave per strip in either kernel;
+    // edge strips: one wave per non-empty sub-tile) counts itself once per channel
+    const bool edge = want_edge && (P.first_edge || P.last_edge);
+    P.edge_counter = g->edge_counter;
+    P.edge_flag = g->edge_flag;
+    P.edge_epoch = g->edge_epoch;
+    P.edge_target = 0;
+    if (edge) {
+        long waves_expected = 0;
+        for (int c = 0; c < P.n_chunks; c += std::max(1, P.n_chunks - 1)) {      // chunk 0 and chunk n_chunks-1, once each
+            if (!fused_is_edge_chunk(P, c)) continue;
+            int ra, rb;
+            fused_chunk_rows(P, c, ra, rb);
+            const int subs = std::min(P.side_subs, (rb - ra + P.side_rows - 1) / P.side_rows);
+            waves_expected += (P.n_strips - edge_strips) + (long)edge_strips * subs;
+        }
+        P.edge_target = (unsigned long long)waves_expected * g->desc.channels;
+        // the counter starts from zero in every edge pass: a miscount can cost one overlap, never the next
+        CCP_HIP(hipMemsetAsync(g->edge_counter, 0, sizeof(unsigned long long), g->stream));
+    }
+    if (signalled) *signalled = edge;
     constexpr int TC = T <= kFusedMaxCheckedT ? T : 1;       // per-sweep sums exist up to kFusedMaxCheckedT
-    hipStream_t bstream = border_stream ? border_stream : g->stream2;
-    // each concurrently issued launch orders its two kernels through an event pair of its own
-    const int band_i = border_stream == nullptr ? -1 : (border_stream == g->stream_eb[0] ? 0 : 1);
-    hipEvent_t ev_main = band_i < 0 ? g->ev_main : g->ev_band[band_i][0];
-    hipEvent_t ev_side = band_i < 0 ? g->ev_side : g->ev_band[band_i][1];
+    hipStream_t bstream = g->stream2;
     // The border launch sees everything queued on the main stream so far, runs beside the ordinary
     // tiles, and whatever comes next on the main stream waits for it.
     if (n_border) {
-        CCP_HIP(hipEventRecord(ev_main, g->stream));
-        CCP_HIP(hipStreamWaitEvent(bstream, ev_main, 0));
+        CCP_HIP(hipEventRecord(g->ev_main, g->stream));
+        CCP_HIP(hipStreamWaitEvent(bstream, g->ev_main, 0));
     }
     if (any_plain) {
         if (l1 == 2) hipLaunchKernelGGL((k_fused_sweep<TC, 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
         else if (l1 == 1) hipLaunchKernelGGL((k_fused_sweep<T, 1, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
+        else if (edge) hipLaunchKernelGGL((k_fused_sweep<T, 0, kFusedUnroll, true>), grid, dim3(kBlock), 0, g->stream, P);
         else hipLaunchKernelGGL((k_fused_sweep<T, 0, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
     }
     if (n_border) {
         const int fb = g->force_border ? 1 : 0;
         if (l1 == 2) hipLaunchKernelGGL((k_fused_border<TC, 2, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
         else if (l1 == 1) hipLaunchKernelGGL((k_fused_border<T, 1, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
+        else if (edge) hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll, true>), bgrid, dim3(kBlock), 0, bstream, P, fb);
         else hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
-        CCP_HIP(hipEventRecord(ev_side, bstream));
-        CCP_HIP(hipStreamWaitEvent(g->stream, ev_side, 0));
+        CCP_HIP(hipEventRecord(g->ev_side, bstream));
+        CCP_HIP(hipStreamWaitEvent(g->stream, g->ev_side, 0));
     }
     CCP_HIP(hipGetLastError());
     g->last_launches++;
     g->region_launches++;
+    g->region_iterations += T;
     return CCP_OK;
 }
 
@@ -260,23 +319,64 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
 template <int TMAX>
 struct FusedDepth {
     static int launch(int T, ccp_grid *g, const double *xin, double *xout, int st_lo, int st_hi, const int *active,
-                      int l1, long *l1_blocks, int rows_override = 0, hipStream_t border_stream = nullptr)
+                      int l1, long *l1_blocks, int rows_override = 0, int edge_rows = 0, bool *signalled = nullptr)
     {
-        if (T == TMAX) return launch_fused_t<TMAX>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks, rows_override, border_stream);
-        return FusedDepth<TMAX - 1>::launch(T, g, xin, xout, st_lo, st_hi, active, l1, l1_blocks, rows_override, border_stream);
+        if (T == TMAX) return launch_fused_t<TMAX>(g, xin, xout, st_lo, st_hi, active, l1, l1_blocks, rows_override, edge_rows, signalled);
+        return FusedDepth<TMAX - 1>::launch(T, g, xin, xout, st_lo, st_hi, active, l1, l1_blocks, rows_override, edge_rows, signalled);
     }
 };
 template <>
 struct FusedDepth<0> {
-    static int launch(int, ccp_grid *, const double *, double *, int, int, const int *, int, long *, int = 0, hipStream_t = nullptr) { return CCP_ERR_BAD_ARG; }
+    static int launch(int, ccp_grid *, const double *, double *, int, int, const int *, int, long *, int = 0, int = 0, bool * = nullptr) { return CCP_ERR_BAD_ARG; }
 };
 
+__global__ void k_publish_flag(unsigned long long *flag, unsigned long long epoch)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// One wave polling the flag (wait_mode 1).  Bounded: gives up after ~2 s of device time, so a lost
+// signal costs the overlap, never the process (the flag is always published again after the pass).
+__global__ void k_wait_flag(const unsigned long long *flag, unsigned long long epoch)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
+        __builtin_amdgcn_s_sleep(64);
+        if (wall_clock64() - t0 > 200000000ull) break;             // 100 MHz constant clock
+    }
+}
+
+// A new epoch of the edge hand-off: returns the value waiters of THIS pass look for.
+void edge_epoch_begin(ccp_grid *g) { g->edge_epoch++; }
+
+// After the pass: whatever happened inside it, the flag reaches the epoch once the whole pass is done
+// (also the only publication when the pass could not signal by itself).
+int edge_epoch_publish_after_pass(ccp_grid *g)
+{
+    if (!g->edge_flag) return CCP_OK;
+    hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(64), 0, g->stream, g->edge_flag, g->edge_epoch);
+    CCP_HIP(hipGetLastError());
+    return CCP_OK;
+}
+
+// Make `s` wait until the edge rows of the last edge pass are final.
+int edge_wait_on_stream(ccp_grid *g, hipStream_t s)
+{
+    if (!g->edge_flag) return CCP_OK;
+    if (g->wait_mode == 0) {
+        CCP_HIP(hipStreamWaitValue64(s, g->edge_flag, g->edge_epoch, hipStreamWaitValueGte, ~0ull));
+    } else {
+        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, s, g->edge_flag, g->edge_epoch);
+        CCP_HIP(hipGetLastError());
+    }
+    return CCP_OK;
+}
+
 // T fused iterations xin -> xout, with the ghost bookkeeping of 2T half-sweeps.
-// edge_rows > 0 (row blocks with neighbours): the pass is issued as up to three launches — the band
-// of `edge_rows` owned rows next to each neighbour first, each on its own stream, then the middle
-// on the main stream beside them — and ev_edge[] fire when the bands are final, so the halo
-// exchange can start while the middle of the block is still being swept.  Same tiles, same
-// arithmetic: the only difference to one launch is two extra row seams (re-read halo rows).
+// edge_rows > 0 (row blocks with neighbours): the owned rows next to each neighbour are finished first
+// inside the launch and published through the edge flag (see launch_fused_t); without an in-launch
+// signal the flag is published after the pass.  Same tiles, same arithmetic.
 int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int *active, int l1 = 0,
                  long *l1_blocks = nullptr, int edge_rows = 0)
 {
@@ -285,52 +385,8 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int 
     if (shrinking && s + 2 * T > g->desc.ghost) return CCP_ERR_STATE;   // ghosts exhausted: refresh first
     const int st_lo = g->shrink_top ? std::min(s + 2 * T, g->ghost_top) : 0;
     const int st_hi = g->geom.local_rows - (g->shrink_bottom ? std::min(s + 2 * T, g->ghost_bottom) : 0);
-    if (st_hi > st_lo) {
-        const int top_end = (edge_rows > 0 && g->shrink_top) ? std::min(g->geom.own_lo + edge_rows, st_hi) : st_lo;
-        const int bot_begin = (edge_rows > 0 && g->shrink_bottom) ? std::max(g->geom.own_hi - edge_rows, top_end) : st_hi;
-        const int band[2][2] = {{st_lo, top_end}, {bot_begin, st_hi}};
-        const bool split = l1 == 0 && (top_end > st_lo || st_hi > bot_begin) && bot_begin > top_end;
-        if (!split) {
-            CCP_TRY(FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, st_lo, st_hi, active, l1, l1_blocks));
-            if (edge_rows > 0)
-                for (int i = 0; i < 2; ++i) CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream));
-        } else {
-            const int before = g->last_launches;
-            const long region_before = g->region_launches;
-            hipStream_t main_stream = g->stream;
-            CCP_HIP(hipEventRecord(g->ev_prev, main_stream));
-            const int mode = g->edge_mode;
-            for (int i = 0; i < 2; ++i) {
-                if (band[i][1] > band[i][0]) {
-                    // mode 0: bands on the main stream before the middle; 1: both bands on one extra stream,
-                    // their border tiles on the shared border stream; 2: a stream pair per band
-                    hipStream_t bs = mode == 0 ? main_stream : g->stream_e[mode == 1 ? 0 : i];
-                    hipStream_t bbs = mode == 2 ? g->stream_eb[i] : nullptr;
-                    if (mode != 0) CCP_HIP(hipStreamWaitEvent(bs, g->ev_prev, 0));
-                    g->stream = bs;
-                    const int st = FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, band[i][0], band[i][1], active, 0, nullptr,
-                                                                  band[i][1] - band[i][0], bbs);
-                    g->stream = main_stream;
-                    CCP_TRY(st);
-                    CCP_HIP(hipEventRecord(g->ev_edge[i], bs));
-                } else {
-                    CCP_HIP(hipEventRecord(g->ev_edge[i], main_stream));
-                }
-            }
-            // the bands take tile slots too: give the middle correspondingly fewer, taller chunks, so the
-            // split pass needs no more rounds on the chip than the whole pass would
-            const int R = (g->tuned && g->tune_rows[T] > 0) ? g->tune_rows[T] : g->rows_per_chunk;
-            const int n_whole = (st_hi - st_lo + R - 1) / R;
-            const int n_bands = (band[0][1] > band[0][0]) + (band[1][1] > band[1][0]);
-            const int n_mid = std::max(1, n_whole - n_bands);
-            int r_mid = (bot_begin - top_end + n_mid - 1) / n_mid;
-            r_mid += r_mid & 1;
-            CCP_TRY(FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, top_end, bot_begin, active, 0, nullptr, std::max(R, r_mid)));
-            for (int i = 0; i < 2; ++i) CCP_HIP(hipStreamWaitEvent(main_stream, g->ev_edge[i], 0));
-            g->last_launches = before + 1;            // one pass
-            g->region_launches = region_before + 1;
-        }
-    }
+    if (st_hi > st_lo)
+        CCP_TRY(FusedDepth<kFusedMaxT>::launch(T, g, xin, xout, st_lo, st_hi, active, l1, l1_blocks, 0, edge_rows, nullptr));
     if (shrinking) g->half_sweeps_since_refresh += 2 * T;
     return CCP_OK;
 }
@@ -338,14 +394,15 @@ int launch_fused(ccp_grid *g, int T, const double *xin, double *xout, const int 
 // `iterations` unchecked sweeps: an even number of fused launches (so the result lands back
 // in g->x), a lone leftover iteration through the in-place half-sweep kernels.
 // l1_last: the last launch also accumulates the L1 step of the final iteration (fused check).
+// edge_rows > 0: a new edge epoch — the last launch hands the neighbours' rows over early.
 int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool l1_last = false,
                   long *l1_blocks = nullptr, int edge_rows = 0)
 {
+    if (edge_rows > 0) edge_epoch_begin(g);
     if (!g->fuse || iterations < 2) {
         if (l1_last) return CCP_ERR_STATE;
         for (int k = 0; k < iterations; ++k) CCP_TRY(one_iteration(g, false, active, nullptr));
-        if (edge_rows > 0)
-            for (int i = 0; i < 2; ++i) CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream));
+        if (edge_rows > 0) CCP_TRY(edge_epoch_publish_after_pass(g));
         return CCP_OK;
     }
     if (!g->x_alt.p) {
@@ -363,8 +420,7 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool
         if (l1_last) return CCP_ERR_STATE;
         CCP_TRY(run_unchecked(g, iterations - 1, active, false, nullptr, 0));
         CCP_TRY(one_iteration(g, false, active, nullptr));
-        if (edge_rows > 0)
-            for (int i = 0; i < 2; ++i) CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream));
+        if (edge_rows > 0) CCP_TRY(edge_epoch_publish_after_pass(g));
         return CCP_OK;
     }
     auto cost = [&](int T) -> double { return g->tuned && g->tune_ms[T] > 0 ? (double)g->tune_ms[T] : 1.0 + 0.01 * T; };
@@ -396,6 +452,7 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool
         CCP_TRY(launch_fused(g, plan[k], cur, alt, active, (l1_last && last) ? 1 : 0, l1_blocks, last ? edge_rows : 0));
         std::swap(cur, alt);
     }
+    if (edge_rows > 0) CCP_TRY(edge_epoch_publish_after_pass(g));
     return CCP_OK;
 }
 
@@ -482,7 +539,6 @@ try {
     if (const char *e = getenv("CCP_GS_SHFL")) g->shfl = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SHORT_EDGES")) g->short_edges = atoi(e) != 0;
-    if (const char *e = getenv("CCP_GS_EDGE_MODE")) g->edge_mode = std::max(0, std::min(2, atoi(e)));
     if (const char *e = getenv("CCP_GS_SIDE_ROWS")) g->side_rows_override = atoi(e);
     if (const char *e = getenv("CCP_GS_TMAX")) g->fuse_tmax = std::max(1, std::min(kFusedMaxT, atoi(e)));
     if (const char *e = getenv("CCP_GS_ALL_BORDER")) g->all_border = atoi(e) != 0;
@@ -507,17 +563,17 @@ try {
                          hipEventCreateWithFlags(&g->ev_side, hipEventDisableTiming) != hipSuccess))
         st = CCP_ERR_HIP;
     if (st == CCP_OK && (g->ghost_top || g->ghost_bottom)) {
-        int lo = 0, hi = 0;                              // hi = greatest priority (numerically lowest)
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
-        if (const char *e = getenv("CCP_GS_EDGE_PRIO")) { if (atoi(e) == 0) hi = lo; }
-        for (int i = 0; i < 2 && st == CCP_OK; ++i)
-            if (hipStreamCreateWithPriority(&g->stream_e[i], hipStreamNonBlocking, hi) != hipSuccess ||
-                hipStreamCreateWithPriority(&g->stream_eb[i], hipStreamNonBlocking, hi) != hipSuccess ||
-                hipEventCreateWithFlags(&g->ev_edge[i], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&g->ev_band[i][0], hipEventDisableTiming) != hipSuccess ||
-                hipEventCreateWithFlags(&g->ev_band[i][1], hipEventDisableTiming) != hipSuccess)
-                st = CCP_ERR_HIP;
-        if (st == CCP_OK && hipEventCreateWithFlags(&g->ev_prev, hipEventDisableTiming) != hipSuccess) st = CCP_ERR_HIP;
+        // edge hand-off of a row block with neighbours: counter in device memory, flag in signal memory
+        int can_wait = 0;
+        (void)hipDeviceGetAttribute(&can_wait, hipDeviceAttributeCanUseStreamWaitValue, g->device);
+        g->wait_mode = can_wait ? 0 : 1;
+        if (const char *e = getenv("CCP_GS_EDGE_WAIT")) g->wait_mode = (strcmp(e, "spin") == 0) ? 1 : (can_wait ? 0 : 1);
+        if (const char *e = getenv("CCP_GS_EDGE_SIGNAL")) g->edge_signal = atoi(e) != 0;
+        if (hipMalloc(reinterpret_cast<void **>(&g->edge_counter), sizeof(unsigned long long)) != hipSuccess ||
+            hipExtMallocWithFlags(reinterpret_cast<void **>(&g->edge_flag), sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess ||
+            hipMemset(g->edge_counter, 0, sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(g->edge_flag, 0, sizeof(unsigned long long)) != hipSuccess)
+            st = CCP_ERR_HIP;
     }
     if (st == CCP_OK && (hipMemset(g->x.p, 0, elems * sizeof(double)) != hipSuccess ||
                          hipMemset(g->b.p, 0, elems * sizeof(double)) != hipSuccess))
@@ -544,20 +600,14 @@ try {
         (void)hipStreamSynchronize(g->stream2);
         (void)hipStreamDestroy(g->stream2);
     }
-    for (int i = 0; i < 2; ++i) {
-        if (g->stream_e[i]) {
-            (void)hipStreamSynchronize(g->stream_e[i]);
-            (void)hipStreamDestroy(g->stream_e[i]);
-        }
-        if (g->stream_eb[i]) {
-            (void)hipStreamSynchronize(g->stream_eb[i]);
-            (void)hipStreamDestroy(g->stream_eb[i]);
-        }
-        if (g->ev_edge[i]) (void)hipEventDestroy(g->ev_edge[i]);
-        for (int k = 0; k < 2; ++k)
-            if (g->ev_band[i][k]) (void)hipEventDestroy(g->ev_band[i][k]);
+    if (g->stream_comm) {
+        (void)hipStreamSynchronize(g->stream_comm);
+        (void)hipStreamDestroy(g->stream_comm);
     }
-    if (g->ev_prev) (void)hipEventDestroy(g->ev_prev);
+    if (g->ev_comm) (void)hipEventDestroy(g->ev_comm);
+    if (g->ev_ready) (void)hipEventDestroy(g->ev_ready);
+    if (g->edge_counter) (void)hipFree(g->edge_counter);
+    if (g->edge_flag) (void)hipFree(g->edge_flag);
     delete g;
     return CCP_OK;
 } CCP_ABI_CATCH
@@ -669,11 +719,9 @@ int ccp_grid_sweep_edges_first(ccp_grid *g, int32_t iterations, int32_t edge_row
 try {
     CCP_TRY(bind(g));
     if (iterations < 0 || edge_rows < 0) return CCP_ERR_BAD_ARG;
-    if (!g->stream_e[0]) return ccp_grid_sweep(g, iterations);          // no neighbour blocks: nothing to hand over early
+    if (!g->edge_flag) return ccp_grid_sweep(g, iterations);          // no neighbour blocks: nothing to hand over early
     CCP_TRY(begin_timing(g));
     CCP_TRY(run_unchecked(g, iterations, nullptr, false, nullptr, std::max(1, edge_rows)));
-    if (iterations == 0)
-        for (int i = 0; i < 2; ++i) CCP_HIP(hipEventRecord(g->ev_edge[i], g->stream));
     CCP_TRY(end_timing(g));
     return CCP_OK;
 } CCP_ABI_CATCH
@@ -681,9 +729,7 @@ try {
 int ccp_grid_stream_wait_edges(ccp_grid *g, void *hip_stream)
 try {
     CCP_TRY(bind(g));
-    if (!g->stream_e[0]) return CCP_OK;
-    for (int i = 0; i < 2; ++i) CCP_HIP(hipStreamWaitEvent(reinterpret_cast<hipStream_t>(hip_stream), g->ev_edge[i], 0));
-    return CCP_OK;
+    return edge_wait_on_stream(g, reinterpret_cast<hipStream_t>(hip_stream));
 } CCP_ABI_CATCH
 
 int ccp_grid_tune(ccp_grid *g, int32_t max_t, int32_t *chosen_t, int32_t *chosen_rows_per_chunk, float *ms_per_iteration)
@@ -1134,10 +1180,11 @@ try {
     return CCP_OK;
 } CCP_ABI_CATCH
 
-int ccp_grid_residual_norm2(ccp_grid *g, double *rr_bb)
-try {
-    CCP_TRY(bind(g));
-    if (!rr_bb) return CCP_ERR_BAD_ARG;
+namespace {
+
+// g->small.p[2*ch] = sum (b - A x)^2, [2*ch+1] = sum b^2 over the OWNED rows (device, on g->stream)
+int residual_to_small(ccp_grid *g)
+{
     if ((g->shrink_top || g->shrink_bottom) && g->half_sweeps_since_refresh >= g->desc.ghost) return CCP_ERR_STATE;
     const Geom &geo = g->geom;
     const int C = g->desc.channels;
@@ -1146,6 +1193,12 @@ try {
     CCP_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_pair_reduce, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, (long)grid.x * grid.y, g->small.p);
     CCP_HIP(hipGetLastError());
+    return CCP_OK;
+}
+
+int small_to_rr_bb(ccp_grid *g, double *rr_bb)
+{
+    const int C = g->desc.channels;
     double host[2 * kMaxChannels];
     CCP_HIP(hipMemcpyAsync(host, g->small.p, sizeof(double) * 2 * C, hipMemcpyDeviceToHost, g->stream));
     CCP_HIP(hipStreamSynchronize(g->stream));
@@ -1154,6 +1207,16 @@ try {
         rr_bb[C + ch] = host[2 * ch + 1];
     }
     return CCP_OK;
+}
+
+}  // namespace
+
+int ccp_grid_residual_norm2(ccp_grid *g, double *rr_bb)
+try {
+    CCP_TRY(bind(g));
+    if (!rr_bb) return CCP_ERR_BAD_ARG;
+    CCP_TRY(residual_to_small(g));
+    return small_to_rr_bb(g, rr_bb);
 } CCP_ABI_CATCH
 
 int ccp_grid_abs_sum(ccp_grid *g, double *per_channel)
@@ -1271,6 +1334,255 @@ try {
     return CCP_OK;
 } CCP_ABI_CATCH
 
+// ============================================================================================
+// Row blocks over RCCL: neighbour halo exchange and all-reduced norms behind the C ABI.
+// ============================================================================================
+namespace {
+
+bool has_neighbours(const ccp_grid *g) { return g->up_rank >= 0 || g->down_rank >= 0; }
+
+// The messages of one exchange, all in one RCCL group on `s`: the outermost owned rows go to the
+// neighbours' ghost rows, theirs arrive in ours.  One image row of one channel is 2*pitch contiguous
+// doubles, so a block of rows is one message per channel and direction.
+int issue_exchange(ccp_grid *g, hipStream_t s)
+{
+    const RcclApi *api = rccl_api();
+    if (!api || !g->comm) return CCP_ERR_STATE;
+    const Geom &geo = g->geom;
+    const size_t row = (size_t)2 * geo.pitch;
+    CCP_RCCL(api->GroupStart());
+    ncclResult_t r = ncclSuccess;
+    for (int ch = 0; ch < g->desc.channels && r == ncclSuccess; ++ch) {
+        double *x = g->x.p + (size_t)ch * geo.ch_stride;
+        if (g->up_rank >= 0) {
+            r = api->Send(x + (size_t)geo.own_lo * row, (size_t)g->send_up * row, ncclDouble, g->up_rank, g->comm->comm, s);
+            if (r == ncclSuccess) r = api->Recv(x, (size_t)g->ghost_top * row, ncclDouble, g->up_rank, g->comm->comm, s);
+        }
+        if (g->down_rank >= 0 && r == ncclSuccess) {
+            r = api->Send(x + (size_t)(geo.own_hi - g->send_down) * row, (size_t)g->send_down * row, ncclDouble, g->down_rank,
+                          g->comm->comm, s);
+            if (r == ncclSuccess) r = api->Recv(x + (size_t)geo.own_hi * row, (size_t)g->ghost_bottom * row, ncclDouble, g->down_rank,
+                                               g->comm->comm, s);
+        }
+    }
+    const ncclResult_t e = api->GroupEnd();
+    if (r != ncclSuccess) return rccl_fail(r, "ncclSend/ncclRecv", __FILE__, __LINE__);
+    CCP_RCCL(e);
+    return CCP_OK;
+}
+
+// Refresh the ghost rows.  after_edges: the sweeps were issued with an edge epoch — the messages wait for
+// the edge flag only and travel beside the rest of the pass; otherwise they wait for everything queued.
+int exchange(ccp_grid *g, bool after_edges)
+{
+    if (!g->comm) return CCP_ERR_STATE;
+    if (has_neighbours(g)) {
+        if (after_edges) {
+            CCP_TRY(edge_wait_on_stream(g, g->stream_comm));
+        } else {
+            CCP_HIP(hipEventRecord(g->ev_ready, g->stream));
+            CCP_HIP(hipStreamWaitEvent(g->stream_comm, g->ev_ready, 0));
+        }
+        CCP_TRY(issue_exchange(g, g->stream_comm));
+        CCP_HIP(hipEventRecord(g->ev_comm, g->stream_comm));
+        CCP_HIP(hipStreamWaitEvent(g->stream, g->ev_comm, 0));
+        g->exchanges++;
+    }
+    g->half_sweeps_since_refresh = 0;
+    return CCP_OK;
+}
+
+// `iterations` sweeps with a halo exchange every ghost/2 iterations.
+int sweep_rowblocked(ccp_grid *g, int iterations)
+{
+    const bool nb = has_neighbours(g);
+    const int ipe = std::max(1, g->desc.ghost / 2);
+    int left = iterations;
+    while (left > 0) {
+        int since = g->half_sweeps_since_refresh / 2;
+        if (nb && since >= ipe) {
+            CCP_TRY(exchange(g, false));
+            since = 0;
+        }
+        const int room = nb ? std::min(left, ipe - since) : left;
+        if (nb && g->overlap && since + room == ipe) {
+            // these sweeps use up the ghost rows: their last pass hands the neighbours' rows over first and
+            // the exchange runs beside the rest of it
+            CCP_TRY(run_unchecked(g, room, nullptr, false, nullptr, g->desc.ghost));
+            CCP_TRY(exchange(g, true));
+        } else {
+            CCP_TRY(run_unchecked(g, room));
+        }
+        left -= room;
+    }
+    return CCP_OK;
+}
+
+}  // namespace
+
+int ccp_grid_attach_comm(ccp_grid *g, ccp_comm *c)
+try {
+    CCP_TRY(bind(g));
+    if (!c) {                                        // detach
+        g->comm = nullptr;
+        g->up_rank = g->down_rank = -1;
+        return CCP_OK;
+    }
+    if (c->device != g->device) return CCP_ERR_BAD_ARG;
+    const RcclApi *api = rccl_api();
+    if (!api) return CCP_ERR_RCCL;
+    // every rank learns every block: the partition must be contiguous row blocks of one image, in rank order
+    const int me[4] = {g->desc.row_begin, g->desc.row_count, g->desc.ghost, g->desc.width ^ (g->desc.height << 1) ^ (g->desc.channels << 28)};
+    int *dev = reinterpret_cast<int *>(c->scratch.p);
+    std::vector<int> all((size_t)4 * c->world);
+    CCP_HIP(hipMemcpyAsync(dev + 4 * c->rank, me, sizeof(me), hipMemcpyHostToDevice, g->stream));
+    CCP_RCCL(api->AllGather(dev + 4 * c->rank, dev, 4, ncclInt32, c->comm, g->stream));
+    CCP_HIP(hipMemcpyAsync(all.data(), dev, sizeof(int) * all.size(), hipMemcpyDeviceToHost, g->stream));
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    int next = 0;
+    for (int r = 0; r < c->world; ++r) {
+        if (all[4 * r] != next || all[4 * r + 2] != me[2] || all[4 * r + 3] != me[3]) return CCP_ERR_BAD_ARG;
+        next += all[4 * r + 1];
+    }
+    if (next != g->desc.height) return CCP_ERR_BAD_ARG;
+    g->up_rank = (c->rank > 0 && g->ghost_top > 0) ? c->rank - 1 : -1;
+    g->down_rank = (c->rank + 1 < c->world && g->ghost_bottom > 0) ? c->rank + 1 : -1;
+    if ((c->rank > 0) != (g->up_rank >= 0) || (c->rank + 1 < c->world) != (g->down_rank >= 0)) return CCP_ERR_STATE;   // a neighbour without ghost rows
+    // what the neighbours' ghost zones take: their depth, clipped by the image border on their far side
+    g->send_up = g->up_rank >= 0 ? std::min(g->desc.ghost, g->desc.height - g->desc.row_begin) : 0;
+    g->send_down = g->down_rank >= 0 ? std::min(g->desc.ghost, g->desc.row_begin + g->desc.row_count) : 0;
+    if (g->send_up > g->desc.row_count || g->send_down > g->desc.row_count) return CCP_ERR_UNSUPPORTED;   // block thinner than the ghost depth
+    if (!g->stream_comm) {
+        int lo = 0, hi = 0;                              // hi = greatest priority (numerically lowest)
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+        CCP_HIP(hipStreamCreateWithPriority(&g->stream_comm, hipStreamNonBlocking, hi));
+        CCP_HIP(hipEventCreateWithFlags(&g->ev_comm, hipEventDisableTiming));
+        CCP_HIP(hipEventCreateWithFlags(&g->ev_ready, hipEventDisableTiming));
+    }
+    g->comm = c;
+    return CCP_OK;
+} CCP_ABI_CATCH
+
+int ccp_grid_set_overlap(ccp_grid *g, int32_t on)
+try {
+    if (!g) return CCP_ERR_BAD_ARG;
+    g->overlap = on != 0;
+    return CCP_OK;
+} CCP_ABI_CATCH
+
+int ccp_grid_exchange_halos(ccp_grid *g)
+try {
+    CCP_TRY(bind(g));
+    return exchange(g, false);
+} CCP_ABI_CATCH
+
+int ccp_grid_sweep_rowblocked(ccp_grid *g, int32_t iterations)
+try {
+    CCP_TRY(bind(g));
+    if (iterations < 0) return CCP_ERR_BAD_ARG;
+    if (!g->comm) return CCP_ERR_STATE;
+    CCP_TRY(begin_timing(g));
+    CCP_TRY(sweep_rowblocked(g, iterations));
+    CCP_TRY(end_timing(g));
+    return CCP_OK;
+} CCP_ABI_CATCH
+
+int ccp_grid_residual_norm2_global(ccp_grid *g, double *rr_bb)
+try {
+    CCP_TRY(bind(g));
+    if (!rr_bb) return CCP_ERR_BAD_ARG;
+    if (!g->comm) return CCP_ERR_STATE;
+    const RcclApi *api = rccl_api();
+    if (!api) return CCP_ERR_RCCL;
+    if (has_neighbours(g) && g->half_sweeps_since_refresh > 0) CCP_TRY(exchange(g, false));   // A x needs current ghost rows
+    CCP_TRY(residual_to_small(g));
+    CCP_RCCL(api->AllReduce(g->small.p, g->small.p, (size_t)2 * g->desc.channels, ncclDouble, ncclSum, g->comm->comm, g->stream));
+    return small_to_rr_bb(g, rr_bb);
+} CCP_ABI_CATCH
+
+int ccp_grid_gauss_seidel_rowblocked(ccp_grid *g, double epsilon, int32_t max_iteration, int32_t check_every,
+                                     ccp_gs_report *report)
+try {
+    CCP_TRY(bind(g));
+    if (!g->comm) return CCP_ERR_STATE;
+    if (max_iteration < 0 || check_every < 0) return CCP_ERR_BAD_ARG;
+    const RcclApi *api = rccl_api();
+    if (!api) return CCP_ERR_RCCL;
+    const int C = g->desc.channels;
+    const bool nb = has_neighbours(g);
+    const int ipe = std::max(1, g->desc.ghost / 2);
+    double eps[kMaxChannels];
+    int stop_at[kMaxChannels];
+    for (int ch = 0; ch < C; ++ch) {
+        eps[ch] = 10.0;                                   // `double eps = 10` (sparse-matrix.h:354)
+        stop_at[ch] = 0;
+    }
+    CCP_TRY(begin_timing(g));
+    int cnt = 0;
+    auto any_above = [&]() {
+        for (int ch = 0; ch < C; ++ch)
+            if (stop_at[ch] == 0 && eps[ch] > epsilon) return true;
+        return false;
+    };
+    if (check_every == 0) {
+        if (10.0 > epsilon) {
+            CCP_TRY(sweep_rowblocked(g, max_iteration));
+            cnt = max_iteration;
+        }
+    } else {
+        // `while (eps > epsilon && cnt < max_iteration)` (sparse-matrix.h:356) with the step summed over all blocks
+        while (any_above() && cnt < max_iteration) {
+            const int plain = std::min(check_every - 1, max_iteration - cnt);
+            if (plain > 0) {
+                CCP_TRY(sweep_rowblocked(g, plain));
+                cnt += plain;
+            }
+            if (cnt >= max_iteration) break;
+            if (nb && g->half_sweeps_since_refresh / 2 >= ipe) CCP_TRY(exchange(g, false));
+            long blocks[2] = {0, 0};
+            CCP_TRY(one_iteration(g, true, nullptr, blocks));
+            ++cnt;
+            hipLaunchKernelGGL(k_check, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
+                               g->partial.p + g->partial_region, blocks[1], 0.0, 0, static_cast<SolveState *>(nullptr), g->small.p);
+            CCP_HIP(hipGetLastError());
+            CCP_RCCL(api->AllReduce(g->small.p, g->small.p, (size_t)C, ncclDouble, ncclSum, g->comm->comm, g->stream));
+            double host[kMaxChannels];
+            CCP_HIP(hipMemcpyAsync(host, g->small.p, sizeof(double) * C, hipMemcpyDeviceToHost, g->stream));
+            CCP_HIP(hipStreamSynchronize(g->stream));
+            for (int ch = 0; ch < C; ++ch) {
+                if (stop_at[ch]) continue;
+                eps[ch] = host[ch];
+                if (!(eps[ch] > epsilon)) stop_at[ch] = cnt;
+            }
+        }
+    }
+    CCP_TRY(end_timing(g));
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    float ms = 0.f;
+    CCP_HIP(hipEventElapsedTime(&ms, g->ev0, g->ev1));
+    g->last_ms = ms;
+    g->timing_pending = false;
+    if (report) {
+        for (int ch = 0; ch < C; ++ch) {
+            report[ch].converged = stop_at[ch] ? 1 : 0;
+            report[ch].iterations = stop_at[ch] ? stop_at[ch] : cnt;
+            report[ch].last_l1_step = eps[ch];
+            report[ch].seconds = ms * 1e-3;
+        }
+    }
+    return CCP_OK;
+} CCP_ABI_CATCH
+
+int ccp_grid_comm_stats(ccp_grid *g, int64_t *exchanges, int32_t *wait_mode, int32_t *send_up_rows, int32_t *send_down_rows)
+try {
+    if (!g) return CCP_ERR_BAD_ARG;
+    if (exchanges) *exchanges = g->exchanges;
+    if (wait_mode) *wait_mode = g->edge_flag ? g->wait_mode : -1;
+    if (send_up_rows) *send_up_rows = g->send_up;
+    if (send_down_rows) *send_down_rows = g->send_down;
+    return CCP_OK;
+} CCP_ABI_CATCH
+
 int ccp_grid_region_begin(ccp_grid *g)
 try {
     CCP_TRY(bind(g));
@@ -1279,11 +1591,12 @@ try {
         CCP_HIP(hipEventCreate(&g->ev_r1));
     }
     g->region_launches = 0;
+    g->region_iterations = 0;
     CCP_HIP(hipEventRecord(g->ev_r0, g->stream));
     return CCP_OK;
 } CCP_ABI_CATCH
 
-int ccp_grid_region_end(ccp_grid *g, float *milliseconds, int64_t *sweep_launches)
+int ccp_grid_region_end(ccp_grid *g, float *milliseconds, int64_t *sweep_launches, int64_t *pass_iterations)
 try {
     CCP_TRY(bind(g));
     if (!g->ev_r0) return CCP_ERR_STATE;
@@ -1293,6 +1606,7 @@ try {
     CCP_HIP(hipEventElapsedTime(&ms, g->ev_r0, g->ev_r1));
     if (milliseconds) *milliseconds = ms;
     if (sweep_launches) *sweep_launches = g->region_launches;
+    if (pass_iterations) *pass_iterations = g->region_iterations;
     return CCP_OK;
 } CCP_ABI_CATCH
 

@@ -91,7 +91,42 @@ struct FusedParams {
     // is cut into side_subs tiles of side_rows rows: the slow tiles end with the ordinary ones
     int side_rows, side_subs;
     double *__restrict__ partial_border;   // L1 sums of the border launch (same layout, own region)
+    // Row blocks with neighbours (EDGE kernels): chunk 0 / chunk n_chunks-1 hold exactly the owned rows the
+    // upper / lower neighbour's ghost zone takes (first_edge / last_edge).  They are short (first_rows /
+    // last_rows), dispatched first (fused_chunk_of), and every wave that finished one of their tiles counts
+    // itself in *edge_counter; the wave that brings it to edge_target publishes edge_epoch in *edge_flag,
+    // which the halo exchange's stream is waiting for (hipStreamWaitValue64) — so the messages leave while
+    // the rest of the pass is still running.
+    int first_edge, last_edge;
+    unsigned long long *__restrict__ edge_counter;
+    unsigned long long *__restrict__ edge_flag;
+    unsigned long long edge_target, edge_epoch;
 };
+
+// blockIdx.y -> chunk with the edge chunks first (workgroups are dispatched in block-index order)
+__host__ __device__ __forceinline__ int fused_chunk_of(const FusedParams &P, int y)
+{
+    const int n_e = P.first_edge + P.last_edge;
+    if (y < n_e) return (P.first_edge && y == 0) ? 0 : P.n_chunks - 1;
+    return y - n_e + P.first_edge;
+}
+
+__host__ __device__ __forceinline__ bool fused_is_edge_chunk(const FusedParams &P, int chunk)
+{
+    return (P.first_edge && chunk == 0) || (P.last_edge && chunk == P.n_chunks - 1);
+}
+
+// One wave reports a finished edge tile.  Producer side of the hand-off (MI355X_MICROARCH.md, correctness
+// boundaries): the wave's stores are drained and written back at agent scope before it counts itself.
+__device__ __forceinline__ void fused_signal_edge(const FusedParams &P)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        const unsigned long long old = __hip_atomic_fetch_add(P.edge_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1 == P.edge_target)
+            __hip_atomic_store(P.edge_flag, P.edge_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
 
 // rows [ra, rb) of chunk c
 __host__ __device__ __forceinline__ void fused_chunk_rows(const FusedParams &P, int c, int &ra, int &rb)
@@ -413,7 +448,7 @@ __device__ __forceinline__ void fused_write_partials(double (&acc)[AN], double *
 
 // Ordinary tiles.  grid = (ceil(n_strips / 4), n_chunks, channels); block = 256 threads = 4 waves =
 // 4 adjacent strips of one chunk; waves of border tiles leave at once (k_fused_border runs them).
-template <int T, int L1, int UNR>
+template <int T, int L1, int UNR, bool EDGE = false>
 __global__ void __launch_bounds__(kBlock, fused_waves_per_simd(T, L1))
 k_fused_sweep(FusedParams P)
 {
@@ -422,7 +457,7 @@ k_fused_sweep(FusedParams P)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int sx = blockIdx.x * (kBlock / kWave) + wave;
     const int ch = blockIdx.z;
-    const int chunk = blockIdx.y;
+    const int chunk = EDGE ? fused_chunk_of(P, (int)blockIdx.y) : (int)blockIdx.y;
     int ra, rb;
     fused_chunk_rows(P, chunk, ra, rb);
     constexpr int AN = L1 == 2 ? T : 1;
@@ -434,6 +469,7 @@ k_fused_sweep(FusedParams P)
         const Geom &g = P.g;
         const long off = (long)ch * g.ch_stride;
         fused_wave<T, false, L1, UNR, AN>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc);
+        if (EDGE && fused_is_edge_chunk(P, chunk)) fused_signal_edge(P);
     }
     fused_write_partials<L1, AN>(acc, P.partial, ch, scratch);
 }
@@ -442,7 +478,7 @@ k_fused_sweep(FusedParams P)
 // left/right edge), then the left and right strips of every chunk, each cut into side_subs tiles.  grid = (ceil(n_border_tiles / 4), 1, channels).  Runs on
 // a second stream beside k_fused_sweep: its waves take ~2.6x longer at T=8 when a whole trip is
 // border work, and as part of one launch they used to be the tail every small grid waited for.
-template <int T, int L1, int UNR>
+template <int T, int L1, int UNR, bool EDGE = false>
 __global__ void __launch_bounds__(kBlock, fused_border_waves_per_simd(T, L1))
 k_fused_border(FusedParams P, int force_border)
 {
@@ -472,7 +508,7 @@ k_fused_border(FusedParams P, int force_border)
             const int sub = k % P.side_subs;
             k /= P.side_subs;
             const int e = k % edge_strips;
-            chunk = k / edge_strips;
+            chunk = EDGE ? fused_chunk_of(P, k / edge_strips) : k / edge_strips;
             sx = e < P.ns_left ? e : P.n_strips - edge_strips + e;
             int c0, c1;
             fused_chunk_rows(P, chunk, c0, c1);
@@ -483,6 +519,7 @@ k_fused_border(FusedParams P, int force_border)
             const Geom &g = P.g;
             const long off = (long)ch * g.ch_stride;
             fused_wave<T, true, L1, UNR, AN>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc, force_border != 0);
+            if (EDGE && fused_is_edge_chunk(P, chunk)) fused_signal_edge(P);
         }
     }
     fused_write_partials<L1, AN>(acc, P.partial_border, ch, scratch);

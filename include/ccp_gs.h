@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCP_GS_ABI_VERSION 1
+#define CCP_GS_ABI_VERSION 2
 
 typedef enum ccp_status {
     CCP_OK = 0,
@@ -38,7 +38,8 @@ typedef enum ccp_status {
     CCP_ERR_HIP = 3,          /* a HIP runtime call or kernel launch failed                  */
     CCP_ERR_ALLOC = 4,        /* host or device allocation failed                            */
     CCP_ERR_STATE = 5,        /* call sequence error (e.g. solve before upload)              */
-    CCP_ERR_UNSUPPORTED = 6   /* e.g. colouring that is not a proper colouring of the matrix */
+    CCP_ERR_UNSUPPORTED = 6,  /* e.g. colouring that is not a proper colouring of the matrix */
+    CCP_ERR_RCCL = 7          /* RCCL could not be loaded, or a communicator / collective call failed */
 } ccp_status;
 
 /* Sweep ordering of the Gauss-Seidel solve.
@@ -191,12 +192,15 @@ int ccp_grid_randomize_x(ccp_grid *g, uint64_t seed, double lo, double hi);
  * run between two halo refreshes (enforced: CCP_ERR_STATE). */
 int ccp_grid_sweep(ccp_grid *g, int32_t iterations);
 
-/* The same sweeps for a row block with neighbour blocks: the LAST pass finalises the
- * `edge_rows` owned rows next to each neighbour first, on streams of their own, beside the middle of
- * the block, so the halo exchange can overlap the rest of the pass.  Results are identical to
- * ccp_grid_sweep.  ccp_grid_stream_wait_edges makes `hip_stream` (the stream the caller's
- * send/receive is issued on) wait until those rows are final; the handle's own stream already
- * waits for them.  A block without ghost rows: plain ccp_grid_sweep / no-op. */
+/* The same sweeps for a row block with neighbour blocks whose halo exchange the CALLER performs (SURVEY
+ * §8e; the RCCL path inside the library is ccp_grid_sweep_rowblocked): the LAST pass finalises the
+ * `edge_rows` owned rows next to each neighbour first — short edge chunks dispatched first inside the one
+ * launch, whose waves count themselves and publish an epoch in a signal-memory flag — so the exchange can
+ * overlap the rest of the pass.  Results are identical to ccp_grid_sweep.  ccp_grid_stream_wait_edges makes
+ * `hip_stream` (the stream the caller's send/receive is issued on) wait until those rows are final
+ * (hipStreamWaitValue64, or a one-wave polling kernel where that is unsupported); the caller must make the
+ * handle's stream wait for its receives before the next sweep.  A block without ghost rows: plain
+ * ccp_grid_sweep / no-op. */
 int ccp_grid_sweep_edges_first(ccp_grid *g, int32_t iterations, int32_t edge_rows);
 int ccp_grid_stream_wait_edges(ccp_grid *g, void *hip_stream);
 /* Pick the temporal-blocking depth (iterations fused per kernel pass, <= max_t) and the rows a
@@ -245,6 +249,53 @@ int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max
  * entries (may be NULL).  Single-block handles only. */
 int ccp_grid_conjugate_gradient(ccp_grid *g, double epsilon, int32_t max_iteration, ccp_gs_report *report);
 
+/* ----------------------------------------------------------------------------------------
+ * Row blocks across the GPUs of one node (BASELINE configs[3]).  One process (or host
+ * thread) per GPU; each creates a communicator rank and one grid handle owning a contiguous block of
+ * image rows plus `ghost` rows per neighbour side.  The reference has no counterpart — its solver is a
+ * single-threaded loop (sparse-matrix.h:350-380); the call site that would drive this is the per-channel
+ * solve of BuildSolveGradientFusion (PhotoMontage.cpp:428-434).
+ *   id:   rank 0 calls ccp_comm_unique_id and hands the CCP_COMM_ID_BYTES bytes to the other ranks by
+ *         any host channel (file, socket, MPI, torch.distributed ...);
+ *   comm: every rank calls ccp_comm_create(id, rank, world, device) — collective (ncclCommInitRank);
+ *   grid: ccp_grid_create with its row block, ccp_grid_attach_comm (collective: the blocks are checked
+ *         to be the rank-ordered contiguous partition of one image), then the *_rowblocked calls.
+ * Halo exchange: the `ghost` outermost owned rows per side travel to the neighbour's ghost rows once per
+ * ghost/2 iterations (ncclSend/ncclRecv, one group, a stream of their own); in between the ghost rows are
+ * recomputed redundantly, so the owned rows are bit-identical to the single-GPU red-black sweep.  With
+ * overlap on (default) the pass that uses up the ghost rows finishes the rows the neighbours need first,
+ * inside its one launch, and the messages leave while the rest of the pass is still running.
+ * RCCL is bound at run time (librccl.so.1); CCP_ERR_RCCL reports a missing library or a failed call. */
+#define CCP_COMM_ID_BYTES 128
+typedef struct ccp_comm ccp_comm;
+int ccp_comm_unique_id(uint8_t *id_out /* CCP_COMM_ID_BYTES */);
+int ccp_comm_create(const uint8_t *id /* CCP_COMM_ID_BYTES */, int32_t rank, int32_t world, int32_t device, ccp_comm **out);
+int ccp_comm_destroy(ccp_comm *c);
+int ccp_comm_info(ccp_comm *c, int32_t *rank, int32_t *world, int32_t *device, int32_t *rccl_version);
+/* In-place sum / maximum over all ranks of `count` (<= 64) host doubles; synchronises. */
+int ccp_comm_all_reduce_sum(ccp_comm *c, double *values, int32_t count);
+int ccp_comm_all_reduce_max(ccp_comm *c, double *values, int32_t count);
+
+/* Collective over the communicator.  c == NULL detaches.  The communicator must outlive the attachment. */
+int ccp_grid_attach_comm(ccp_grid *g, ccp_comm *c);
+int ccp_grid_set_overlap(ccp_grid *g, int32_t on);
+/* Refresh the ghost rows now (after the caller wrote x, or before reading the ghost rows).  Async. */
+int ccp_grid_exchange_halos(ccp_grid *g);
+/* `iterations` red-black sweeps with the exchanges they need; no stop rule, no host sync.  Precondition:
+ * ghost rows valid (fresh handle after fill/randomize on every rank, or ccp_grid_exchange_halos). */
+int ccp_grid_sweep_rowblocked(ccp_grid *g, int32_t iterations);
+/* SparseMatrix::gaussSeidel's loop (sparse-matrix.h:350-380) on the partitioned system: the L1 step of a
+ * checked sweep is all-reduced, so every rank takes the same decision.  check_every as for
+ * ccp_grid_gauss_seidel.  With several channels all of them run until the last one has met the rule (each
+ * report carries the sweep at which ITS rule fired first). */
+int ccp_grid_gauss_seidel_rowblocked(ccp_grid *g, double epsilon, int32_t max_iteration, int32_t check_every,
+                                     ccp_gs_report *report);
+/* ccp_grid_residual_norm2 summed over all blocks (refreshes stale ghost rows first).  Collective. */
+int ccp_grid_residual_norm2_global(ccp_grid *g, double *rr_bb);
+/* Statistics: exchanges issued; how the exchange waits for the edge rows (0 hipStreamWaitValue64, 1 polling
+ * kernel, -1 no neighbours); rows sent up / down per exchange.  Outputs may be NULL. */
+int ccp_grid_comm_stats(ccp_grid *g, int64_t *exchanges, int32_t *wait_mode, int32_t *send_up_rows, int32_t *send_down_rows);
+
 /* Per-channel sums over the OWNED rows: rr = sum (b - A x)^2, bb = sum b^2 (2*channels
  * doubles: rr[0..ch), bb[0..ch)).  Synchronises. */
 int ccp_grid_residual_norm2(ccp_grid *g, double *rr_bb);
@@ -279,10 +330,11 @@ int ccp_grid_last_timing(ccp_grid *g, float *milliseconds, int32_t *kernel_launc
 /* The same over a caller-chosen region spanning many calls: _begin records a HIP event on the handle's
  * stream, _end records a second one, waits for it and returns the device time between them and the
  * number of sweep launches issued in between (a temporally blocked pass — its ordinary and its border
- * kernel run side by side — counts once; an in-place half-sweep counts once).  bench.py's roofline
- * figure is this time / this count, over exactly the timed steps. */
+ * kernel run side by side — counts once; an in-place half-sweep counts once) and the iterations the
+ * temporally blocked passes among them performed (sum of their depths).  bench.py's roofline figure is
+ * this time / this count, over exactly the timed steps. */
 int ccp_grid_region_begin(ccp_grid *g);
-int ccp_grid_region_end(ccp_grid *g, float *milliseconds, int64_t *sweep_launches);
+int ccp_grid_region_end(ccp_grid *g, float *milliseconds, int64_t *sweep_launches, int64_t *pass_iterations);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libccp_gs.so does not export {name}"
     assert sorted(capi.ABI_SYMBOLS) == declared, "capi.ABI_SYMBOLS out of sync with include/ccp_gs.h"
-    assert lib.ccp_abi_version() == 1
+    assert lib.ccp_abi_version() == 2
 
 
 def test_status_strings():
@@ -56,6 +56,14 @@ def test_bad_arguments_rejected_before_touching_the_device():
     assert lib.ccp_grid_create(ctypes.byref(d), ctypes.byref(h)) == 1
     assert lib.ccp_csr_create(0, None) == 1
     assert lib.ccp_grid_destroy(None) == 0 and lib.ccp_csr_destroy(None) == 0
+    # communicator handles: argument errors come before any RCCL / device work
+    buf = (ctypes.c_uint8 * capi.COMM_ID_BYTES)()
+    assert lib.ccp_comm_create(buf, 0, 1, 0, None) == 1
+    assert lib.ccp_comm_create(None, 0, 1, 0, ctypes.byref(h)) == 1
+    assert lib.ccp_comm_create(buf, 3, 2, 0, ctypes.byref(h)) == 1
+    assert lib.ccp_comm_destroy(None) == 0 and lib.ccp_comm_unique_id(None) == 1
+    assert lib.ccp_grid_attach_comm(None, None) == 1
+    assert "RCCL" in capi.status_string(7)
 
 
 def test_product_package_never_imports_the_oracle():

@@ -32,7 +32,7 @@ def test_bench_contract_line_single_gpu():
     assert d["value"] > 1e10 and d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
     assert "workload" in d["config"]
     assert 0 < d["roofline"]["frac"] <= 1.0 and "traffic" in d["roofline"]       # a fraction of the 8 TB/s peak
-    assert d["roofline"]["launches_timed"] == 2 * 16 // d["config"]["tiling"]["fused_depth"]
+    assert d["roofline"]["launches_timed"] * d["roofline"]["iterations_per_launch"] == 2 * 16
     pc = d["parity_check"]
     assert pc["iterations"] == 48 and pc["abs_sum_equal"] and pc["residual_sums_equal"] and pc["bands_equal"]
     assert "iters_to_1e-5" in d and d["rel_residual_after_timed"][0] == 48

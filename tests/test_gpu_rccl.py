@@ -1,0 +1,164 @@
+"""GPU: the RCCL path behind the C ABI (ccp_comm_*, ccp_grid_*_rowblocked) at world size 1 — the whole
+code path a multi-GPU run takes (communicator init, partition all-gather, zero-neighbour exchange,
+all-reduced stop rule and residual, teardown) on the one GPU a test box has — from Python and from the
+C++ host tests/cpp/rowblock_driver.cpp; plus the in-launch edge hand-off that lets the exchange overlap
+the sweep, exercised with several row blocks on ONE card (halo messages staged by the test)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+@pytest.fixture(scope="module")
+def capi():
+    from coursecomputationalphotography_amd import capi
+    assert capi.device_count() >= 1
+    return capi
+
+
+def make(capi, W, H, C=1, **kw):
+    g = capi.Grid(W, H, C, **kw)
+    g.randomize_x(1234, 0.0, 255.0)
+    g.b_from_x()
+    g.fill_x(1.0)
+    return g
+
+
+def test_world1_full_rccl_path(capi):
+    comm = capi.Comm(capi.comm_unique_id(), 0, 1, 0)
+    info = comm.info()
+    assert info["rank"] == 0 and info["world"] == 1 and info["rccl_version"] >= 20000
+    assert np.array_equal(comm.all_reduce_sum([1.5, -2.0, 3.25]), [1.5, -2.0, 3.25])
+    assert np.array_equal(comm.all_reduce_max([7.0]), [7.0])
+    W, H, C = 1500, 1100, 2
+    ref = make(capi, W, H, C)
+    ref.sweep(21)
+    want = [ref.get_x(ch) for ch in range(C)]
+    rr_w, bb_w = ref.residual_norm2()
+    g = make(capi, W, H, C)
+    g.attach_comm(comm)                                   # all-gather of the (one-block) partition
+    assert g.comm_stats()[1] == -1                        # no neighbours
+    g.exchange_halos()                                    # zero-neighbour exchange
+    g.sweep_rowblocked(21)
+    for ch in range(C):
+        assert np.array_equal(g.get_x(ch), want[ch])
+    rr, bb = g.residual_norm2_global()                    # all-reduce over one rank
+    assert np.array_equal(rr, rr_w) and np.array_equal(bb, bb_w)
+    # the reference loop with its stop rule, step all-reduced: same stop sweep and iterate as the one-GPU entry point
+    eps = 0.75 * float(ref.sweep_l1().max())
+    ref.fill_x(1.0)
+    reps_w = ref.gauss_seidel(eps, 400, 1)
+    g.fill_x(1.0)
+    reps = g.gauss_seidel_rowblocked(eps, 400, 1)
+    stop = max(r.iterations for r in reps_w)
+    assert all(r.converged == 1 for r in reps) and max(r.iterations for r in reps) == stop
+    # a channel keeps iterating until the last one stops (documented): compare the last channel to stop
+    last = int(np.argmax([r.iterations for r in reps_w]))
+    assert np.array_equal(g.get_x(last), ref.get_x(last))
+    assert abs(reps[last].last_l1_step - reps_w[last].last_l1_step) <= 1e-10 * reps_w[last].last_l1_step
+    g.attach_comm(None)
+    g.close()
+    ref.close()
+    comm.close()
+
+
+def test_attach_rejects_a_partition_that_is_not_the_image(capi):
+    comm = capi.Comm(capi.comm_unique_id(), 0, 1, 0)
+    g = capi.Grid(256, 256, 1, 0, 128, 0, 0)             # half the image as the only rank of the communicator
+    with pytest.raises(capi.CcpError) as e:
+        g.attach_comm(comm)
+    assert e.value.status == 1
+    with pytest.raises(capi.CcpError) as e:
+        g.sweep_rowblocked(2)                              # nothing attached
+    assert e.value.status == 5
+    g.close()
+    comm.close()
+
+
+def test_cpp_host_drives_the_row_blocked_path(capi, tmp_path):
+    """tests/cpp/rowblock_driver.cpp: a C++ program that sees only include/ccp_gs.h."""
+    cpp = os.path.join(ROOT, "tests", "cpp")
+    subprocess.check_call(["make", "-C", cpp], stdout=subprocess.DEVNULL)
+    W, H, iters = 2048, 1200, 37
+    out = subprocess.run([os.path.join(cpp, "rowblock_driver"), "1", "0", str(tmp_path / "id.bin"), str(W), str(H), "16", str(iters)],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    tok = out.stdout.split()
+    val = {tok[i]: tok[i + 1] for i in range(0, len(tok) - 1)}
+    g = make(capi, W, H)
+    g.sweep(iters)
+    rr, bb = g.residual_norm2()
+    assert int(val["iterations"]) == iters
+    assert float(val["rr"]) == rr[0] and float(val["bb"]) == bb[0] and float(val["abs"]) == g.abs_sum()[0]
+    g.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"CCP_GS_EDGE_WAIT": "spin"}, {"CCP_GS_EDGE_SIGNAL": "0"}])
+@pytest.mark.parametrize("W,H,parts,ghost,iters", [(16384, 1536, 3, 32, 40), (1000, 300, 2, 8, 13)])
+def test_edge_hand_off_inside_the_launch(capi, monkeypatch, env, W, H, parts, ghost, iters):
+    """Row blocks of one image on ONE card.  Each interval's last pass finishes the rows the neighbours take
+    first and publishes the edge flag from inside the launch; a side stream waits for the flag only
+    (hipStreamWaitValue64, or the polling kernel) and copies those rows into the neighbours' ghost rows
+    while the rest of the pass is still running.  Owned rows must equal the one-block sweep bit for bit —
+    they would not if the flag fired before the edge rows were final."""
+    import torch
+    from coursecomputationalphotography_amd import rowblock
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    whole = make(capi, W, H)
+    whole.sweep(iters)
+    want = whole.get_x()
+    whole.close()
+    rows = rowblock.partition_rows(H, parts)
+    blocks = []
+    for rb, rc in rows:
+        blk = rowblock.GridBlock(W, H, 1, rb, rc, ghost, 0)
+        blk.grid.randomize_x(1234, 0.0, 255.0)
+        blk.grid.b_from_x()
+        blk.grid.fill_x(1.0)
+        blocks.append(blk)
+    ipe = ghost // 2
+    side = [torch.cuda.Stream() for _ in blocks]
+
+    def exchange(after_edges):
+        # neighbour copies on each RECEIVER's side stream, which waits for the SENDER's edge flag
+        for i, blk in enumerate(blocks):
+            gt, gb, own_lo = blk.ghost_top, blk.ghost_bottom, blk.ghost_top
+            own_hi = own_lo + blk.row_count
+            for src, dst_rows, src_rows in ((i - 1, slice(0, gt), None), (i + 1, slice(own_hi, own_hi + gb), None)):
+                if src < 0 or src >= len(blocks):
+                    continue
+                s = blocks[src]
+                s_lo, s_hi = s.ghost_top, s.ghost_top + s.row_count
+                take = s.x_rows[:, s_hi - gt:s_hi] if src == i - 1 else s.x_rows[:, s_lo:s_lo + gb]
+                if after_edges:
+                    s.grid.stream_wait_edges(side[i].cuda_stream)
+                    blk.grid.stream_wait_edges(side[i].cuda_stream)      # and my own pass has started (its input is intact)
+                else:
+                    side[i].wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side[i]):
+                    blk.x_rows[:, dst_rows].copy_(take, non_blocking=True)
+        for i, blk in enumerate(blocks):
+            torch.cuda.current_stream().wait_stream(side[i])
+            blk.halo_refreshed()
+
+    exchange(False)
+    done = 0
+    while done < iters:
+        room = min(ipe, iters - done)
+        if room == ipe:
+            for blk in blocks:
+                blk.sweep_edges_first(room, ghost)
+            exchange(True)
+        else:
+            for blk in blocks:
+                blk.sweep(room)
+        done += room
+    got = np.concatenate([blk.grid.get_x_owned() for blk in blocks])
+    for blk in blocks:
+        blk.close()
+    assert np.array_equal(got, want)
