@@ -6,8 +6,11 @@ the calls raise (``CcpError``) instead of computing anything on the host.
 """
 from __future__ import annotations
 
+import atexit
 import ctypes as C
 import os
+import sys
+import weakref
 from typing import Optional
 
 import numpy as np
@@ -62,25 +65,43 @@ class GridLayout(C.Structure):
 
 _lib: Optional[C.CDLL] = None
 
+# Live handles, closed in dependency order (grids before the communicators they are attached to, both
+# before the HIP / RCCL runtimes unload) if the program exits without closing them itself.
+_live_grids: "weakref.WeakSet" = weakref.WeakSet()
+_live_comms: "weakref.WeakSet" = weakref.WeakSet()
+
+
+def _close_all_at_exit() -> None:
+    for pool in (_live_grids, _live_comms):
+        for h in list(pool):
+            try:
+                h.close()
+            except Exception:
+                pass
+
+
+atexit.register(_close_all_at_exit)
+
 
 def _share_rccl_with_torch() -> None:
     """The same for RCCL, which libccp_gs.so binds at run time by soname (ccp_comm.hpp): inside a Python
     process the HIP runtime is torch's, so the collective library must be the one torch ships with it.
-    Loading torch's copy first makes the soname lookup inside the library find that one."""
+    Importing torch (where it is installed) before the first communicator call loads that copy in torch's
+    own order; the soname lookup inside the library then finds it.  (Loading torch's librccl.so by hand
+    and importing torch LATER in the same process aborts at exit — "double free" in the teardown of the
+    two runtimes — measured on ROCm 7.0/7.2; tools/_tmp history)"""
     import importlib.util
-    if os.environ.get("CCP_GS_NO_TORCH_HIP") or os.environ.get("CCP_GS_RCCL_LIB"):
+    if "torch" in sys.modules or os.environ.get("CCP_GS_NO_TORCH_HIP") or os.environ.get("CCP_GS_RCCL_LIB"):
         return
     try:
         spec = importlib.util.find_spec("torch")
     except (ImportError, ValueError):
         spec = None
-    if spec and spec.origin:
-        cand = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
-        if os.path.exists(cand):
-            try:
-                C.CDLL(cand, mode=C.RTLD_GLOBAL)
-            except OSError:
-                pass
+    if spec is not None:
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
 
 
 def _share_hip_runtime_with_torch() -> None:
@@ -228,6 +249,7 @@ class Comm:
         buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
         check(self.L.ccp_comm_create(buf, rank, world, device, C.byref(self.h)), "ccp_comm_create")
         self.rank, self.world, self.device = rank, world, device
+        _live_comms.add(self)
 
     def info(self):
         r, w, d, v = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
@@ -250,6 +272,8 @@ class Comm:
             self.h = C.c_void_p()
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -271,6 +295,8 @@ class CsrMatrix:
             self.h = C.c_void_p()
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:
@@ -364,6 +390,8 @@ class Grid:
         self.row_begin, self.row_count = row_begin, row_count
         self.first_local_row = row_begin - self.layout.ghost_top       # image row of local row 0
         self.local_rows = self.layout.local_rows
+        self._comm = None
+        _live_grids.add(self)
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:
@@ -371,6 +399,8 @@ class Grid:
             self.h = C.c_void_p()
 
     def __del__(self):
+        if sys is None or sys.is_finalizing():
+            return
         try:
             self.close()
         except Exception:

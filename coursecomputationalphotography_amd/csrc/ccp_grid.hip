@@ -12,6 +12,8 @@
 
 using namespace ccp;
 
+constexpr int kEdgeRing = 64;        // edge-counter slots (one per edge epoch, cleared together every kEdgeRing epochs)
+
 struct ccp_grid {
     ccp_grid_desc desc{};
     Geom geom{};
@@ -27,7 +29,7 @@ struct ccp_grid {
     // neighbours need FIRST, inside the one launch (short edge chunks dispatched first): its waves count
     // themselves in *edge_counter and the last one publishes edge_epoch in *edge_flag (signal memory),
     // which the stream of the halo exchange waits for (ccp_grid_fused.hpp: fused_signal_edge).
-    unsigned long long *edge_counter = nullptr;   // device memory
+    unsigned long long *edge_counter = nullptr;   // device memory: kEdgeRing counters, the pass of epoch e uses slot e % kEdgeRing
     unsigned long long *edge_flag = nullptr;      // hipMallocSignalMemory
     unsigned long long edge_epoch = 0;
     int wait_mode = 0;                   // 0: hipStreamWaitValue64, 1: a one-wave polling kernel (CCP_GS_EDGE_WAIT=spin, or no wait-value support)
@@ -198,7 +200,17 @@ void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P, int edge_rows =
         }
     }
     const int mid = rows - P.first_rows - P.last_rows;
-    P.n_chunks = (mid + R - 1) / R + (P.first_rows > 0) + (P.last_rows > 0);
+    if (P.first_edge || P.last_edge) {
+        // the edge chunks take tile slots too: give the middle correspondingly fewer, taller chunks, so the
+        // pass needs no more rounds on the chip's wave slots than it would without the hand-off (one
+        // workgroup past a whole round costs a round)
+        const int n_whole = (rows + R - 1) / R;
+        const int n_mid = std::max(1, n_whole - P.first_edge - P.last_edge);
+        int r_mid = (mid + n_mid - 1) / n_mid;
+        r_mid += r_mid & 1;
+        P.rows_per_chunk = std::max(R, r_mid);
+    }
+    P.n_chunks = (mid + P.rows_per_chunk - 1) / P.rows_per_chunk + (P.first_rows > 0) + (P.last_rows > 0);
     auto top = [&](int c) { int ra, rb; fused_chunk_rows(P, c, ra, rb); return geo.y0 + ra - HS <= 0; };
     auto bot = [&](int c) { int ra, rb; fused_chunk_rows(P, c, ra, rb); return geo.y0 + rb + HS >= geo.H - 1; };
     P.nb_top = 0;
@@ -246,14 +258,17 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     const int edge_strips = std::min(P.ns_left + P.ns_right, P.n_strips);
     // side-strip tiles: ~2.5x the time per march step of an ordinary tile -> 2/5 of its march length
     {
-        const int HS = 2 * T, R = P.rows_per_chunk;
+        const int HS = 2 * T, R = P.rows_per_chunk;               // (possibly raised by fused_tile_counts for an edge pass)
         int sr = std::max(16, (R + 2 * HS) * 2 / 5 - 2 * HS);
         sr += sr & 1;
         if (g->side_rows_override > 0) sr = std::max(2, g->side_rows_override);
         P.side_rows = std::min(sr, R);
         P.side_subs = (R + P.side_rows - 1) / P.side_rows;
-        // an edge chunk may be taller than R: its side strips still need enough sub-tiles
-        P.side_subs = std::max(P.side_subs, (std::max(P.first_rows, P.last_rows) + P.side_rows - 1) / P.side_rows);
+        // the side strips of an edge chunk are cut finer (their waves march ~2.5x slower and a sub-tile pays
+        // 4T rows of halo march whatever its height: 16 rows end at about half a pass)
+        P.side_rows_edge = std::min(P.side_rows, 16);
+        if (P.first_edge || P.last_edge)
+            P.side_subs = std::max(P.side_subs, (std::max(P.first_rows, P.last_rows) + P.side_rows_edge - 1) / P.side_rows_edge);
     }
     const long n_border = (long)edge_chunks * (P.n_strips - edge_strips) + (long)P.n_chunks * edge_strips * P.side_subs;
     const bool any_plain = edge_chunks < P.n_chunks && edge_strips < P.n_strips;
@@ -277,12 +292,14 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
             if (!fused_is_edge_chunk(P, c)) continue;
             int ra, rb;
             fused_chunk_rows(P, c, ra, rb);
-            const int subs = std::min(P.side_subs, (rb - ra + P.side_rows - 1) / P.side_rows);
+            const int subs = std::min(P.side_subs, (rb - ra + P.side_rows_edge - 1) / P.side_rows_edge);
             waves_expected += (P.n_strips - edge_strips) + (long)edge_strips * subs;
         }
         P.edge_target = (unsigned long long)waves_expected * g->desc.channels;
-        // the counter starts from zero in every edge pass: a miscount can cost one overlap, never the next
-        CCP_HIP(hipMemsetAsync(g->edge_counter, 0, sizeof(unsigned long long), g->stream));
+        // every edge pass counts from zero in a ring slot of its own (a miscount can cost one overlap, never
+        // the next); the whole ring is cleared once per kEdgeRing epochs, off the critical path of a pass
+        if (g->edge_epoch % kEdgeRing == 0) CCP_HIP(hipMemsetAsync(g->edge_counter, 0, sizeof(unsigned long long) * kEdgeRing, g->stream));
+        P.edge_counter = g->edge_counter + (g->edge_epoch % kEdgeRing);
     }
     if (signalled) *signalled = edge;
     constexpr int TC = T <= kFusedMaxCheckedT ? T : 1;       // per-sweep sums exist up to kFusedMaxCheckedT
@@ -292,6 +309,11 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     if (n_border) {
         CCP_HIP(hipEventRecord(g->ev_main, g->stream));
         CCP_HIP(hipStreamWaitEvent(bstream, g->ev_main, 0));
+    }
+    // an EDGE pass issues its border tiles first: the few side-strip waves of the edge chunks must not queue
+    // behind a chip full of ordinary tiles, or the hand-off would come at the end of the pass
+    if (n_border && edge) {
+        hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll, true>), bgrid, dim3(kBlock), 0, bstream, P, g->force_border ? 1 : 0);
     }
     if (any_plain) {
         if (l1 == 2) hipLaunchKernelGGL((k_fused_sweep<TC, 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
@@ -303,8 +325,7 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
         const int fb = g->force_border ? 1 : 0;
         if (l1 == 2) hipLaunchKernelGGL((k_fused_border<TC, 2, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
         else if (l1 == 1) hipLaunchKernelGGL((k_fused_border<T, 1, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
-        else if (edge) hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll, true>), bgrid, dim3(kBlock), 0, bstream, P, fb);
-        else hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
+        else if (!edge) hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
         CCP_HIP(hipEventRecord(g->ev_side, bstream));
         CCP_HIP(hipStreamWaitEvent(g->stream, g->ev_side, 0));
     }
@@ -355,8 +376,12 @@ void edge_epoch_begin(ccp_grid *g) { g->edge_epoch++; }
 int edge_epoch_publish_after_pass(ccp_grid *g)
 {
     if (!g->edge_flag) return CCP_OK;
-    hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(64), 0, g->stream, g->edge_flag, g->edge_epoch);
-    CCP_HIP(hipGetLastError());
+    if (g->wait_mode == 0) {
+        CCP_HIP(hipStreamWriteValue64(g->stream, g->edge_flag, g->edge_epoch, 0));      // a queue packet, no kernel launch
+    } else {
+        hipLaunchKernelGGL(k_publish_flag, dim3(1), dim3(64), 0, g->stream, g->edge_flag, g->edge_epoch);
+        CCP_HIP(hipGetLastError());
+    }
     return CCP_OK;
 }
 
@@ -569,9 +594,9 @@ try {
         g->wait_mode = can_wait ? 0 : 1;
         if (const char *e = getenv("CCP_GS_EDGE_WAIT")) g->wait_mode = (strcmp(e, "spin") == 0) ? 1 : (can_wait ? 0 : 1);
         if (const char *e = getenv("CCP_GS_EDGE_SIGNAL")) g->edge_signal = atoi(e) != 0;
-        if (hipMalloc(reinterpret_cast<void **>(&g->edge_counter), sizeof(unsigned long long)) != hipSuccess ||
+        if (hipMalloc(reinterpret_cast<void **>(&g->edge_counter), sizeof(unsigned long long) * kEdgeRing) != hipSuccess ||
             hipExtMallocWithFlags(reinterpret_cast<void **>(&g->edge_flag), sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess ||
-            hipMemset(g->edge_counter, 0, sizeof(unsigned long long)) != hipSuccess ||
+            hipMemset(g->edge_counter, 0, sizeof(unsigned long long) * kEdgeRing) != hipSuccess ||
             hipMemset(g->edge_flag, 0, sizeof(unsigned long long)) != hipSuccess)
             st = CCP_ERR_HIP;
     }
@@ -1022,7 +1047,9 @@ int lex_run(ccp_grid *g, int iterations, unsigned mask, double *partial)
     const LexGeom &lg = g->lexg;
     const int d_max = lg.n_diag - 1;
     const int C = g->desc.channels;
+    static const int sync_every = getenv("CCP_GS_LEX_SYNC_EVERY") ? atoi(getenv("CCP_GS_LEX_SYNC_EVERY")) : 0;   // profiling aid
     for (int tau = 0; tau <= d_max + 2 * (iterations - 1); ++tau) {
+        if (sync_every > 0 && tau % sync_every == sync_every - 1) CCP_HIP(hipStreamSynchronize(g->stream));
         const int k_lo = std::max(0, (tau - d_max + 1) / 2);          // smallest k with tau - 2k <= d_max
         const int k_hi = std::min(iterations - 1, tau / 2);           // largest k with tau - 2k >= 0
         if (k_hi < k_lo) continue;
@@ -1554,6 +1581,7 @@ try {
                 eps[ch] = host[ch];
                 if (!(eps[ch] > epsilon)) stop_at[ch] = cnt;
             }
+            if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] rowblocked sweep %d: step %.17g (channel 0), epsilon %.17g\n", cnt, eps[0], epsilon);
         }
     }
     CCP_TRY(end_timing(g));

@@ -90,6 +90,7 @@ struct FusedParams {
     // the side strips of the middle chunks march slower per step (kStepSide), so each chunk of them
     // is cut into side_subs tiles of side_rows rows: the slow tiles end with the ordinary ones
     int side_rows, side_subs;
+    int side_rows_edge;                    // sub-tile height in the edge chunks of an EDGE pass: short, so they are final early
     double *__restrict__ partial_border;   // L1 sums of the border launch (same layout, own region)
     // Row blocks with neighbours (EDGE kernels): chunk 0 / chunk n_chunks-1 hold exactly the owned rows the
     // upper / lower neighbour's ghost zone takes (first_edge / last_edge).  They are short (first_rows /
@@ -512,8 +513,9 @@ k_fused_border(FusedParams P, int force_border)
             sx = e < P.ns_left ? e : P.n_strips - edge_strips + e;
             int c0, c1;
             fused_chunk_rows(P, chunk, c0, c1);
-            ra = c0 + sub * P.side_rows;
-            rb = min(ra + P.side_rows, c1);
+            const int sr = (EDGE && fused_is_edge_chunk(P, chunk)) ? P.side_rows_edge : P.side_rows;
+            ra = c0 + sub * sr;
+            rb = min(ra + sr, c1);
         }
         if (ra < rb) {
             const Geom &g = P.g;

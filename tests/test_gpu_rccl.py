@@ -48,18 +48,36 @@ def test_world1_full_rccl_path(capi):
         assert np.array_equal(g.get_x(ch), want[ch])
     rr, bb = g.residual_norm2_global()                    # all-reduce over one rank
     assert np.array_equal(rr, rr_w) and np.array_equal(bb, bb_w)
-    # the reference loop with its stop rule, step all-reduced: same stop sweep and iterate as the one-GPU entry point
-    eps = 0.75 * float(ref.sweep_l1().max())
-    ref.fill_x(1.0)
-    reps_w = ref.gauss_seidel(eps, 400, 1)
-    g.fill_x(1.0)
-    reps = g.gauss_seidel_rowblocked(eps, 400, 1)
-    stop = max(r.iterations for r in reps_w)
-    assert all(r.converged == 1 for r in reps) and max(r.iterations for r in reps) == stop
-    # a channel keeps iterating until the last one stops (documented): compare the last channel to stop
+    g.attach_comm(None)
+    g.close()
+    ref.close()
+    # the reference loop with its stop rule (sparse-matrix.h:356), step all-reduced: same stop sweep and
+    # iterate as the one-GPU entry point (small right-hand sides so that the L1 step falls below eps = 10's scale)
+    from coursecomputationalphotography_amd import synth
+    W, H = 96, 80
+    base = synth.poisson_system(W, H, 1234)[0]
+    ref, g = capi.Grid(W, H, 2), capi.Grid(W, H, 2)
+    for h in (ref, g):
+        h.set_b(base * 1e-3, 0)
+        h.set_b(base * 3e-4, 1)
+        h.fill_x(1.0)
+    g.attach_comm(comm)
+    eps = 0.5
+    reps_w = ref.gauss_seidel(eps, 600, 1)
+    reps = g.gauss_seidel_rowblocked(eps, 600, 1)
+    assert all(r.converged == 1 for r in reps_w) and all(r.converged == 1 for r in reps)
+    assert [r.iterations for r in reps] == [r.iterations for r in reps_w]
+    # all channels run until the last one stops (documented): the channel that stops last is bit-identical
     last = int(np.argmax([r.iterations for r in reps_w]))
     assert np.array_equal(g.get_x(last), ref.get_x(last))
     assert abs(reps[last].last_l1_step - reps_w[last].last_l1_step) <= 1e-10 * reps_w[last].last_l1_step
+    # fixed count, no rule: identical to the plain sweep
+    for h in (ref, g):
+        h.fill_x(1.0)
+    ref.sweep(33)
+    rep = g.gauss_seidel_rowblocked(0.0, 33, 0)[0]
+    assert rep.iterations == 33 and rep.converged == 0
+    assert np.array_equal(g.get_x(0), ref.get_x(0)) and np.array_equal(g.get_x(1), ref.get_x(1))
     g.attach_comm(None)
     g.close()
     ref.close()
