@@ -26,7 +26,7 @@ ORDER_MULTICOLOUR = 1
 # every symbol include/ccp_gs.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "ccp_status_string", "ccp_abi_version", "ccp_device_count",
-    "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_set_colouring", "ccp_csr_get_colouring",
+    "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_set_colouring", "ccp_csr_get_colouring", "ccp_csr_insert", "ccp_csr_edit_stats",
     "ccp_csr_gauss_seidel", "ccp_csr_conjugate_gradient", "ccp_csr_conjugate_gradient_jacobi", "ccp_csr_apply_to_vector", "ccp_csr_residual_norm2",
     "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
@@ -145,6 +145,8 @@ def load() -> C.CDLL:
     L.ccp_csr_upload.argtypes = [vp, i32, i32, i64, vp, vp, vp, vp]
     L.ccp_csr_set_colouring.argtypes = [vp, vp, i32]
     L.ccp_csr_get_colouring.argtypes = [vp, vp, C.POINTER(i32)]
+    L.ccp_csr_insert.argtypes = [vp, i32, i32, dbl]
+    L.ccp_csr_edit_stats.argtypes = [vp] + [C.POINTER(i64)] * 5
     L.ccp_csr_gauss_seidel.argtypes = [vp, vp, vp, vp, dbl, i32, i32, i32, C.POINTER(Report)]
     L.ccp_csr_conjugate_gradient.argtypes = [vp, vp, vp, vp, dbl, i32, C.POINTER(Report)]
     L.ccp_csr_conjugate_gradient_jacobi.argtypes = [vp, vp, vp, dbl, i32, C.POINTER(Report)]
@@ -325,6 +327,15 @@ class CsrMatrix:
         nc = int(colour.max()) + 1 if n_colours is None else n_colours
         check(self.L.ccp_csr_set_colouring(self.h, _ptr(colour), nc), "ccp_csr_set_colouring")
         return self
+
+    def insert(self, val: float, row: int, col: int):
+        """SparseMatrix::insert(val, row, col) on the uploaded matrix (applied on the device incrementally)."""
+        check(self.L.ccp_csr_insert(self.h, row, col, float(val)), "ccp_csr_insert")
+
+    def edit_stats(self):
+        v = [C.c_int64() for _ in range(5)]
+        check(self.L.ccp_csr_edit_stats(self.h, *[C.byref(t) for t in v]), "ccp_csr_edit_stats")
+        return dict(zip(("edits", "image_uploads", "rows_patched", "slices_relocated", "image_rebuilds"), (t.value for t in v)))
 
     def get_colouring(self):
         """(colour[n_rows], n_colours) the multi-colour sweep uses (caller's or the library's greedy one)."""

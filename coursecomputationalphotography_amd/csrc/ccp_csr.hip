@@ -13,6 +13,7 @@
 #include <thread>
 #include <atomic>
 #include <chrono>
+#include <unordered_map>
 
 using namespace ccp;
 
@@ -32,9 +33,22 @@ struct Schedule {
     int max_group_slices = 0;
     int level_span = -1;                 // lexicographic: max level difference of two coupled rows (-1: not a level schedule)
     DevBuf<double> vals;
+    // host mirrors for incremental edits (ccp_csr_insert): where a row lives in the image and how much
+    // room its slice has.  A slice is laid out with kSliceSlack spare entry columns and the arrays end in
+    // a reserve, so that a growing row is patched in place, or its slice moved to the reserve, without
+    // touching the rest of the image.
+    std::vector<int> inv;                // original row -> permuted row
+    std::vector<long> gstart;            // [n_groups+1] first permuted row of each group
+    std::vector<int> group_of;           // original row -> group
+    std::vector<long> h_soff;
+    std::vector<int> h_swidth, h_scap;
+    long entries_used = 0, entries_cap = 0;
+    bool sort_by_permuted = false;
     void reset()
     {
         built = false;
+        inv.clear(); gstart.clear(); group_of.clear(); h_soff.clear(); h_swidth.clear(); h_scap.clear();
+        entries_used = entries_cap = 0;
         n_groups = n_slices = 0;
         group_slice_ptr.clear();
         group_block_off.clear();
@@ -64,6 +78,18 @@ struct ccp_csr {
     int user_n_colours = 0;
     std::vector<int> used_colour;          // the colouring the multi-colour schedule was built from
     int used_n_colours = 0;
+    // Incremental edits (ccp_csr_insert; SparseMatrix::insert, sparse-matrix.h:183-247).  An edited row's
+    // whole current content lives in `overlay` (the compact arrays above stay as uploaded until a schedule
+    // has to be built again: materialise()); `touched` rows are re-laid in the device images before the
+    // next solve (flush_edits).
+    struct RowContent { std::vector<int> col; std::vector<double> val; };
+    std::unordered_map<int, RowContent> overlay;
+    std::vector<int> touched;
+    long stat_uploads = 0, stat_rows_patched = 0, stat_slices_relocated = 0, stat_schedule_rebuilds = 0, stat_edits = 0;
+    DevBuf<long> patch_base;
+    DevBuf<int> patch_cap, patch_cols;
+    DevBuf<long> patch_off;
+    DevBuf<double> patch_vals;
     Schedule natural;        // identity order, one group: SpMV / residual
     Schedule multicolour;    // colour-major, columns sorted by permuted index (reference on P A P^T)
     Schedule lexicographic;  // level-major, original storage order kept inside a row
@@ -77,6 +103,7 @@ struct ccp_csr {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     // structured-matrix detection: -1 unknown, 0 not the SolveChannel Poisson matrix, else W
     int poisson_w = -1, poisson_h = 0;
+    int compact_poisson_w = -1, compact_poisson_h = 0;   // the same question for the compact host copy alone (cached)
     ccp_grid *grid = nullptr;              // matrix-free twin used when the matrix is that Poisson matrix
     bool allow_structured = true;
     bool allow_one_block = true;           // CCP_GS_ONE_BLOCK=0: always one launch per group
@@ -246,8 +273,13 @@ int upload_vec(DevBuf<T> &d, const std::vector<T> &h, hipStream_t s)
 // Build the sliced-ELL image for rows ordered by `group` (stable: ascending row index inside a
 // group).  sort_by_permuted: order a row's entries by their PERMUTED column (what the reference
 // would see on P A P^T); otherwise keep the original storage order.
+constexpr int kSliceSlack = 2;          // spare entry columns per slice (never read: kernels stop at the live width)
+
+int materialise(ccp_csr *m);
+
 int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int n_groups, bool sort_by_permuted)
 {
+    CCP_TRY(materialise(m));             // pending edits go into the compact host copy first
     const int n = m->n_rows;
     const double t_begin = now_s();
     std::vector<long> gcount((size_t)n_groups + 1, 0);
@@ -264,7 +296,7 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
     auto map_col = [&](int c) { return (c >= 0 && c < n) ? inv[c] : c; };
 
     const double t_perm = now_s();
-    std::vector<int> srow0, srows, swidth;
+    std::vector<int> srow0, srows, swidth, scap;
     std::vector<long> soff;
     sc.group_slice_ptr.assign((size_t)n_groups + 1, 0);
     sc.group_block_off.assign((size_t)n_groups + 1, 0);
@@ -280,8 +312,9 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
             srow0.push_back((int)r);
             srows.push_back(rows);
             swidth.push_back(width);
+            scap.push_back(width + kSliceSlack);
             soff.push_back(total);
-            total += (long)width * kWave;
+            total += (long)(width + kSliceSlack) * kWave;
         }
         sc.group_slice_ptr[g + 1] = (int)srow0.size();
         const int slices = sc.group_slice_ptr[g + 1] - sc.group_slice_ptr[g];
@@ -291,6 +324,8 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
     sc.n_groups = n_groups;
     const double t_fill0 = now_s();
     // uninitialised on purpose: every element is written below, by the thread that first touches its page
+    // the arrays end in a reserve that relocated (grown) slices move into
+    const long reserve = std::max<long>(1L << 16, total / 64);
     const size_t n_entries = (size_t)std::max<long>(total, 1);
     std::unique_ptr<int[]> cols(new int[n_entries]);
     std::unique_ptr<double[]> vals(new double[n_entries]);
@@ -298,7 +333,7 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
         std::vector<std::pair<int, double>> tmp;
         for (long s = s_lo; s < s_hi; ++s) {
             // padding: column -1, value 0
-            const size_t base = (size_t)soff[s], len = (size_t)swidth[s] * kWave;
+            const size_t base = (size_t)soff[s], len = (size_t)scap[s] * kWave;
             std::fill(cols.get() + base, cols.get() + base + len, -1);
             std::fill(vals.get() + base, vals.get() + base + len, 0.0);
             for (int t = 0; t < srows[s]; ++t) {
@@ -334,8 +369,8 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
         cols[0] = -1;
         vals[0] = 0.0;
     }
-    CCP_TRY(sc.cols.alloc(n_entries));
-    CCP_TRY(sc.vals.alloc(n_entries));
+    CCP_TRY(sc.cols.alloc(n_entries + (size_t)reserve));
+    CCP_TRY(sc.vals.alloc(n_entries + (size_t)reserve));
     CCP_HIP(hipMemcpyAsync(sc.cols.p, cols.get(), n_entries * sizeof(int), hipMemcpyHostToDevice, m->stream));
     CCP_HIP(hipMemcpyAsync(sc.vals.p, vals.get(), n_entries * sizeof(double), hipMemcpyHostToDevice, m->stream));
     CCP_TRY(upload_vec(sc.perm, perm, m->stream));
@@ -348,44 +383,113 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
     if (getenv("CCP_GS_DEBUG"))
         fprintf(stderr, "[ccp_gs] schedule of %d slices: permutation %.3f s, slice table %.3f s, fill %.3f s, upload %.3f s\n",
                 sc.n_slices, t_perm - t_begin, t_fill0 - t_perm, t_fill1 - t_fill0, now_s() - t_fill1);
+    sc.inv.swap(inv);
+    sc.gstart.swap(gcount);
+    sc.group_of = group;
+    sc.h_soff.swap(soff);
+    sc.h_swidth.swap(swidth);
+    sc.h_scap.swap(scap);
+    sc.entries_used = total;
+    sc.entries_cap = (long)n_entries + reserve;
+    sc.sort_by_permuted = sort_by_permuted;
+    m->stat_uploads++;
     sc.built = true;
+    return CCP_OK;
+}
+
+// Current content of row i: the overlay if the row was edited since the upload, else the compact copy.
+struct RowView { const int *col; const double *val; long len; };
+RowView row_view(const ccp_csr *m, int i)
+{
+    auto it = m->overlay.find(i);
+    if (it != m->overlay.end()) return RowView{it->second.col.data(), it->second.val.data(), (long)it->second.col.size()};
+    const long a = m->row_ptr[i];
+    return RowView{m->col.data() + a, m->val.data() + a, m->row_ptr[i + 1] - a};
+}
+
+// Merge the overlay into the compact host copy (one pass over the matrix; only when a schedule has to be
+// built from scratch again — never on the edit-and-solve path).
+int materialise(ccp_csr *m)
+{
+    if (m->overlay.empty()) return CCP_OK;
+    const int n = m->n_rows;
+    std::vector<long> ptr((size_t)n + 1, 0);
+    for (int i = 0; i < n; ++i) ptr[i + 1] = ptr[i] + row_view(m, i).len;
+    std::vector<int> col((size_t)ptr[n]);
+    std::vector<double> val((size_t)ptr[n]);
+    parallel_ranges(n, 1 << 15, [&](long lo, long hi) {
+        for (long i = lo; i < hi; ++i) {
+            const RowView r = row_view(m, (int)i);
+            if (!r.len) continue;
+            std::memcpy(&col[ptr[i]], r.col, sizeof(int) * (size_t)r.len);
+            std::memcpy(&val[ptr[i]], r.val, sizeof(double) * (size_t)r.len);
+        }
+    });
+    m->row_ptr.swap(ptr);
+    m->col.swap(col);
+    m->val.swap(val);
+    m->overlay.clear();
+    m->compact_poisson_w = -1;
+    m->poisson_w = -1;
     return CCP_OK;
 }
 
 // Is this exactly the matrix SolveChannel assembles (closed form) for some W x H?
 // Row 0 of that matrix is [3 @0, -1 @1, -1 @W], which fixes W; then every row is compared.
+bool row_is_poisson(int W, int H, int i, const RowView &rv)
+{
+    const int x = i % W, y = i / W;
+    auto cell = [&](int cx, int cy) { return cx >= 0 && cy >= 0 && cx < W - 1 && cy < H - 1; };
+    const bool up = cell(x, y - 1), left = cell(x - 1, y), here = cell(x, y);
+    const int diag = (int)up + (int)left + 2 * (int)here + (i == 0 ? 1 : 0);
+    long k = 0;
+    const long end = rv.len;
+    auto next_is = [&](int c, double v) {
+        if (k >= end || rv.col[k] != c || rv.val[k] != v) return false;
+        ++k;
+        return true;
+    };
+    if (up && !next_is(i - W, -1.0)) return false;
+    if (left && !next_is(i - 1, -1.0)) return false;
+    if (diag && !next_is(i, (double)diag)) return false;
+    if (here && (!next_is(i + 1, -1.0) || !next_is(i + W, -1.0))) return false;
+    return k == end;
+}
+
 void detect_poisson(ccp_csr *m)
 {
     if (m->poisson_w >= 0) return;
     m->poisson_w = 0;
     const int n = m->n_rows;
     if (n < 4 || m->n_cols != n) return;
-    if (m->row_ptr[1] - m->row_ptr[0] != 3) return;
-    const int W = m->col[m->row_ptr[0] + 2];
-    if (W < 2 || n % W != 0) return;
-    const int H = n / W;
-    if (H < 2) return;
-    auto cell = [&](int x, int y) { return x >= 0 && y >= 0 && x < W - 1 && y < H - 1; };
-    for (int y = 0; y < H; ++y)
-        for (int x = 0; x < W; ++x) {
-            const int i = y * W + x;
-            const bool up = cell(x, y - 1), left = cell(x - 1, y), here = cell(x, y);
-            const int diag = (int)up + (int)left + 2 * (int)here + (i == 0 ? 1 : 0);
-            long k = m->row_ptr[i];
-            const long end = m->row_ptr[i + 1];
-            auto next_is = [&](int c, double v) {
-                if (k >= end || m->col[k] != c || m->val[k] != v) return false;
-                ++k;
-                return true;
-            };
-            if (up && !next_is(i - W, -1.0)) return;
-            if (left && !next_is(i - 1, -1.0)) return;
-            if (diag && !next_is(i, (double)diag)) return;
-            if (here && (!next_is(i + 1, -1.0) || !next_is(i + W, -1.0))) return;
-            if (k != end) return;
+    // the compact host copy is examined once (cached); rows edited since are examined on top of it
+    if (m->compact_poisson_w < 0) {
+        m->compact_poisson_w = 0;
+        const long len0 = m->row_ptr[1] - m->row_ptr[0];
+        const int W = len0 == 3 ? m->col[m->row_ptr[0] + 2] : 0;
+        if (W >= 2 && n % W == 0 && n / W >= 2) {
+            const int H = n / W;
+            std::atomic<int> bad{0};
+            parallel_ranges(n, 1 << 16, [&](long lo, long hi) {
+                for (long i = lo; i < hi && !bad.load(std::memory_order_relaxed); ++i) {
+                    const long a = m->row_ptr[i];
+                    if (!row_is_poisson(W, H, (int)i, RowView{m->col.data() + a, m->val.data() + a, m->row_ptr[i + 1] - a}))
+                        bad.store(1, std::memory_order_relaxed);
+                }
+            });
+            if (!bad.load()) {
+                m->compact_poisson_w = W;
+                m->compact_poisson_h = H;
+            }
         }
-    m->poisson_w = W;
-    m->poisson_h = H;
+    }
+    if (m->compact_poisson_w <= 0) return;
+    for (const auto &kv : m->overlay)
+        if (!row_is_poisson(m->compact_poisson_w, m->compact_poisson_h, kv.first,
+                            RowView{kv.second.col.data(), kv.second.val.data(), (long)kv.second.col.size()}))
+            return;
+    m->poisson_w = m->compact_poisson_w;
+    m->poisson_h = m->compact_poisson_h;
 }
 
 // The user colouring (if any) must be the grid's red-black colouring with pixel 0 red, because
@@ -403,6 +507,7 @@ bool colouring_is_checkerboard(const ccp_csr *m)
 int ensure_natural(ccp_csr *m)
 {
     if (m->natural.built) return CCP_OK;
+    CCP_TRY(materialise(m));
     std::vector<int> group((size_t)m->n_rows, 0);
     return build_schedule(m, m->natural, group, m->n_rows ? 1 : 0, false);
 }
@@ -410,6 +515,7 @@ int ensure_natural(ccp_csr *m)
 int ensure_multicolour(ccp_csr *m)
 {
     if (m->multicolour.built) return CCP_OK;
+    CCP_TRY(materialise(m));
     const double t0 = now_s();
     std::vector<int> colour;
     int nc;
@@ -446,6 +552,7 @@ int ensure_multicolour(ccp_csr *m)
 int ensure_lexicographic(ccp_csr *m)
 {
     if (m->lexicographic.built) return CCP_OK;
+    CCP_TRY(materialise(m));
     std::vector<long> lptr;
     std::vector<int> lidx;
     build_lower(m, lptr, lidx);
@@ -461,6 +568,118 @@ int ensure_lexicographic(ccp_csr *m)
     CCP_TRY(build_schedule(m, m->lexicographic, level, nl, false));
     m->lexicographic.level_span = span;
     if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] level schedule: %d levels, span %d\n", nl, span);
+    return CCP_OK;
+}
+
+// ---- incremental edits -------------------------------------------------------------------------------
+// Where original row i lives in a schedule's image.
+void locate(const Schedule &sc, int i, int &slice, int &lane)
+{
+    const int p = sc.inv[i], g = sc.group_of[i];
+    const long in_group = p - sc.gstart[g];
+    slice = sc.group_slice_ptr[g] + (int)(in_group / kWave);
+    lane = (int)(in_group % kWave);
+}
+
+// May the edited row keep its place in this schedule?  Every coupled pair must still be ordered the way
+// the schedule promises: different colours (multi-colour); 0 < level(hi) - level(lo) <= span for lo < hi
+// (level schedule, pipelined over sweeps); anything goes for the identity order of the SpMV.
+bool row_still_fits(const ccp_csr *m, const Schedule &sc, int kind, int i, const RowView &r)
+{
+    if (kind == 0) return true;
+    for (long k = 0; k < r.len; ++k) {
+        const int c = r.col[k];
+        if (c == i || c < 0 || c >= m->n_rows) continue;
+        if (kind == 1) {
+            if (sc.group_of[c] == sc.group_of[i]) return false;
+        } else {
+            const int lo = std::min(i, c), hi = std::max(i, c);
+            const int d = sc.group_of[hi] - sc.group_of[lo];
+            if (d <= 0 || d > std::max(sc.level_span, 1)) return false;
+        }
+    }
+    return true;
+}
+
+// Re-lay the touched rows in every built image: one batched patch kernel per image, slices that outgrew
+// their spare columns move into the reserve at the end of the arrays; an image whose ordering a new
+// coupling breaks (same colour, wrong level) or whose reserve is used up is dropped and rebuilt from the
+// host copy at the next solve that needs it.
+int flush_edits(ccp_csr *m)
+{
+    if (m->touched.empty()) return CCP_OK;
+    std::sort(m->touched.begin(), m->touched.end());
+    m->touched.erase(std::unique(m->touched.begin(), m->touched.end()), m->touched.end());
+    Schedule *scs[3] = {&m->natural, &m->multicolour, &m->lexicographic};
+    for (int kind = 0; kind < 3; ++kind) {
+        Schedule &sc = *scs[kind];
+        if (!sc.built) continue;
+        std::vector<long> base, off;
+        std::vector<int> cap, pc;
+        std::vector<double> pv;
+        std::vector<std::pair<int, double>> tmp;
+        bool drop = false;
+        for (int i : m->touched) {
+            const RowView r = row_view(m, i);
+            if (!row_still_fits(m, sc, kind, i, r)) {
+                drop = true;
+                break;
+            }
+            int s, lane;
+            locate(sc, i, s, lane);
+            if (r.len > sc.h_scap[s]) {                       // the slice needs more entry columns: move it to the reserve
+                const int new_cap = (int)r.len + kSliceSlack;
+                if (sc.entries_used + (long)new_cap * kWave > sc.entries_cap) {
+                    drop = true;
+                    break;
+                }
+                const long dst = sc.entries_used;
+                hipLaunchKernelGGL(k_move_slice, dim3(1), dim3(kWave), 0, m->stream, sc.cols.p, sc.vals.p, sc.h_soff[s], dst,
+                                   sc.h_swidth[s], new_cap);
+                CCP_HIP(hipGetLastError());
+                CCP_HIP(hipMemcpyAsync(sc.slice_off.p + s, &dst, sizeof(long), hipMemcpyHostToDevice, m->stream));
+                CCP_HIP(hipStreamSynchronize(m->stream));     // `dst` lives on this stack frame
+                sc.h_soff[s] = dst;
+                sc.h_scap[s] = new_cap;
+                sc.entries_used += (long)new_cap * kWave;
+                m->stat_slices_relocated++;
+            }
+            if (r.len > sc.h_swidth[s]) {                     // the live width only ever grows (padding is skipped by the kernels)
+                sc.h_swidth[s] = (int)r.len;
+                CCP_HIP(hipMemcpyAsync(sc.slice_width.p + s, &sc.h_swidth[s], sizeof(int), hipMemcpyHostToDevice, m->stream));
+            }
+            tmp.clear();
+            for (long k = 0; k < r.len; ++k) {
+                const int c = r.col[k];
+                tmp.emplace_back((c >= 0 && c < m->n_rows) ? sc.inv[c] : c, r.val[k]);
+            }
+            if (sc.sort_by_permuted) std::stable_sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+            base.push_back(sc.h_soff[s] + lane);
+            cap.push_back(sc.h_scap[s]);
+            off.push_back((long)pc.size());
+            for (int k = 0; k < sc.h_scap[s]; ++k) {
+                const bool live = k < (int)tmp.size();
+                pc.push_back(live ? tmp[k].first : -1);
+                pv.push_back(live ? tmp[k].second : 0.0);
+            }
+        }
+        if (drop) {
+            sc.reset();
+            m->stat_schedule_rebuilds++;
+            continue;
+        }
+        CCP_TRY(upload_vec(m->patch_base, base, m->stream));
+        CCP_TRY(upload_vec(m->patch_cap, cap, m->stream));
+        CCP_TRY(upload_vec(m->patch_off, off, m->stream));
+        CCP_TRY(upload_vec(m->patch_cols, pc, m->stream));
+        CCP_TRY(upload_vec(m->patch_vals, pv, m->stream));
+        hipLaunchKernelGGL(k_patch_rows, dim3((unsigned)base.size()), dim3(kWave), 0, m->stream, sc.cols.p, sc.vals.p, m->patch_base.p,
+                           m->patch_cap.p, m->patch_off.p, m->patch_cols.p, m->patch_vals.p);
+        CCP_HIP(hipGetLastError());
+        CCP_HIP(hipStreamSynchronize(m->stream));             // host vectors die at scope exit
+        m->stat_rows_patched += (long)base.size();
+    }
+    m->touched.clear();
     return CCP_OK;
 }
 
@@ -551,8 +770,11 @@ try {
     m->user_n_colours = 0;
     m->used_colour.clear();
     m->used_n_colours = 0;
+    m->overlay.clear();
+    m->touched.clear();
     m->poisson_w = -1;
     m->poisson_h = 0;
+    m->compact_poisson_w = -1;
     if (m->grid) ccp_grid_destroy(m->grid);
     m->grid = nullptr;
     if (const char *e = getenv("CCP_GS_STRUCTURED")) m->allow_structured = atoi(e) != 0;
@@ -585,10 +807,65 @@ try {
     return CCP_OK;
 } CCP_ABI_CATCH
 
+int ccp_csr_insert(ccp_csr *m, int32_t row, int32_t col, double val)
+try {
+    if (!m) return CCP_ERR_BAD_ARG;
+    if (!m->uploaded) return CCP_ERR_STATE;
+    if (row < 0 || row >= m->n_rows || col < 0 || col >= m->n_cols) return CCP_ERR_BAD_ARG;
+    // the row's current content, copied into the overlay on its first edit
+    auto it = m->overlay.find(row);
+    if (it == m->overlay.end()) {
+        const RowView r = row_view(m, row);
+        ccp_csr::RowContent rc;
+        rc.col.assign(r.col, r.col + r.len);
+        rc.val.assign(r.val, r.val + r.len);
+        it = m->overlay.emplace(row, std::move(rc)).first;
+    }
+    std::vector<int> &c = it->second.col;
+    std::vector<double> &v = it->second.val;
+    const auto pos = std::lower_bound(c.begin(), c.end(), col);      // live entries of a row are sorted by column
+    const size_t k = (size_t)(pos - c.begin());
+    const bool present = pos != c.end() && *pos == col;
+    bool changed = false;
+    if (val == 0.0) {                                                // insertZero (:183-200): the entry becomes slack
+        if (present) {
+            c.erase(pos);
+            v.erase(v.begin() + (long)k);
+            changed = true;
+        }
+    } else if (present) {                                            // insertNoneZero (:206-212): overwrite in place
+        changed = v[k] != val;
+        v[k] = val;
+    } else {                                                         // (:214-233): a new live entry, kept in column order
+        c.insert(pos, col);
+        v.insert(v.begin() + (long)k, val);
+        changed = true;
+    }
+    m->stat_edits++;
+    if (changed) {
+        m->touched.push_back(row);
+        m->poisson_w = -1;                                           // the structured twin must be recognised again
+    }
+    return CCP_OK;
+} CCP_ABI_CATCH
+
+int ccp_csr_edit_stats(ccp_csr *m, int64_t *edits, int64_t *image_uploads, int64_t *rows_patched, int64_t *slices_relocated,
+                       int64_t *image_rebuilds)
+try {
+    if (!m) return CCP_ERR_BAD_ARG;
+    if (edits) *edits = m->stat_edits;
+    if (image_uploads) *image_uploads = m->stat_uploads;
+    if (rows_patched) *rows_patched = m->stat_rows_patched;
+    if (slices_relocated) *slices_relocated = m->stat_slices_relocated;
+    if (image_rebuilds) *image_rebuilds = m->stat_schedule_rebuilds;
+    return CCP_OK;
+} CCP_ABI_CATCH
+
 int ccp_csr_get_colouring(ccp_csr *m, int32_t *colour, int32_t *n_colours)
 try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
+    CCP_TRY(flush_edits(m));
     if (!n_colours) return CCP_ERR_BAD_ARG;
     CCP_TRY(ensure_multicolour(m));          // colours the rows now if no solve has done so yet
     *n_colours = m->used_n_colours;
@@ -601,6 +878,7 @@ int ccp_csr_gauss_seidel(ccp_csr *m, const double *b, const double *x0, double *
 try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
+    CCP_TRY(flush_edits(m));
     if (!b || !x_out || check_every < 0) return CCP_ERR_BAD_ARG;
     if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;   // the reference asserts len(b) == n_cols and sizes x from b
     if (ordering != CCP_ORDER_LEXICOGRAPHIC && ordering != CCP_ORDER_MULTICOLOUR) return CCP_ERR_BAD_ARG;
@@ -805,6 +1083,7 @@ int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, 
 try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
+    CCP_TRY(flush_edits(m));
     if (!b || !x_out) return CCP_ERR_BAD_ARG;
     if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;
     if (m->allow_structured) {
@@ -866,6 +1145,7 @@ int ccp_csr_conjugate_gradient_jacobi(ccp_csr *m, const double *b, double *x_out
 try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
+    CCP_TRY(flush_edits(m));
     if (!b || !x_out) return CCP_ERR_BAD_ARG;
     if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;
     CCP_TRY(ensure_natural(m));
@@ -881,6 +1161,7 @@ try {
     CCP_TRY(ensure_partial(m, std::max<long>(2048, spmv_blocks)));
     if (m->cg_partial2.n != 4096) CCP_TRY(m->cg_partial2.alloc(4096));
     // extractDiagnolColInv (sparse-matrix.h:472-491): 1/a_ii of the first stored diagonal entry, 1 if absent or 0
+    CCP_TRY(materialise(m));
     std::vector<double> inv((size_t)std::max<long>(n, 1), 1.0);
     parallel_ranges(n, 1 << 16, [&](long lo, long hi) {
         for (long i = lo; i < hi; ++i)
@@ -916,6 +1197,7 @@ int ccp_csr_apply_to_vector(ccp_csr *m, const double *in, double *out)
 try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
+    CCP_TRY(flush_edits(m));
     if ((m->n_cols && !in) || (m->n_rows && !out)) return CCP_ERR_BAD_ARG;
     CCP_TRY(ensure_natural(m));
     hipStream_t s = m->stream;
@@ -936,6 +1218,7 @@ int ccp_csr_residual_norm2(ccp_csr *m, const double *b, const double *x, double 
 try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
+    CCP_TRY(flush_edits(m));
     if (!b || !x || !rr || !bb) return CCP_ERR_BAD_ARG;
     CCP_TRY(ensure_natural(m));
     hipStream_t s = m->stream;

@@ -219,6 +219,32 @@ k_reduce_to(const double *__restrict__ partial, long count, long stride, double 
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + t : t;
 }
 
+// Incremental edits (ccp_csr_insert).  One block per patched row: write the row's `cap` entry slots
+// (entry k at base + k*64; beyond the row's live entries the patch carries padding: column -1, value 0).
+__global__ void __launch_bounds__(kWave)
+k_patch_rows(int *__restrict__ cols, double *__restrict__ vals, const long *__restrict__ base, const int *__restrict__ cap,
+             const long *__restrict__ off, const int *__restrict__ pcols, const double *__restrict__ pvals)
+{
+    const long b = base[blockIdx.x], o = off[blockIdx.x];
+    for (int k = threadIdx.x; k < cap[blockIdx.x]; k += kWave) {
+        cols[b + (long)k * kWave] = pcols[o + k];
+        vals[b + (long)k * kWave] = pvals[o + k];
+    }
+}
+
+// Move one slice (64 lanes x `width` live entry columns) to a block of `new_cap` columns at `dst`, padding
+// the new spare columns.  One block of 64 threads.
+__global__ void __launch_bounds__(kWave)
+k_move_slice(int *__restrict__ cols, double *__restrict__ vals, long src, long dst, int width, int new_cap)
+{
+    const int lane = threadIdx.x;
+    for (int k = 0; k < new_cap; ++k) {
+        const bool live = k < width;
+        cols[dst + (long)k * kWave + lane] = live ? cols[src + (long)k * kWave + lane] : -1;
+        vals[dst + (long)k * kWave + lane] = live ? vals[src + (long)k * kWave + lane] : 0.0;
+    }
+}
+
 __global__ void k_csr_check(CsrSolveState *__restrict__ st, double epsilon, int sweep_index)
 {
     if (threadIdx.x == 0 && blockIdx.x == 0 && st->active) {

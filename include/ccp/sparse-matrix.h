@@ -12,6 +12,7 @@
 //     The default ordering is ccp::Ordering::Lexicographic — bit-identical to the reference —
 //     and ccp::Ordering::MultiColour is the fast red-black / multi-colour sweep, identical to
 //     the reference applied to the colour-major permuted matrix.
+//   * insert() on a matrix that is already on the device is applied there incrementally (no re-upload).
 //   * insert() implements the semantics the reference's own test asserts (CheckEqual against a
 //     dense mirror, main6.cc:19-33).  The reference's memmove counts lose or expose entries on
 //     general input (sparse-matrix.h:196-198,219-221); this facade keeps rows sorted and exact.
@@ -174,11 +175,31 @@ public:
     // ---- modification -------------------------------------------------------------------------
     void insert(const T &val, Index row, Index col) { insert(T(val), row, col); }
 
+    // Reference: sparse-matrix.h:183-247.  Once the matrix is on the device an edit inside its shape is
+    // forwarded (ccp_csr_insert) and applied there incrementally — the rows touched are re-laid in their
+    // slices before the next solve; nothing is uploaded again.  An edit that grows the shape re-uploads.
     void insert(T &&val, Index row, Index col)
     {
-        dirty_ = true;
+        const double as_double = static_cast<double>(val);
+        const bool inside = row >= 0 && row < n_rows_ && col >= 0 && col < n_cols_;
         if (val == T(0)) erase(row, col);
         else put(std::move(val), row, col);
+        if (dev_ && !dirty_ && inside) ccp::throw_on(ccp_csr_insert(dev_, row, col, as_double), "ccp_csr_insert");
+        else dirty_ = true;
+    }
+
+    // How the device copy has been maintained so far: whole images built and uploaded, rows patched in
+    // place, slices moved to the reserve, images dropped for a rebuild (ccp_csr_edit_stats).
+    struct DeviceEditStats { long long edits, image_uploads, rows_patched, slices_relocated, image_rebuilds; };
+    DeviceEditStats deviceEditStats() const
+    {
+        DeviceEditStats st{0, 0, 0, 0, 0};
+        if (dev_) {
+            int64_t v[5] = {0, 0, 0, 0, 0};
+            ccp::throw_on(ccp_csr_edit_stats(dev_, &v[0], &v[1], &v[2], &v[3], &v[4]), "ccp_csr_edit_stats");
+            st = DeviceEditStats{v[0], v[1], v[2], v[3], v[4]};
+        }
+        return st;
     }
 
     void initializeFromTriplets(Triplet *a, Index cnt)

@@ -89,6 +89,19 @@ int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values,
  * raster mask gets its checkerboard). */
 int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours);
 
+/* SparseMatrix::insert(val, row, col) (sparse-matrix.h:183-247) on the uploaded matrix: val == 0 removes the
+ * entry (insertZero: it becomes slack), an existing entry is overwritten, a new one is inserted in column
+ * order (insertNoneZero).  The edit is applied to the device images of the matrix incrementally before the
+ * next solve: the rows touched are re-laid in their slices by one small kernel (a slice has spare entry
+ * columns; one that outgrows them moves to a reserve at the end of the arrays) — no re-upload and no new
+ * schedule.  Only a new coupling that breaks the ordering a schedule promises (two rows of one colour, a
+ * level out of order) drops THAT image, which is rebuilt at the next solve that needs it.  row/col must be
+ * inside the uploaded shape.  ccp_csr_edit_stats: edits received, whole images built and uploaded, rows
+ * patched, slices relocated, images dropped for a rebuild (outputs may be NULL). */
+int ccp_csr_insert(ccp_csr *m, int32_t row, int32_t col, double val);
+int ccp_csr_edit_stats(ccp_csr *m, int64_t *edits, int64_t *image_uploads, int64_t *rows_patched, int64_t *slices_relocated,
+                       int64_t *image_rebuilds);
+
 /* The colouring the multi-colour sweep uses (the caller's, or the library's greedy one): colour[i]
  * for every row (n_rows entries; may be NULL to ask for the count only).  With it a caller can hand
  * the reference gaussSeidel the same permuted matrix P A P^T and compare iterate for iterate. */

@@ -443,6 +443,22 @@ class Ref:
                                              _i32([o[0] for o in ops]), len(ops), n_rows, n_cols, out)
         return out
 
+    def lab3_modify_bench(self, rows, cols, vals, mods, size):
+        """The reference's own insert(0) benchmark on SparseMatrix<int> (main6.cc:92-187): milliseconds for
+        the ingest and for the edits, and the sum of the dense scan afterwards."""
+        if not hasattr(self.L3, "ref_lab3_modify_bench"):
+            raise OSError("oracle/_ref was built before ref_lab3_modify_bench existed")
+        mods = np.asarray(mods)
+        ms_i, ms_m, chk = C.c_double(), C.c_double(), C.c_longlong()
+        self.L3.ref_lab3_modify_bench.argtypes = [C.c_void_p] * 3 + [C.c_int] + [C.c_void_p] * 2 + [C.c_int, C.c_int,
+                                                  C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+        rows, cols, vals = _i32(rows), _i32(cols), _i32(vals)
+        orow, ocol = _i32(mods[:, 0]), _i32(mods[:, 1])
+        self.L3.ref_lab3_modify_bench(rows.ctypes.data, cols.ctypes.data, vals.ctypes.data, len(vals), orow.ctypes.data,
+                                      ocol.ctypes.data, len(orow), size, C.byref(ms_i), C.byref(ms_m), C.byref(chk))
+        return {"init_ms": ms_i.value, "modify_ms": ms_m.value, "dense_checksum": chk.value, "cores": 1,
+                "kind": "reference (lab3 SparseMatrix<int>, compiled header)"}
+
     def lab3_gs_vector_double(self, rows, cols, vals, b, epsilon=1e-6, max_iteration=1000):
         b = _f64(b)
         x = np.empty(len(b))

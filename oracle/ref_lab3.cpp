@@ -3,6 +3,7 @@
 // compiled where it lies (see oracle/Makefile; output goes to oracle/_ref/ only).
 // Test infrastructure only.  Built as its own shared object because the lab3 and project
 // headers define same-named inline helpers.
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -92,6 +93,30 @@ int ref_lab3_spmv_vector_double(const int *rows, const int *cols, const double *
     std::vector<double> iv(in, in + m.cols()), ov(n_rows, 0.0);
     m.applyToVector(iv, ov);
     std::memcpy(out, ov.data(), sizeof(double) * ov.size());
+    return 0;
+}
+
+// The reference's modify benchmark (labs/lab3/src/OpenCVHW1/main6.cc:92-187) without its Eigen half:
+// the scenario arrives from the caller (the same arrays the device-side benchmark uses), the lab3
+// SparseMatrix<int> ingests it (initializeFromVector), every edit is insert(0, row, col), and the dense
+// scan its own CheckEqual performs (main6.cc:19-33) is summed into `checksum`.  Returns milliseconds.
+int ref_lab3_modify_bench(const int *rows, const int *cols, const int *vals, int count,
+                          const int *op_row, const int *op_col, int n_ops, int size,
+                          double *ms_init, double *ms_modify, long long *checksum)
+{
+    using clk = std::chrono::steady_clock;
+    SparseMatrix<int> m;
+    std::vector<int> r(rows, rows + count), c(cols, cols + count), v(vals, vals + count);
+    auto t0 = clk::now();
+    m.initializeFromVector(r, std::move(c), std::move(v));
+    *ms_init = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+    t0 = clk::now();
+    for (int k = 0; k < n_ops; ++k) m.insert(0, op_row[k], op_col[k]);
+    *ms_modify = std::chrono::duration<double, std::milli>(clk::now() - t0).count();
+    long long sum = 0;
+    for (int i = 0; i < size; ++i)
+        for (int j = 0; j < size; ++j) sum += m.at(i, j);
+    *checksum = sum;
     return 0;
 }
 

@@ -298,3 +298,54 @@ def test_conjugate_gradient_jacobi_vs_oracle_and_fixture(capi, orc, golden):
     assert rep.converged == 1 and abs(rep.iterations - it) <= 1
     assert np.linalg.norm(x - d["mask_x_converged"]) <= 1e-8 * np.linalg.norm(d["mask_x_converged"])
     mm.close()
+
+
+def _random_spd_csr(seed, n, density):
+    """Random symmetric, strictly diagonally dominant sparse matrix (not bipartite: >= 3 colours)."""
+    import scipy.sparse as sp
+    from coursecomputationalphotography_amd import synth
+    g = synth.rng(seed)
+    a = sp.random(n, n, density=density, random_state=np.random.RandomState(seed), data_rvs=lambda k: g.uniform(-1, 1, k)).tocsr()
+    a = a + a.T
+    a.setdiag(0.0)
+    a.eliminate_zeros()
+    a = (a + sp.diags(np.asarray(abs(a).sum(axis=1)).ravel() + 1.0)).tocsr()
+    a.sort_indices()
+    return a.data.astype(np.float64), a.indices.astype(np.int32), a.indptr.astype(np.int32), g
+
+
+@pytest.mark.parametrize("seed,n,density", [(11, 300, 0.03), (12, 1777, 0.004), (13, 40000, 0.0002)])
+def test_multicolour_iterates_equal_oracle_with_the_exported_colouring(capi, orc, seed, n, density):
+    """the general multi-colour sweep on non-bipartite matrices, iterate for iterate.
+    The library colours the rows itself (greedy); ccp_csr_get_colouring exports that colouring, the oracle
+    runs the reference gaussSeidel on P A P^T with the rows listed colour by colour (sparse-matrix.h:350-380)
+    and every iterate k = 1, 2, 10 must agree bit for bit — as must the stop sweep of the L1 rule."""
+    v, c, r, g = _random_spd_csr(seed, n, density)
+    b = g.uniform(-10, 10, n)
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    colour, nc = m.get_colouring()
+    assert nc >= 3 and colour.min() == 0 and colour.max() == nc - 1
+    # a proper colouring: no stored off-diagonal couples two rows of one colour
+    rows = np.repeat(np.arange(n), np.diff(r))
+    off = rows != c
+    assert not np.any(colour[rows[off]] == colour[c[off]])
+    for k in (1, 2, 10):
+        x, rep = m.gauss_seidel(b, 0.0, k, check_every=0, ordering=capi.ORDER_MULTICOLOUR)
+        want, _, _ = orc.multicolour_gauss_seidel(v, c, r, colour, b, 0.0, k)
+        assert rep.iterations == k and np.array_equal(x, want), k
+    want, it, eps = orc.multicolour_gauss_seidel(v, c, r, colour, b, 1e-7, 400)
+    x, rep = m.gauss_seidel(b, 1e-7, 400, check_every=1, ordering=capi.ORDER_MULTICOLOUR)
+    assert it < 400 and rep.iterations == it and rep.converged == 1 and np.array_equal(x, want)
+    assert abs(rep.last_l1_step - eps) <= 1e-9 * eps + 1e-18
+    # the caller's own colouring is what comes back
+    mine = (np.arange(n) % (nc + 2)).astype(np.int32)
+    m.set_colouring(None)
+    m2 = capi.CsrMatrix().upload_compressed(v, c, r)
+    try:
+        m2.set_colouring(mine, nc + 2)
+        got, got_nc = m2.get_colouring()
+        assert got_nc == nc + 2 and np.array_equal(got, mine)
+    except capi.CcpError as e:                       # arbitrary labels are rarely a proper colouring: rejected, not used
+        assert e.status == 6
+    m2.close()
+    m.close()
