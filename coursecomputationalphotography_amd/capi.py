@@ -20,17 +20,18 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("CCP_GS_LIB") or os.path.join(_HERE, "lib", "libccp_gs.so")
 
 CCP_OK = 0
+GRID_DIRICHLET_MASK = 1
 ORDER_LEXICOGRAPHIC = 0
 ORDER_MULTICOLOUR = 1
 
 # every symbol include/ccp_gs.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "ccp_status_string", "ccp_abi_version", "ccp_device_count",
-    "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_set_colouring", "ccp_csr_get_colouring", "ccp_csr_insert", "ccp_csr_edit_stats",
+    "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_set_colouring", "ccp_csr_get_colouring", "ccp_csr_insert", "ccp_csr_insert_many", "ccp_csr_edit_stats", "ccp_csr_last_path", "ccp_csr_embed_region_host",
     "ccp_csr_gauss_seidel", "ccp_csr_conjugate_gradient", "ccp_csr_conjugate_gradient_jacobi", "ccp_csr_apply_to_vector", "ccp_csr_residual_norm2",
     "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
-    "ccp_grid_get_b_host", "ccp_grid_fill_x", "ccp_grid_b_from_x", "ccp_grid_randomize_x",
+    "ccp_grid_get_b_host", "ccp_grid_set_mask_host", "ccp_grid_fill_x", "ccp_grid_b_from_x", "ccp_grid_randomize_x",
     "ccp_grid_sweep", "ccp_grid_sweep_edges_first", "ccp_grid_stream_wait_edges", "ccp_grid_tune", "ccp_grid_set_fused", "ccp_grid_set_tiling", "ccp_grid_get_tiling", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_gauss_seidel_lexicographic", "ccp_grid_conjugate_gradient",
     "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_assemble_from_images", "ccp_grid_store_u8",
     "ccp_grid_set_x_u8", "ccp_grid_last_timing", "ccp_grid_region_begin", "ccp_grid_region_end",
@@ -146,6 +147,8 @@ def load() -> C.CDLL:
     L.ccp_csr_set_colouring.argtypes = [vp, vp, i32]
     L.ccp_csr_get_colouring.argtypes = [vp, vp, C.POINTER(i32)]
     L.ccp_csr_insert.argtypes = [vp, i32, i32, dbl]
+    L.ccp_csr_insert_many.argtypes = [vp, i64, vp, vp, vp]
+    L.ccp_csr_last_path.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     L.ccp_csr_edit_stats.argtypes = [vp] + [C.POINTER(i64)] * 5
     L.ccp_csr_gauss_seidel.argtypes = [vp, vp, vp, vp, dbl, i32, i32, i32, C.POINTER(Report)]
     L.ccp_csr_conjugate_gradient.argtypes = [vp, vp, vp, vp, dbl, i32, C.POINTER(Report)]
@@ -160,6 +163,7 @@ def load() -> C.CDLL:
     L.ccp_grid_synchronize.argtypes = [vp]
     for name in ("ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host", "ccp_grid_get_b_host"):
         getattr(L, name).argtypes = [vp, i32, vp, i32, i32]
+    L.ccp_grid_set_mask_host.argtypes = [vp, vp, i64]
     L.ccp_grid_fill_x.argtypes = [vp, dbl]
     L.ccp_grid_b_from_x.argtypes = [vp]
     L.ccp_grid_randomize_x.argtypes = [vp, C.c_uint64, dbl, dbl]
@@ -282,6 +286,19 @@ class Comm:
             pass
 
 
+def embed_region_host(values, col_offset, row_offset, colour):
+    """ccp_csr_embed_region_host: (recognised, W, H, x[n], y[n]) — the raster-region recognition alone, on the host."""
+    L = load()
+    values, col_offset, row_offset, colour = _f64(values), _i32(col_offset), _i32(row_offset), _i32(colour)
+    n = len(row_offset) - 1
+    ok, w, h = C.c_int32(), C.c_int32(), C.c_int32()
+    x, y = np.zeros(max(n, 1), dtype=np.int32), np.zeros(max(n, 1), dtype=np.int32)
+    L.ccp_csr_embed_region_host.argtypes = [C.c_int32] + [C.c_void_p] * 4 + [C.POINTER(C.c_int32)] * 3 + [C.c_void_p] * 2
+    check(L.ccp_csr_embed_region_host(n, _ptr(row_offset), _ptr(col_offset), _ptr(values), _ptr(colour), C.byref(ok), C.byref(w),
+                                      C.byref(h), _ptr(x), _ptr(y)), "ccp_csr_embed_region_host")
+    return bool(ok.value), w.value, h.value, x[:n], y[:n]
+
+
 class CsrMatrix:
     """Device-resident slack-CSR matrix (ccp_csr_*)."""
 
@@ -331,6 +348,16 @@ class CsrMatrix:
     def insert(self, val: float, row: int, col: int):
         """SparseMatrix::insert(val, row, col) on the uploaded matrix (applied on the device incrementally)."""
         check(self.L.ccp_csr_insert(self.h, row, col, float(val)), "ccp_csr_insert")
+
+    def last_path(self) -> str:
+        """Kernels of the last gauss_seidel: "sliced ELL", "Poisson grid WxH" or "region grid WxH" (canvas)."""
+        p, w, h = C.c_int32(), C.c_int32(), C.c_int32()
+        check(self.L.ccp_csr_last_path(self.h, C.byref(p), C.byref(w), C.byref(h)), "ccp_csr_last_path")
+        return {0: "sliced ELL", 1: f"Poisson grid {w.value}x{h.value}", 2: f"region grid {w.value}x{h.value}"}[p.value]
+
+    def insert_many(self, vals, rows, cols):
+        vals, rows, cols = _f64(vals), _i32(rows), _i32(cols)
+        check(self.L.ccp_csr_insert_many(self.h, len(vals), _ptr(rows), _ptr(cols), _ptr(vals)), "ccp_csr_insert_many")
 
     def edit_stats(self):
         v = [C.c_int64() for _ in range(5)]
@@ -389,11 +416,12 @@ class CsrMatrix:
 class Grid:
     """Structured Poisson grid block (ccp_grid_*)."""
 
-    def __init__(self, width, height, channels=1, row_begin=0, row_count=None, ghost=0, device=0):
+    def __init__(self, width, height, channels=1, row_begin=0, row_count=None, ghost=0, device=0, mask=None):
+        """mask: H x W array (non-zero = unknown) makes this a Dirichlet-mask grid (CCP_GRID_DIRICHLET_MASK)."""
         self.L = load()
         self.h = C.c_void_p()
         row_count = height if row_count is None else row_count
-        self.desc = GridDesc(width, height, channels, row_begin, row_count, ghost, device, 0)
+        self.desc = GridDesc(width, height, channels, row_begin, row_count, ghost, device, 0 if mask is None else GRID_DIRICHLET_MASK)
         check(self.L.ccp_grid_create(C.byref(self.desc), C.byref(self.h)), "ccp_grid_create")
         self.layout = GridLayout()
         check(self.L.ccp_grid_get_layout(self.h, C.byref(self.layout)), "ccp_grid_get_layout")
@@ -403,6 +431,14 @@ class Grid:
         self.local_rows = self.layout.local_rows
         self._comm = None
         _live_grids.add(self)
+        if mask is not None:
+            self.set_mask(mask)
+
+    def set_mask(self, mask):
+        mask = np.ascontiguousarray(np.asarray(mask) != 0, dtype=np.uint8)
+        if mask.shape != (self.H, self.W):
+            raise ValueError("mask must be H x W")
+        check(self.L.ccp_grid_set_mask_host(self.h, _ptr(mask), mask.strides[0]), "ccp_grid_set_mask_host")
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h:

@@ -219,6 +219,19 @@ k_reduce_to(const double *__restrict__ partial, long count, long stride, double 
     if (threadIdx.x == 0) out[0] = accumulate ? out[0] + t : t;
 }
 
+// Raster-region dispatch: unknown i of the uploaded matrix lives at element where[i] of the canvas planes.
+// canvas[where[i]] = v[i] (scatter) / v[i] = canvas[where[i]] (gather); fill: canvas[where[i]] = value.
+template <int MODE>
+__global__ void __launch_bounds__(kBlock)
+k_canvas_move(double *__restrict__ canvas, double *__restrict__ v, const long *__restrict__ where, long n, double value)
+{
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+        if (MODE == 0) canvas[where[i]] = v[i];
+        else if (MODE == 1) v[i] = canvas[where[i]];
+        else canvas[where[i]] = value;
+    }
+}
+
 // Incremental edits (ccp_csr_insert).  One block per patched row: write the row's `cap` entry slots
 // (entry k at base + k*64; beyond the row's live entries the patch carries padding: column -1, value 0).
 __global__ void __launch_bounds__(kWave)

@@ -47,6 +47,13 @@ struct ccp_grid {
     DevBuf<double> cg_r, cg_p, cg_ap;   // conjugate-gradient work vectors, one channel each
     DevBuf<CgState> cg_state;
     DevBuf<double> x_alt;        // ping-pong partner of x for the temporally blocked sweep
+    // Dirichlet-mask grid (CCP_GRID_DIRICHLET_MASK): uniform 5-point stencil on the pixels whose mask byte
+    // is 1, everything else fixed at zero.  maskp: one byte per pixel in the layout of x (one channel);
+    // tile_live: which tiles of the current tiling hold any unknown (k_masked_tile_census), cached per tiling.
+    bool masked = false;
+    DevBuf<unsigned char> maskp, tile_live;
+    int live_T = -1, live_R = -1, live_lo = -1, live_hi = -1;
+    long unknowns = 0;           // mask bytes set (owned rows), for the statistics
     bool fuse = true;            // use k_fused_sweep for unchecked sweeps
     bool short_edges = true;     // chunk rows at an image edge are short (CCP_GS_SHORT_EDGES=0 turns it off)
     int side_rows_override = 0;  // CCP_GS_SIDE_ROWS
@@ -114,8 +121,11 @@ int launch_half_sweep(ccp_grid *g, int c, int l_lo, int l_hi, const int *active)
     double *part = g->partial.p + (long)c * g->partial_region;
 #define CCP_LAUNCH_SWEEP(CPT_, SHFL_)                                                                          \
     hipLaunchKernelGGL((k_half_sweep<CPT_, L1, SHFL_>), grid, block, 0, g->stream, g->x.p, g->x.p, g->b.p, geo, \
-                       c, l_lo, l_hi, rpb, part, active)
-    if (g->cpt == 4) {
+                       c, l_lo, l_hi, rpb, part, active, static_cast<const unsigned char *>(nullptr))
+    if (g->masked) {
+        hipLaunchKernelGGL((k_half_sweep<2, L1, true, true>), grid, block, 0, g->stream, g->x.p, g->x.p, g->b.p, geo, c, l_lo, l_hi,
+                           rpb, part, active, g->maskp.p);
+    } else if (g->cpt == 4) {
         if (g->shfl) CCP_LAUNCH_SWEEP(4, true); else CCP_LAUNCH_SWEEP(4, false);
     } else {
         if (g->shfl) CCP_LAUNCH_SWEEP(2, true); else CCP_LAUNCH_SWEEP(2, false);
@@ -230,6 +240,54 @@ void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P, int edge_rows =
     }
 }
 
+// One pass of depth T over a Dirichlet-mask grid: every tile is an ordinary tile (zero lies outside the block
+// as it does outside the region), tiles without any unknown in reach leave at once.
+template <int T>
+int launch_fused_masked(ccp_grid *g, FusedParams &P, int l1, long *l1_blocks)
+{
+    if (T > kMaskedMaxT) return CCP_ERR_BAD_ARG;
+    constexpr int TM = T <= kMaskedMaxT ? T : 1;
+    const int rows = P.st_hi - P.st_lo;
+    P.first_rows = P.last_rows = 0;
+    P.first_edge = P.last_edge = 0;
+    P.n_chunks = (rows + P.rows_per_chunk - 1) / P.rows_per_chunk;
+    P.nb_top = P.nb_bot = P.ns_left = P.ns_right = 0;
+    P.side_rows = P.rows_per_chunk;
+    P.side_subs = 1;
+    P.side_rows_edge = P.rows_per_chunk;
+    P.edge_counter = nullptr;
+    P.edge_flag = nullptr;
+    P.edge_target = P.edge_epoch = 0;
+    const int waves = kBlock / kWave;
+    dim3 grid((unsigned)((P.n_strips + waves - 1) / waves), (unsigned)P.n_chunks, (unsigned)g->desc.channels);
+    if (l1_blocks) {
+        l1_blocks[0] = (long)grid.x * grid.y;
+        l1_blocks[1] = 0;
+    }
+    // which tiles hold unknowns: one census per tiling (depth, chunk rows, row range)
+    if (g->live_T != T || g->live_R != P.rows_per_chunk || g->live_lo != P.st_lo || g->live_hi != P.st_hi) {
+        const size_t tiles = (size_t)P.n_chunks * P.n_strips;
+        if (g->tile_live.n < tiles) CCP_TRY(g->tile_live.alloc(tiles));
+        hipLaunchKernelGGL(k_masked_tile_census, dim3((unsigned)P.n_strips, (unsigned)P.n_chunks), dim3(kWave), 0, g->stream, P, T,
+                           g->tile_live.p);
+        CCP_HIP(hipGetLastError());
+        g->live_T = T;
+        g->live_R = P.rows_per_chunk;
+        g->live_lo = P.st_lo;
+        g->live_hi = P.st_hi;
+    }
+    if (l1 == 2 && T > kMaskedMaxCheckedT) return CCP_ERR_BAD_ARG;
+    constexpr int TMC = T <= kMaskedMaxCheckedT ? T : 1;
+    if (l1 == 2) hipLaunchKernelGGL((k_fused_sweep_masked<TMC, 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P, g->tile_live.p);
+    else if (l1 == 1) hipLaunchKernelGGL((k_fused_sweep_masked<TM, 1, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P, g->tile_live.p);
+    else hipLaunchKernelGGL((k_fused_sweep_masked<TM, 0, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P, g->tile_live.p);
+    CCP_HIP(hipGetLastError());
+    g->last_launches++;
+    g->region_launches++;
+    g->region_iterations += T;
+    return CCP_OK;
+}
+
 // One pass of depth T.  l1: 0 none, 1 step of the last sweep, 2 step of every sweep of the pass;
 // l1_blocks[0/1]: block results per (sweep, channel) of the ordinary / the border launch.
 // edge_rows > 0: the EDGE kernels (edge chunks first, in-launch signal); *signalled tells the caller
@@ -252,6 +310,8 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     P.partial_border = g->partial.p + g->partial_region;
     P.active = active;
     const bool want_edge = edge_rows > 0 && l1 == 0 && active == nullptr && g->edge_counter && g->edge_signal;
+    P.mask = g->maskp.p;
+    if (g->masked) return launch_fused_masked<T>(g, P, l1, l1_blocks);
     fused_tile_counts(g, T, P, want_edge ? edge_rows : 0);
     const int waves = kBlock / kWave;
     const int edge_chunks = std::min(P.nb_top + P.nb_bot, P.n_chunks);
@@ -481,6 +541,24 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool
     return CCP_OK;
 }
 
+// Dirichlet-mask grids: p := 0 wherever the mask byte is 0 (all channels).  grid = (blocks, 1, channels)
+__global__ void __launch_bounds__(kBlock)
+k_zero_unmasked(double *__restrict__ p, const unsigned char *__restrict__ mask, long per_channel)
+{
+    double *__restrict__ q = p + (long)blockIdx.z * per_channel;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < per_channel; i += (long)gridDim.x * kBlock)
+        if (mask[i] == 0) q[i] = 0.0;
+}
+
+int zero_unmasked(ccp_grid *g, double *plane)
+{
+    if (!g->masked) return CCP_OK;
+    hipLaunchKernelGGL(k_zero_unmasked, dim3(2048, 1, (unsigned)g->desc.channels), dim3(kBlock), 0, g->stream, plane, g->maskp.p,
+                       g->geom.ch_stride);
+    CCP_HIP(hipGetLastError());
+    return CCP_OK;
+}
+
 int begin_timing(ccp_grid *g)
 {
     g->last_launches = 0;
@@ -570,9 +648,21 @@ try {
     if (const char *e = getenv("CCP_GS_FORCE_BORDER")) g->force_border = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_CHUNK")) g->rows_per_chunk = std::max(1, atoi(e));
     choose_tiling(g);
+    g->masked = (d->flags & CCP_GRID_DIRICHLET_MASK) != 0;
+    if (g->masked) {
+        if (g->ghost_top || g->ghost_bottom) {               // row blocks of a masked grid: not built
+            delete g;
+            return CCP_ERR_UNSUPPORTED;
+        }
+        g->fuse_tmax = std::min(g->fuse_tmax, kMaskedMaxT);
+    }
 
     const size_t elems = (size_t)geo.ch_stride * d->channels;
     int st = g->x.alloc(elems);
+    if (st == CCP_OK && g->masked) {
+        st = g->maskp.alloc((size_t)geo.ch_stride);
+        if (st == CCP_OK && hipMemset(g->maskp.p, 0, (size_t)geo.ch_stride) != hipSuccess) st = CCP_ERR_HIP;
+    }
     if (st == CCP_OK) st = g->b.alloc(elems);
     // partial sums: the finest launch is one block per (x tile, row, channel*2) with 2 doubles
     const size_t part = (size_t)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)) * geo.local_rows * d->channels * 2 * 2 + 64;
@@ -667,13 +757,15 @@ try {
 int ccp_grid_set_b_host(ccp_grid *g, int32_t channel, const double *rows, int32_t first_row, int32_t n_rows)
 try {
     if (!g) return CCP_ERR_BAD_ARG;
-    return transfer_rows<true>(g, g->b.p, channel, const_cast<double *>(rows), first_row, n_rows);
+    CCP_TRY(transfer_rows<true>(g, g->b.p, channel, const_cast<double *>(rows), first_row, n_rows));
+    return zero_unmasked(g, g->b.p);
 } CCP_ABI_CATCH
 
 int ccp_grid_set_x_host(ccp_grid *g, int32_t channel, const double *rows, int32_t first_row, int32_t n_rows)
 try {
     if (!g) return CCP_ERR_BAD_ARG;
-    return transfer_rows<true>(g, g->x.p, channel, const_cast<double *>(rows), first_row, n_rows);
+    CCP_TRY(transfer_rows<true>(g, g->x.p, channel, const_cast<double *>(rows), first_row, n_rows));
+    return zero_unmasked(g, g->x.p);
 } CCP_ABI_CATCH
 
 int ccp_grid_get_x_host(ccp_grid *g, int32_t channel, double *rows, int32_t first_row, int32_t n_rows)
@@ -688,12 +780,40 @@ try {
     return transfer_rows<false>(g, g->b.p, channel, rows, first_row, n_rows);
 } CCP_ABI_CATCH
 
+int ccp_grid_set_mask_host(ccp_grid *g, const uint8_t *mask, int64_t row_stride_bytes)
+try {
+    CCP_TRY(bind(g));
+    if (!g->masked) return CCP_ERR_STATE;
+    if (!mask || row_stride_bytes < g->desc.width) return CCP_ERR_BAD_ARG;
+    const Geom &geo = g->geom;
+    std::vector<unsigned char> split((size_t)geo.ch_stride, 0);
+    long count = 0;
+    for (int l = 0; l < geo.local_rows; ++l) {
+        const int y = geo.y0 + l;
+        const uint8_t *row = mask + (size_t)y * (size_t)row_stride_bytes;
+        for (int x = 0; x < geo.W; ++x) {
+            if (!row[x]) continue;
+            split[(size_t)(((long)l * 2 + ((x + y) & 1)) * geo.pitch + (x >> 1))] = 1;
+            ++count;
+        }
+    }
+    CCP_HIP(hipMemcpyAsync(g->maskp.p, split.data(), split.size(), hipMemcpyHostToDevice, g->stream));
+    CCP_HIP(hipStreamSynchronize(g->stream));
+    g->unknowns = count;
+    g->live_T = -1;                                      // the tile census belongs to the old mask
+    CCP_TRY(zero_unmasked(g, g->x.p));
+    CCP_TRY(zero_unmasked(g, g->b.p));
+    if (g->x_alt.p) CCP_TRY(zero_unmasked(g, g->x_alt.p));
+    return CCP_OK;
+} CCP_ABI_CATCH
+
 int ccp_grid_fill_x(ccp_grid *g, double value)
 try {
     CCP_TRY(bind(g));
     const long n = g->geom.ch_stride * g->desc.channels;
     hipLaunchKernelGGL(k_fill, dim3(2048), dim3(kBlock), 0, g->stream, g->x.p, n, value);
     CCP_HIP(hipGetLastError());
+    CCP_TRY(zero_unmasked(g, g->x.p));
     g->half_sweeps_since_refresh = 0;
     return CCP_OK;
 } CCP_ABI_CATCH
@@ -704,6 +824,7 @@ try {
     dim3 grid((unsigned)((g->geom.pitch + kBlock - 1) / kBlock), (unsigned)g->geom.local_rows, (unsigned)g->desc.channels * 2);
     hipLaunchKernelGGL(k_randomize, grid, dim3(kBlock), 0, g->stream, g->x.p, g->geom, seed, lo, hi);
     CCP_HIP(hipGetLastError());
+    CCP_TRY(zero_unmasked(g, g->x.p));
     g->half_sweeps_since_refresh = 0;
     return CCP_OK;
 } CCP_ABI_CATCH
@@ -718,7 +839,11 @@ try {
     const int l_lo = g->shrink_top ? 1 : 0;
     const int l_hi = geo.local_rows - (g->shrink_bottom ? 1 : 0);
     dim3 grid((unsigned)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)), (unsigned)(l_hi - l_lo), (unsigned)g->desc.channels * 2);
-    hipLaunchKernelGGL((k_apply<2, 0>), grid, dim3(kBlock), 0, g->stream, g->x.p, g->b.p, g->b.p, geo, l_lo, g->partial.p);
+    if (g->masked)
+        hipLaunchKernelGGL((k_apply<2, 0, true>), grid, dim3(kBlock), 0, g->stream, g->x.p, g->b.p, g->b.p, geo, l_lo, g->partial.p, g->maskp.p);
+    else
+        hipLaunchKernelGGL((k_apply<2, 0>), grid, dim3(kBlock), 0, g->stream, g->x.p, g->b.p, g->b.p, geo, l_lo, g->partial.p,
+                           static_cast<const unsigned char *>(nullptr));
     CCP_HIP(hipGetLastError());
     return CCP_OK;
 } CCP_ABI_CATCH
@@ -761,7 +886,7 @@ int ccp_grid_tune(ccp_grid *g, int32_t max_t, int32_t *chosen_t, int32_t *chosen
 try {
     CCP_TRY(bind(g));
     if (max_t < 1) return CCP_ERR_BAD_ARG;
-    max_t = std::min<int>(max_t, kFusedMaxT);
+    max_t = std::min<int>(max_t, g->masked ? kMaskedMaxT : kFusedMaxT);
     if (!g->x_alt.p) {
         const size_t elems = (size_t)g->geom.ch_stride * g->desc.channels;
         CCP_TRY(g->x_alt.alloc(elems));
@@ -789,7 +914,7 @@ try {
         {
             const int U = fused_useful_px(T);
             const long blocks_x = ((g->geom.W + U - 1) / U + kBlock / kWave - 1) / (kBlock / kWave);
-            const long slots = (long)cus * fused_waves_per_simd(T);       // resident workgroups
+            const long slots = (long)cus * (g->masked ? masked_waves_per_simd(T) : fused_waves_per_simd(T));       // resident workgroups
             // chunk rows at an image edge are short ones of their own (fused_tile_counts)
             const int n_short = (g->geom.y0 - 2 * T <= 0) + (g->geom.y0 + rows + 2 * T >= g->geom.H - 1);
             const int short_rows = n_short * (2 * T + 16);
@@ -940,7 +1065,7 @@ try {
         for (int ch = 0; ch < C; ++ch) was_active[ch] = 1;
         int k0 = 0;
         while (any_active && k0 < max_iteration) {
-            const int T = std::min(kFusedMaxCheckedT, max_iteration - k0);
+            const int T = std::min(g->masked ? kMaskedMaxCheckedT : kFusedMaxCheckedT, max_iteration - k0);
             long blocks[2] = {0, 0};
             CCP_TRY(launch_fused(g, T, cur, alt, active, 2, blocks));
             hipLaunchKernelGGL(k_check_multi, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
@@ -961,7 +1086,7 @@ try {
                     CCP_HIP(hipMemcpyAsync(g->redo_mask.p, mask, sizeof(mask), hipMemcpyHostToDevice, g->stream));
                     double *p = cur, *q = alt;
                     for (int left = m; left > 0;) {
-                        const int t = std::min(left, kFusedMaxT);
+                        const int t = std::min(left, g->masked ? kMaskedMaxT : kFusedMaxT);
                         CCP_TRY(launch_fused(g, t, p, q, g->redo_mask.p));
                         std::swap(p, q);
                         left -= t;
@@ -1072,6 +1197,7 @@ int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max
 try {
     CCP_TRY(bind(g));
     if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;   // whole image only
+    if (g->masked) return CCP_ERR_UNSUPPORTED;            // the reference-order sweep of a masked region is the CSR path's
     if (max_iteration < 0 || check_every < 0) return CCP_ERR_BAD_ARG;
     const int C = g->desc.channels, W = g->desc.width, H = g->desc.height;
     LexGeom &lg = g->lexg;
@@ -1193,11 +1319,13 @@ try {
         CCP_HIP(hipMemsetAsync(g->cg_ap.p, 0, sizeof(double) * n, s));
         // matrix-free A*v on one channel: the kernel sees channel 0 of the offset pointers
         auto spmv = [&](const double *in, double *out) -> int {
-            hipLaunchKernelGGL((k_apply<2, 0>), grid, dim3(kBlock), 0, s, in, out, out, geo, 0, g->partial.p);
+            if (g->masked) hipLaunchKernelGGL((k_apply<2, 0, true>), grid, dim3(kBlock), 0, s, in, out, out, geo, 0, g->partial.p, g->maskp.p);
+            else hipLaunchKernelGGL((k_apply<2, 0>), grid, dim3(kBlock), 0, s, in, out, out, geo, 0, g->partial.p, static_cast<const unsigned char *>(nullptr));
             return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
         };
         auto spmv_dot = [&](const double *in, double *out, int *n_partials) -> int {
-            hipLaunchKernelGGL((k_apply<2, 2>), grid, dim3(kBlock), 0, s, in, out, out, geo, 0, g->partial.p);
+            if (g->masked) hipLaunchKernelGGL((k_apply<2, 2, true>), grid, dim3(kBlock), 0, s, in, out, out, geo, 0, g->partial.p, g->maskp.p);
+            else hipLaunchKernelGGL((k_apply<2, 2>), grid, dim3(kBlock), 0, s, in, out, out, geo, 0, g->partial.p, static_cast<const unsigned char *>(nullptr));
             *n_partials = (int)(grid.x * grid.y * grid.z);
             return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
         };
@@ -1216,7 +1344,11 @@ int residual_to_small(ccp_grid *g)
     const Geom &geo = g->geom;
     const int C = g->desc.channels;
     dim3 grid((unsigned)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)), (unsigned)(geo.own_hi - geo.own_lo), (unsigned)C * 2);
-    hipLaunchKernelGGL((k_apply<2, 1>), grid, dim3(kBlock), 0, g->stream, g->x.p, g->b.p, g->b.p, geo, geo.own_lo, g->partial.p);
+    if (g->masked)
+        hipLaunchKernelGGL((k_apply<2, 1, true>), grid, dim3(kBlock), 0, g->stream, g->x.p, g->b.p, g->b.p, geo, geo.own_lo, g->partial.p, g->maskp.p);
+    else
+        hipLaunchKernelGGL((k_apply<2, 1>), grid, dim3(kBlock), 0, g->stream, g->x.p, g->b.p, g->b.p, geo, geo.own_lo, g->partial.p,
+                           static_cast<const unsigned char *>(nullptr));
     CCP_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_pair_reduce, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, (long)grid.x * grid.y, g->small.p);
     CCP_HIP(hipGetLastError());
@@ -1265,6 +1397,7 @@ int ccp_grid_assemble_rhs(ccp_grid *g, const float *gx, const float *gy, int64_t
 try {
     CCP_TRY(bind(g));
     if (!gx || !gy || !constraint) return CCP_ERR_BAD_ARG;
+    if (g->masked) return CCP_ERR_UNSUPPORTED;            // SolveChannel's right-hand side belongs to SolveChannel's matrix
     if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;
     const int W = g->desc.width, H = g->desc.height, C = g->desc.channels;
     const size_t row_bytes = (size_t)W * C * sizeof(float);
@@ -1298,7 +1431,7 @@ int ccp_grid_assemble_from_images(ccp_grid *g, const uint8_t *const *images, int
 try {
     CCP_TRY(bind(g));
     if (!images || !label || n_images < 1 || n_images > 256) return CCP_ERR_BAD_ARG;
-    if (g->desc.channels != 3) return CCP_ERR_UNSUPPORTED;                   // BGR images
+    if (g->desc.channels != 3 || g->masked) return CCP_ERR_UNSUPPORTED;      // BGR images; SolveChannel's matrix
     if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;
     const int W = g->desc.width, H = g->desc.height;
     if (image_stride_bytes < (int64_t)W * 3 || label_stride_bytes < W) return CCP_ERR_BAD_ARG;
@@ -1357,6 +1490,7 @@ try {
     dim3 grid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, (unsigned)C);
     hipLaunchKernelGGL(k_load_u8, grid, dim3(kBlock), 0, g->stream, g->x.p, g->geom, d.p, C);
     CCP_HIP(hipGetLastError());
+    CCP_TRY(zero_unmasked(g, g->x.p));
     CCP_HIP(hipStreamSynchronize(g->stream));
     return CCP_OK;
 } CCP_ABI_CATCH

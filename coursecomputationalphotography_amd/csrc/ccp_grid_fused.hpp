@@ -98,6 +98,9 @@ struct FusedParams {
     // itself in *edge_counter; the wave that brings it to edge_target publishes edge_epoch in *edge_flag,
     // which the halo exchange's stream is waiting for (hipStreamWaitValue64) — so the messages leave while
     // the rest of the pass is still running.
+    // Dirichlet-mask grids (MASKED kernels): one byte per pixel in the layout of x (colour half-rows of
+    // `pitch` bytes): 1 = unknown, 0 = fixed at zero
+    const unsigned char *__restrict__ mask;
     int first_edge, last_edge;
     unsigned long long *__restrict__ edge_counter;
     unsigned long long *__restrict__ edge_flag;
@@ -197,6 +200,8 @@ struct FusedCtx {
     int j;              // this lane's half-column (may be negative in the first strip)
     unsigned ld_r, ld_k;   // byte offset of the lane's red / black pixel inside a row, kLaneOut if the half-column does not exist
     unsigned st_r, st_k;   // the same for stores: kLaneOut unless the strip stores this half-column
+    const unsigned char *__restrict__ mask;   // MASKED: the mask plane (channel-independent)
+    unsigned ldm_r, ldm_k; // MASKED: byte offset of the lane's red / black mask byte inside a row
     bool col_store;     // lane's pixels belong to the columns this strip stores
     int ra, rb;         // rows to finalise and store
     int m0, m1;         // rows loaded
@@ -220,6 +225,16 @@ __device__ __forceinline__ void fused_load_row(const FusedCtx &cx, const Geom &g
     dst[3] = buf_load(rbb, cx.ld_k);
 }
 
+// MASKED: the two mask bytes of the lane's pixels in row q (0 outside the block / the image).
+__device__ __forceinline__ void fused_load_mask(const FusedCtx &cx, const Geom &g, int q, int (&dst)[2])
+{
+    const bool exists = q >= cx.m0 && q < cx.m1;
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc((void *)(cx.mask + (long)q * 2 * g.pitch), 0,
+                                                                        exists ? (int)(g.pitch * 2) : 0, 0x00020000);
+    dst[0] = (int)__builtin_amdgcn_raw_buffer_load_b8(rm, (int)cx.ldm_r, 0, 0);
+    dst[1] = (int)__builtin_amdgcn_raw_buffer_load_b8(rm, (int)cx.ldm_k, 0, 0);
+}
+
 // One march step: newest row f, unrolled position i: half-sweep h on row f - h for h = 1..2T, then
 // the store of row f - 2T.  No range checks: rows that do not exist (pipeline fill and drain, the
 // outside of the image) hold zeros or garbage, are updated like any other, are never stored, and
@@ -238,9 +253,13 @@ __device__ __forceinline__ void fused_load_row(const FusedCtx &cx, const Geom &g
 // the window still holds — the reference's per-sweep manhattonDist at no extra memory traffic).
 constexpr int kStepFast = 0, kStepBorder = 2, kStepSide = 3;
 
-template <int T, int MODE, int L1, int UNR, int NT, int AN>
+// MASKED (Dirichlet-mask grid): the update is fma(sum, q, b/4) with q = 1/4 for an unknown and 0 for a pixel
+// fixed at zero (whose b is 0): the same instruction count as the plain update, the mask costs registers (a
+// q window) instead of instructions.  The stencil is the uniform 5-point one — no degree logic anywhere.
+template <int T, int MODE, int L1, int UNR, int NT, int AN, bool MASKED = false, int NQ = 1>
 __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], double (&br)[NT], double (&bk)[NT],
-                                           double (&acc)[AN], const FusedCtx &cx, const Geom &g, int f, int i)
+                                           double (&acc)[AN], const FusedCtx &cx, const Geom &g, int f, int i,
+                                           double (&qr)[NQ], double (&qk)[NQ])
 {
     using Win = FusedWindow<T, UNR>;
     constexpr int HS = Win::HS;
@@ -263,7 +282,8 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
         const double old = c ? wk[sr] : wr[sr];
         double nv = old;
         if (MODE == kStepFast) {
-            nv = __builtin_fma(((up + left) + right) + dn, 0.25, bq);
+            if (MASKED) nv = __builtin_fma(((up + left) + right) + dn, c ? qk[MASKED ? sr : 0] : qr[MASKED ? sr : 0], bq);
+            else nv = __builtin_fma(((up + left) + right) + dn, 0.25, bq);
         } else if (MODE == kStepSide) {
             const double bv = bq * 4.0;
             // ordinary row y in [1, H-2]: cell(x,y-1), cell(x,y) exist iff x < W-1 (up, right,
@@ -329,11 +349,13 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
 // BORDERTILE = false: every pixel the wave can touch is ordinary: one straight-line loop of
 // kStepFast trips.  BORDERTILE = true: each trip picks among the three bodies (force_border:
 // debug, every trip takes kStepBorder).
-template <int T, bool BORDERTILE, int L1, int UNR, int AN>
+template <int T, bool BORDERTILE, int L1, int UNR, int AN, bool MASKED = false>
 __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, double *__restrict__ xout,
                                            const double *__restrict__ bb, const Geom &g, int sx,
-                                           int ra, int rb, double (&acc)[AN], bool force_border = false)
+                                           int ra, int rb, double (&acc)[AN], bool force_border = false,
+                                           const unsigned char *__restrict__ mask = nullptr)
 {
+    static_assert(!(MASKED && BORDERTILE), "a Dirichlet-mask grid has no border tiles: everything outside is zero");
     using Win = FusedWindow<T, UNR>;
     constexpr int HS = Win::HS, G = Win::G, NT = Win::NT;
     FusedCtx cx;
@@ -349,6 +371,9 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     cx.ld_k = col_ok ? (unsigned)(g.pitch + cx.j) * 8u : kLaneOut;
     cx.st_r = cx.col_store ? cx.ld_r : kLaneOut;
     cx.st_k = cx.col_store ? cx.ld_k : kLaneOut;
+    cx.mask = mask;
+    cx.ldm_r = col_ok ? (unsigned)cx.j : kLaneOut;
+    cx.ldm_k = col_ok ? (unsigned)(g.pitch + cx.j) : kLaneOut;
     cx.col_interior = (px0 >= 1) && (px0 + 2 * kStripLanes <= g.W - 1);
     cx.has_first = (px0 <= 0) && (px0 + 2 * kStripLanes > 0);
 #pragma unroll
@@ -368,25 +393,40 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     const int f_end = rb - 1 + HS;                      // last step: row rb-1 gets half-sweep HS
 
     double wr[NT], wk[NT], br[NT], bk[NT];              // x red/black, b red/black per window row
+    constexpr int NQ = MASKED ? NT : 1;
+    double qr[NQ], qk[NQ];                              // MASKED: 1/4 for an unknown, 0 for a pixel fixed at zero
     double land[G][4];                                  // rows in flight
+    int landm[G][2];
 #pragma unroll
     for (int s = 0; s < NT; ++s) wr[s] = wk[s] = br[s] = bk[s] = 0.0;
 #pragma unroll
-    for (int i = 0; i < G; ++i) fused_load_row(cx, g, base + i, land[i]);
+    for (int s = 0; s < NQ; ++s) qr[s] = qk[s] = 0.0;
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+        fused_load_row(cx, g, base + i, land[i]);
+        if (MASKED) fused_load_mask(cx, g, base + i, landm[i]);
+    }
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         const int s0 = Win::slot(i, 0);
         wr[s0] = land[i][0]; wk[s0] = land[i][1]; br[s0] = land[i][2] * 0.25; bk[s0] = land[i][3] * 0.25;
+        if (MASKED) {
+            qr[s0] = landm[i][0] ? 0.25 : 0.0;
+            qk[s0] = landm[i][1] ? 0.25 : 0.0;
+        }
     }
 
     for (int fb = base; fb <= f_end; fb += G) {
 #pragma unroll
-        for (int i = 0; i < G; ++i) fused_load_row(cx, g, fb + G + i, land[i]);
+        for (int i = 0; i < G; ++i) {
+            fused_load_row(cx, g, fb + G + i, land[i]);
+            if (MASKED) fused_load_mask(cx, g, fb + G + i, landm[i]);
+        }
         __builtin_amdgcn_sched_barrier(0);
         if (!BORDERTILE) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
-                fused_step<T, kStepFast, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+                fused_step<T, kStepFast, L1, UNR, NT, AN, MASKED, NQ>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
         } else {
             // rows the trip updates that matter: fb-HS .. fb+G-2, clipped to the rows this wave holds
             const int r_first = max(fb - HS, cx.m0), r_last = min(fb + G - 2, cx.m1 - 1);
@@ -394,25 +434,33 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
             if (rows_plain && cx.col_interior) {
 #pragma unroll
                 for (int i = 0; i < G; ++i)
-                    fused_step<T, kStepFast, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+                    fused_step<T, kStepFast, L1, UNR, NT, AN, false, NQ>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
             } else if (rows_plain) {
 #pragma unroll
                 for (int i = 0; i < G; ++i)
-                    fused_step<T, kStepSide, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+                    fused_step<T, kStepSide, L1, UNR, NT, AN, false, NQ>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
             } else {
 #pragma unroll
                 for (int i = 0; i < G; ++i)
-                    fused_step<T, kStepBorder, L1, UNR, NT, AN>(wr, wk, br, bk, acc, cx, g, fb + i, i);
+                    fused_step<T, kStepBorder, L1, UNR, NT, AN, false, NQ>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
             }
         }
 #pragma unroll
         for (int s = 0; s + G < NT; ++s) {
             wr[s] = wr[s + G]; wk[s] = wk[s + G]; br[s] = br[s + G]; bk[s] = bk[s + G];
+            if (MASKED) {
+                qr[s] = qr[s + G];
+                qk[s] = qk[s + G];
+            }
         }
 #pragma unroll
         for (int i = 0; i < G; ++i) {
             const int s0 = Win::slot(i, 0);
             wr[s0] = land[i][0]; wk[s0] = land[i][1]; br[s0] = land[i][2] * 0.25; bk[s0] = land[i][3] * 0.25;
+            if (MASKED) {
+                qr[s0] = landm[i][0] ? 0.25 : 0.0;
+                qk[s0] = landm[i][1] ? 0.25 : 0.0;
+            }
         }
     }
 }
@@ -473,6 +521,61 @@ k_fused_sweep(FusedParams P)
         if (EDGE && fused_is_edge_chunk(P, chunk)) fused_signal_edge(P);
     }
     fused_write_partials<L1, AN>(acc, P.partial, ch, scratch);
+}
+
+// Dirichlet-mask grid: every tile is an ordinary tile (rows and columns outside the block read as zero
+// through the buffer range check, and zero is what lies outside a Dirichlet region); a tile whose extended
+// region holds no unknown at all leaves at once (its pixels are zero in both ping-pong buffers and stay so).
+// tile_live: one byte per (chunk, strip), written by k_masked_tile_census for this tiling.
+constexpr int kMaskedMaxT = 6;           // the q window costs 2 VGPRs per pixel kept: depth 6 fits where depth 8 fits unmasked
+constexpr int kMaskedMaxCheckedT = 4;    // deepest masked pass that also reports the step of each of its sweeps
+__host__ __device__ constexpr int masked_waves_per_simd(int T, int L1 = 0)
+{
+    return L1 == 0 ? (T <= 1 ? 6 : T <= 2 ? 5 : T <= 3 ? 3 : 2) : (T <= 1 ? 4 : T <= 2 ? 3 : 2);
+}
+
+template <int T, int L1, int UNR>
+__global__ void __launch_bounds__(kBlock, masked_waves_per_simd(T, L1))
+k_fused_sweep_masked(FusedParams P, const unsigned char *__restrict__ tile_live)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int sx = blockIdx.x * (kBlock / kWave) + wave;
+    const int ch = blockIdx.z;
+    const int chunk = blockIdx.y;
+    int ra, rb;
+    fused_chunk_rows(P, chunk, ra, rb);
+    constexpr int AN = L1 == 2 ? T : 1;
+    double acc[AN];
+#pragma unroll
+    for (int t = 0; t < AN; ++t) acc[t] = 0.0;
+    const bool run = (P.active == nullptr) || (P.active[ch] != 0);
+    if (run && sx < P.n_strips && ra < rb && (tile_live == nullptr || tile_live[(long)chunk * P.n_strips + sx] != 0)) {
+        const Geom &g = P.g;
+        const long off = (long)ch * g.ch_stride;
+        fused_wave<T, false, L1, UNR, AN, true>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc, false, P.mask);
+    }
+    fused_write_partials<L1, AN>(acc, P.partial, ch, scratch);
+}
+
+// tile_live[chunk * n_strips + strip] = does the tile's extended region (its rows and columns plus the 2T
+// halo) hold any unknown?  grid = (n_strips, n_chunks), one wave per tile.
+__global__ void __launch_bounds__(kWave)
+k_masked_tile_census(FusedParams P, int T, unsigned char *__restrict__ tile_live)
+{
+    const int sx = blockIdx.x, chunk = blockIdx.y, lane = threadIdx.x;
+    int ra, rb;
+    fused_chunk_rows(P, chunk, ra, rb);
+    const Geom &g = P.g;
+    const int HS = 2 * T;
+    const int m0 = max(ra - HS, 0), m1 = min(rb + HS, g.local_rows);
+    const int U = fused_useful_px(T);
+    const int j = (sx * U - fused_halo_px(T)) / 2 + lane;
+    int any = 0;
+    if (j >= 0 && j < g.pitch)
+        for (int q = m0; q < m1; ++q) any |= P.mask[(long)q * 2 * g.pitch + j] | P.mask[(long)q * 2 * g.pitch + g.pitch + j];
+    const unsigned long long vote = __ballot(any != 0);
+    if (lane == 0) tile_live[(long)chunk * P.n_strips + sx] = vote ? 1 : 0;
 }
 
 // Border tiles, compactly enumerated: first the top and bottom chunk rows (strips away from the

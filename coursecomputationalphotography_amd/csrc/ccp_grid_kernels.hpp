@@ -131,11 +131,15 @@ __device__ __forceinline__ double apply_row(const Stencil &s, double xi, double 
 // lanes of a wave fetch it, together with the row's vector load, one row ahead.  (The first
 // version re-loaded it per lane a row later: by then the line had left the 4 MiB L2 and the
 // kernel fetched 1.43x its algorithmic read bytes — profiles/r01_half_sweep_v0_*.)
-template <int CPT, bool L1, bool SHFL>
+// MASKED (Dirichlet-mask grid, ccp_grid_set_mask_host): the uniform 5-point stencil with a_ii = 4 on the
+// pixels whose mask byte is 1; every other pixel — and everything outside the image — is fixed at zero, so
+// every pixel takes the interior arithmetic and a masked-out one is written back as 0.
+template <int CPT, bool L1, bool SHFL, bool MASKED = false>
 __global__ void __launch_bounds__(kBlock)
 k_half_sweep(const double *__restrict__ xr, double *__restrict__ xw, const double *__restrict__ b,
              Geom g, int c, int l_lo, int l_hi, int rows_per_block,
-             double *__restrict__ partial, const int *__restrict__ active)
+             double *__restrict__ partial, const int *__restrict__ active,
+             const unsigned char *__restrict__ mask = nullptr)
 {
     __shared__ double scratch[kBlock / kWave];
     const int ch = blockIdx.z;
@@ -189,8 +193,8 @@ k_half_sweep(const double *__restrict__ xr, double *__restrict__ xw, const doubl
             const int x_first = 2 * j0 + p;
             const int x_last = x_first + 2 * (CPT - 1);
             const bool owned = (l >= g.own_lo) && (l < g.own_hi);
-            const bool interior = (y >= 1) && (y <= g.H - 2) && (l >= 1) && (l + 1 < g.local_rows) &&
-                                  (x_first >= 1) && (x_last <= g.W - 2);
+            const bool interior = MASKED || ((y >= 1) && (y <= g.H - 2) && (l >= 1) && (l + 1 < g.local_rows) &&
+                                             (x_first >= 1) && (x_last <= g.W - 2));
             if (interior) {
 #pragma unroll
                 for (int k = 0; k < CPT; ++k) {
@@ -198,6 +202,7 @@ k_half_sweep(const double *__restrict__ xr, double *__restrict__ xw, const doubl
                     const double right = p ? (k == CPT - 1 ? side : mid[k < CPT - 1 ? k + 1 : k]) : mid[k];
                     // b - sigma with sigma = (((-xu) + (-xl)) + (-xr)) + (-xd); a_ii = 4
                     nv[k] = (bv[k] + (((up[k] + left) + right) + dn[k])) * 0.25;
+                    if (MASKED && mask[row_off(g, l, c) + j0 + k] == 0) nv[k] = 0.0;
                     if (L1 && owned) acc += fabs(nv[k] - old[k]);
                 }
                 st_vec<CPT>(xc + own, nv);
@@ -303,10 +308,10 @@ k_check_multi(const double *__restrict__ partial0, long blocks0, const double *_
 // MODE 2: b := A x and one partial sum of x'(A x) per block (the p'Ap of conjugateGradient,
 // sparse-matrix.h:419-420, fused into the SpMV pass).
 // grid = (ceil(pitch/(kBlock*CPT)), rows, channels*2); rows l in [l_lo, l_hi).
-template <int CPT, int MODE>
+template <int CPT, int MODE, bool MASKED = false>
 __global__ void __launch_bounds__(kBlock)
 k_apply(const double *__restrict__ x, double *__restrict__ bw, const double *__restrict__ br,
-        Geom g, int l_lo, double *__restrict__ partial)
+        Geom g, int l_lo, double *__restrict__ partial, const unsigned char *__restrict__ mask = nullptr)
 {
     __shared__ double scratch[kBlock / kWave];
     const int ch = blockIdx.z >> 1;
@@ -336,8 +341,22 @@ k_apply(const double *__restrict__ x, double *__restrict__ bw, const double *__r
             if (xi < g.W) {
                 const double left = p ? mid[k] : (k == 0 ? side : mid[k > 0 ? k - 1 : 0]);
                 const double right = p ? (k == CPT - 1 ? side : mid[k < CPT - 1 ? k + 1 : k]) : mid[k];
-                const Stencil s = classify(g, xi, y, l);
-                const double ax = apply_row(s, own[k], up[k], left, right, dn[k]);
+                double ax;
+                if (MASKED) {
+                    // the row of an unknown: -1 to its four neighbours (zero where there is no unknown), 4 on the
+                    // diagonal, applyToVector's order; a pixel fixed at zero has an empty row
+                    ax = 0.0;
+                    if (mask[row_off(g, l, c) + j0 + k] != 0) {
+                        ax += -1.0 * up[k];
+                        ax += -1.0 * left;
+                        ax += 4.0 * own[k];
+                        ax += -1.0 * right;
+                        ax += -1.0 * dn[k];
+                    }
+                } else {
+                    const Stencil s = classify(g, xi, y, l);
+                    ax = apply_row(s, own[k], up[k], left, right, dn[k]);
+                }
                 if (MODE == 0) {
                     bw[at + k] = ax;
                 } else if (MODE == 2) {

@@ -89,6 +89,22 @@ int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values,
  * raster mask gets its checkerboard). */
 int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours);
 
+/* Which kernels the last ccp_csr_gauss_seidel ran on.  The general path stores the matrix (sliced ELL);
+ * two matrix shapes are recognised at the first solve and swept matrix-free with identical results:
+ * SolveChannel's W x H Poisson matrix (PhotoMontage.cpp:541-597) and — multi-colour order — the 5-point
+ * Laplacian of a raster REGION with zero Dirichlet values around it (diagonal 4, -1 to the 4-neighbours
+ * inside, unknowns in raster order: a blend restricted to a brush / label region), whose pixel coordinates
+ * are reconstructed from the couplings and verified against every row.  canvas_*: the grid it ran on. */
+#define CCP_PATH_SLICED_ELL 0
+#define CCP_PATH_POISSON_GRID 1
+#define CCP_PATH_REGION_GRID 2
+int ccp_csr_last_path(ccp_csr *m, int32_t *path, int32_t *canvas_width, int32_t *canvas_height);
+/* The recognition alone, on the host (no device needed; diagnostics and tests): compressed CSR (row_offset has
+ * n+1 entries) plus a 2-colouring in, *recognised and — when 1 — the canvas size and the pixel coordinates of
+ * every unknown out (outputs after `recognised` may be NULL). */
+int ccp_csr_embed_region_host(int32_t n, const int32_t *row_offset, const int32_t *col, const double *val, const int32_t *colour,
+                              int32_t *recognised, int32_t *canvas_width, int32_t *canvas_height, int32_t *x_out, int32_t *y_out);
+
 /* SparseMatrix::insert(val, row, col) (sparse-matrix.h:183-247) on the uploaded matrix: val == 0 removes the
  * entry (insertZero: it becomes slack), an existing entry is overwritten, a new one is inserted in column
  * order (insertNoneZero).  The edit is applied to the device images of the matrix incrementally before the
@@ -99,6 +115,8 @@ int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours);
  * inside the uploaded shape.  ccp_csr_edit_stats: edits received, whole images built and uploaded, rows
  * patched, slices relocated, images dropped for a rebuild (outputs may be NULL). */
 int ccp_csr_insert(ccp_csr *m, int32_t row, int32_t col, double val);
+/* The same for a batch of edits, applied in order (a brush stroke; initializeFromTriplets, :256-263). */
+int ccp_csr_insert_many(ccp_csr *m, int64_t count, const int32_t *rows, const int32_t *cols, const double *vals);
 int ccp_csr_edit_stats(ccp_csr *m, int64_t *edits, int64_t *image_uploads, int64_t *rows_patched, int64_t *slices_relocated,
                        int64_t *image_rebuilds);
 
@@ -159,6 +177,16 @@ typedef struct ccp_grid_desc {
     int32_t flags;        /* CCP_GRID_* bits                                                 */
 } ccp_grid_desc;
 
+/* flags: a Dirichlet-mask grid.  Instead of SolveChannel's matrix the handle carries the 5-point Laplacian of
+ * an arbitrary pixel REGION of the W x H canvas: diagonal 4, -1 to every 4-neighbour inside the region,
+ * nothing outside (zero Dirichlet values around it) — the matrix a gradient-domain blend restricted to a
+ * brush / label region solves (BASELINE configs[4]).  The region is one byte per pixel (ccp_grid_set_mask_host);
+ * pixels outside it are fixed at 0 in x and b.  Sweeps (red-black, fixed count or stop rule), b := A x, the
+ * residual and conjugate gradient honour the mask; the SolveChannel-specific entry points (assembly,
+ * reference-order sweep) and row blocks return CCP_ERR_UNSUPPORTED.  ccp_csr_gauss_seidel reaches this form by
+ * itself when the uploaded matrix is such a Laplacian of a raster region (ccp_csr_last_path). */
+#define CCP_GRID_DIRICHLET_MASK 1
+
 /* Device layout, for callers that move halos themselves (torch.distributed / RCCL).
  * Element (channel ch, local row l, colour c, half-column j) of x or b lives at
  *   base + (((ch*local_rows + l)*2 + c)*pitch + j) * 8 bytes,
@@ -189,6 +217,8 @@ int ccp_grid_set_b_host(ccp_grid *g, int32_t channel, const double *rows, int32_
 int ccp_grid_set_x_host(ccp_grid *g, int32_t channel, const double *rows, int32_t first_row, int32_t n_rows);
 int ccp_grid_get_x_host(ccp_grid *g, int32_t channel, double *rows, int32_t first_row, int32_t n_rows);
 int ccp_grid_get_b_host(ccp_grid *g, int32_t channel, double *rows, int32_t first_row, int32_t n_rows);
+/* Dirichlet-mask grids: the region, H x W bytes (non-zero = unknown), row stride in bytes.  Synchronises. */
+int ccp_grid_set_mask_host(ccp_grid *g, const uint8_t *mask, int64_t row_stride_bytes);
 /* x := value everywhere (the reference start vector is 1.0, sparse-matrix.h:352). Async. */
 int ccp_grid_fill_x(ccp_grid *g, double value);
 /* b := A x (applyToVector order, sparse-matrix.h:382-393) on every local row whose neighbour

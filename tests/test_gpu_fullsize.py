@@ -354,10 +354,13 @@ def test_check_every_and_per_channel_freeze(capi, orc):
     g.close()
 
 
-def test_masked_csr_2048_canvas_vs_oracle(capi, orc):
-    """configs[4] shape at a 2048x2048 canvas (same generator, scaled radii): general CSR path,
-    red-black colouring, against the oracle; SpMV bit-exact."""
+@pytest.mark.parametrize("region_grid", ["1", "0"])
+def test_masked_csr_2048_canvas_vs_oracle(capi, orc, monkeypatch, region_grid):
+    """configs[4] shape at a 2048x2048 canvas (same generator, scaled radii): general CSR entry points,
+    red-black colouring, against the oracle — through the recognised raster-region grid and (CCP_GS_MASKED=0)
+    through the sliced-ELL kernels; SpMV bit-exact."""
     from coursecomputationalphotography_amd import synth
+    monkeypatch.setenv("CCP_GS_MASKED", region_grid)
     mask = synth.disc_mask(2048, 2048, seed=4321)
     v, c, r, colour, ys, xs = synth.masked_laplacian_csr(mask)
     n = len(ys)
@@ -368,6 +371,7 @@ def test_masked_csr_2048_canvas_vs_oracle(capi, orc):
     assert np.array_equal(b, synth.csr_apply(v, c, r, xt))
     m.set_colouring(colour, 2)
     x, rep = m.gauss_seidel(b, 0.0, 5, check_every=0, ordering=capi.ORDER_MULTICOLOUR)
+    assert m.last_path().startswith("region grid") == (region_grid == "1")
     want, _, _ = orc.multicolour_gauss_seidel(v, c, r, colour, b, 0.0, 5)
     assert np.array_equal(x, want)
     rr, bb = m.residual_norm2(b, x)
@@ -503,6 +507,7 @@ def test_config4_full_8192_mask_against_oracle(capi, orc):
     assert np.array_equal(b, synth.csr_apply(v, c, r, xt))
     m.set_colouring(colour, 2)
     x, rep = m.gauss_seidel(b, 0.0, 3, check_every=0, ordering=capi.ORDER_MULTICOLOUR)
+    assert m.last_path().startswith("region grid")           # recognised: swept matrix-free on the embedded canvas
     want, _, _ = orc.multicolour_gauss_seidel(v, c, r, colour, b, 0.0, 3)
     assert rep.iterations == 3 and np.array_equal(x, want)
     del want

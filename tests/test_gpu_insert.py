@@ -132,10 +132,10 @@ def test_thousand_edits_at_the_8192_mask(capi, orc):
     m.set_colouring(colour, 2)
     xt = synth.x_true(n, 4321)
     b = m.apply_to_vector(xt)
-    m.gauss_seidel(b, 0.0, 1, check_every=0, ordering=capi.ORDER_MULTICOLOUR)
+    m.gauss_seidel(b, 0.0, 1, check_every=0, ordering=capi.ORDER_MULTICOLOUR)      # (recognised: runs on the region grid)
     m.gauss_seidel(b, 0.0, 1, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
     before = m.edit_stats()
-    assert before["image_uploads"] == 3
+    assert before["image_uploads"] == 2                         # SpMV image + reference-order image; no colour image yet
     rng = np.random.Generator(np.random.MT19937(99))
     rows = np.repeat(np.arange(n, dtype=np.int64), np.diff(r))
     pick = rng.choice(len(v), 1000, replace=False)
@@ -177,8 +177,10 @@ def test_thousand_edits_at_the_8192_mask(capi, orc):
     assert np.array_equal(x1, want1)
     st = m.edit_stats()
     assert st["edits"] == 1000 + len(restore)
-    assert st["image_uploads"] == 3 and st["image_rebuilds"] == 0          # nothing was uploaded or scheduled again
-    assert st["rows_patched"] >= 3 * 900
+    # the edited matrix left the region grid: its colour-major image was built once, now; the two images that
+    # existed were patched — nothing was uploaded or scheduled again because of the edits
+    assert st["image_uploads"] == 3 and st["image_rebuilds"] == 0
+    assert st["rows_patched"] >= 2 * 900
     m.close()
 
 
