@@ -148,7 +148,7 @@ def load() -> C.CDLL:
     L.ccp_csr_get_colouring.argtypes = [vp, vp, C.POINTER(i32)]
     L.ccp_csr_insert.argtypes = [vp, i32, i32, dbl]
     L.ccp_csr_insert_many.argtypes = [vp, i64, vp, vp, vp]
-    L.ccp_csr_last_path.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
+    L.ccp_csr_last_path.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i64)]
     L.ccp_csr_edit_stats.argtypes = [vp] + [C.POINTER(i64)] * 5
     L.ccp_csr_gauss_seidel.argtypes = [vp, vp, vp, vp, dbl, i32, i32, i32, C.POINTER(Report)]
     L.ccp_csr_conjugate_gradient.argtypes = [vp, vp, vp, vp, dbl, i32, C.POINTER(Report)]
@@ -351,8 +351,9 @@ class CsrMatrix:
 
     def last_path(self) -> str:
         """Kernels of the last gauss_seidel: "sliced ELL", "Poisson grid WxH" or "region grid WxH" (canvas)."""
-        p, w, h = C.c_int32(), C.c_int32(), C.c_int32()
-        check(self.L.ccp_csr_last_path(self.h, C.byref(p), C.byref(w), C.byref(h)), "ccp_csr_last_path")
+        p, w, h, n = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        check(self.L.ccp_csr_last_path(self.h, C.byref(p), C.byref(w), C.byref(h), C.byref(n)), "ccp_csr_last_path")
+        self.last_sweep_launches = n.value
         return {0: "sliced ELL", 1: f"Poisson grid {w.value}x{h.value}", 2: f"region grid {w.value}x{h.value}"}[p.value]
 
     def insert_many(self, vals, rows, cols):

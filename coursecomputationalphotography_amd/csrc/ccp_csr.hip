@@ -118,6 +118,7 @@ struct ccp_csr {
     int region_w = 0, region_h = 0;
     bool allow_region = true;              // CCP_GS_MASKED=0 keeps such matrices on the sliced-ELL path
     int last_path = 0;                     // CCP_PATH_* of the last solve
+    long last_launches = 0;                // sweep launches of the last solve on a grid twin
     bool edited = false;                   // ccp_csr_insert changed the matrix since the upload
     bool allow_one_block = true;           // CCP_GS_ONE_BLOCK=0: always one launch per group
 };
@@ -743,6 +744,7 @@ int detect_region(ccp_csr *m)
         }
     });
     CCP_TRY(ccp_grid_set_mask_host(m->region_grid, mask.data(), E.W));
+    CCP_TRY(ccp_grid_tune(m->region_grid, 8, nullptr, nullptr, nullptr));      // depth (clamped to what a mask grid has) and chunk rows for this canvas: speed only
     CCP_TRY(upload_vec(m->region_where, where, m->stream));
     CCP_HIP(hipStreamSynchronize(m->stream));
     m->region_colour.swap(colour);
@@ -1158,10 +1160,11 @@ try {
     return CCP_OK;
 } CCP_ABI_CATCH
 
-int ccp_csr_last_path(ccp_csr *m, int32_t *path, int32_t *canvas_width, int32_t *canvas_height)
+int ccp_csr_last_path(ccp_csr *m, int32_t *path, int32_t *canvas_width, int32_t *canvas_height, int64_t *sweep_launches)
 try {
     if (!m) return CCP_ERR_BAD_ARG;
     if (path) *path = m->last_path;
+    if (sweep_launches) *sweep_launches = m->last_path == CCP_PATH_REGION_GRID ? m->last_launches : 0;
     if (canvas_width) *canvas_width = m->last_path == CCP_PATH_REGION_GRID ? m->region_w : (m->last_path == CCP_PATH_POISSON_GRID ? m->poisson_w : 0);
     if (canvas_height) *canvas_height = m->last_path == CCP_PATH_REGION_GRID ? m->region_h : (m->last_path == CCP_PATH_POISSON_GRID ? m->poisson_h : 0);
     return CCP_OK;
@@ -1249,7 +1252,12 @@ try {
                 hipLaunchKernelGGL((k_canvas_move<2>), dim3(blocks_for(n)), dim3(kBlock), 0, s, gx, m->tmp.p, m->region_where.p, n, 1.0);   // sparse-matrix.h:352
             }
             CCP_HIP(hipGetLastError());
+            CCP_TRY(ccp_grid_region_begin(g));
             CCP_TRY(ccp_grid_gauss_seidel(g, epsilon, max_iteration, check_every, report));
+            float region_ms = 0.f;
+            int64_t launches = 0, pass_iters = 0;
+            CCP_TRY(ccp_grid_region_end(g, &region_ms, &launches, &pass_iters));
+            m->last_launches = launches;
             hipLaunchKernelGGL((k_canvas_move<1>), dim3(blocks_for(n)), dim3(kBlock), 0, s, gx, m->tmp.p, m->region_where.p, n, 0.0);
             CCP_HIP(hipGetLastError());
             CCP_HIP(hipMemcpyAsync(x_out, m->tmp.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));

@@ -94,11 +94,12 @@ int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours);
  * SolveChannel's W x H Poisson matrix (PhotoMontage.cpp:541-597) and — multi-colour order — the 5-point
  * Laplacian of a raster REGION with zero Dirichlet values around it (diagonal 4, -1 to the 4-neighbours
  * inside, unknowns in raster order: a blend restricted to a brush / label region), whose pixel coordinates
- * are reconstructed from the couplings and verified against every row.  canvas_*: the grid it ran on. */
+ * are reconstructed from the couplings and verified against every row.  canvas_*: the grid it ran on;
+ * sweep_launches: kernel passes of the last solve on the region grid (each several iterations deep). */
 #define CCP_PATH_SLICED_ELL 0
 #define CCP_PATH_POISSON_GRID 1
 #define CCP_PATH_REGION_GRID 2
-int ccp_csr_last_path(ccp_csr *m, int32_t *path, int32_t *canvas_width, int32_t *canvas_height);
+int ccp_csr_last_path(ccp_csr *m, int32_t *path, int32_t *canvas_width, int32_t *canvas_height, int64_t *sweep_launches);
 /* The recognition alone, on the host (no device needed; diagnostics and tests): compressed CSR (row_offset has
  * n+1 entries) plus a 2-colouring in, *recognised and — when 1 — the canvas size and the pixel coordinates of
  * every unknown out (outputs after `recognised` may be NULL). */

@@ -106,10 +106,17 @@ def test_csr_upload_reaches_the_region_grid(capi, orc, monkeypatch, name):
     assert np.array_equal(x, want)
     got_col, nc = m.get_colouring()
     assert nc == 2 and np.array_equal(got_col, colour)
-    bs = b * 1e-3
-    want, it, eps = orc.multicolour_gauss_seidel(v, c, r, colour, bs, 0.5, 2000)
-    x, rep = m.gauss_seidel(bs, 0.5, 2000, check_every=1)
-    assert rep.converged == 1 and rep.iterations == it and np.array_equal(x, want)
+    # the stop rule: start close enough that the L1 step falls below the loop's initial eps = 10 (sparse-matrix.h:354)
+    near = orc.multicolour_gauss_seidel(v, c, r, colour, b, 0.0, 60)[0]
+    threshold = orc.multicolour_gauss_seidel(v, c, r, colour, b, 0.0, 37, x0=near)[2] * (1.0 + 1e-9)   # the step of sweep 37, a hair more
+    want, it, eps = orc.multicolour_gauss_seidel(v, c, r, colour, b, threshold, 2000, x0=near)
+    if threshold < 10.0:
+        assert 2 <= it <= 37
+        x, rep = m.gauss_seidel(b, threshold, 2000, x0=near, check_every=1)
+        assert rep.converged == 1 and rep.iterations == it and np.array_equal(x, want)
+    else:                                   # the reference loop never starts: eps = 10 <= epsilon
+        x, rep = m.gauss_seidel(b, threshold, 2000, x0=near, check_every=1)
+        assert it == 0 and rep.iterations == 0 and np.array_equal(x, near)
     # the reference's own order is not the region grid's business: general path, still exact
     x, _ = m.gauss_seidel(b, 0.0, 3, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
     assert m.last_path() == "sliced ELL"
@@ -137,10 +144,9 @@ def test_black_first_colouring_and_edit_fall_back(capi, orc):
     x, _ = m.gauss_seidel(b, 0.0, 9, check_every=0)
     assert m.last_path().startswith("region grid")
     assert np.array_equal(x, orc.multicolour_gauss_seidel(v, c, r, flipped, b, 0.0, 9)[0])
-    k = int(r[len(ys) // 2])
-    m.insert(5.0, len(ys) // 2, int(c[k]) if c[k] == len(ys) // 2 else len(ys) // 2)      # a heavier diagonal somewhere
-    v2 = v.copy()
     row = len(ys) // 2
+    m.insert(5.0, row, row)                                    # a heavier diagonal somewhere
+    v2 = v.copy()
     sel = np.arange(r[row], r[row + 1])
     v2[sel[c[sel] == row]] = 5.0
     x, _ = m.gauss_seidel(b, 0.0, 9, check_every=0)
