@@ -527,7 +527,7 @@ k_fused_sweep(FusedParams P)
 // through the buffer range check, and zero is what lies outside a Dirichlet region); a tile whose extended
 // region holds no unknown at all leaves at once (its pixels are zero in both ping-pong buffers and stay so).
 // tile_live: one byte per (chunk, strip), written by k_masked_tile_census for this tiling.
-constexpr int kMaskedMaxT = 6;           // the q window costs 2 VGPRs per pixel kept: depth 6 fits where depth 8 fits unmasked
+constexpr int kMaskedMaxT = 7;           // the q window costs 2 VGPRs per pixel kept: depth 6 fits where depth 8 fits unmasked
 constexpr int kMaskedMaxCheckedT = 4;    // deepest masked pass that also reports the step of each of its sweeps
 __host__ __device__ constexpr int masked_waves_per_simd(int T, int L1 = 0)
 {
