@@ -72,6 +72,9 @@ struct ccp_grid {
     DevBuf<int> redo_mask;       // per-channel flags for re-running one channel of a checked pass
     // lexicographic (reference-order) path: diagonal-major copies of x and b, snapshot, step sums
     DevBuf<double> lex_x, lex_b, lex_snap, lex_partial, lex_eps;
+    DevBuf<unsigned> lex_progress, lex_ticket;   // strip-wave pipeline: diagonals finished per (channel, sweep, strip); work tickets
+    int lex_mode = 1;            // 1: strip waves, one launch for all sweeps (default); 0: one launch per hyperplane (CCP_GS_LEX_MODE=planes)
+    int lex_chunk = 0;           // diagonals between two progress publications (CCP_GS_LEX_CHUNK; 0 = by size)
     LexGeom lexg{};
     DevBuf<double> stage;        // natural-order staging rows for host transfers
     long stage_rows = 0;
@@ -643,6 +646,8 @@ try {
     if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SHORT_EDGES")) g->short_edges = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SIDE_ROWS")) g->side_rows_override = atoi(e);
+    if (const char *e = getenv("CCP_GS_LEX_MODE")) g->lex_mode = strcmp(e, "planes") == 0 ? 0 : 1;
+    if (const char *e = getenv("CCP_GS_LEX_CHUNK")) g->lex_chunk = atoi(e);
     if (const char *e = getenv("CCP_GS_TMAX")) g->fuse_tmax = std::max(1, std::min(kFusedMaxT, atoi(e)));
     if (const char *e = getenv("CCP_GS_ALL_BORDER")) g->all_border = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_FORCE_BORDER")) g->force_border = atoi(e) != 0;
@@ -1167,8 +1172,38 @@ namespace {
 
 // `iterations` lexicographic sweeps of the channels in `mask`, pipelined over the hyperplanes
 // tau = x + y + 2k (ccp_grid_lex.hpp).  partial != nullptr: per-sweep step sums are written too.
+int lex_strips(const ccp_grid *g) { return (g->desc.width + kLexStripCols - 1) / kLexStripCols; }
+
+// partial sums one checked sweep writes per channel
+long lex_partials_per_sweep(const ccp_grid *g) { return g->lex_mode == 1 ? (long)lex_strips(g) : (long)g->lexg.n_diag * g->lexg.nbx; }
+
+// `iterations` lexicographic sweeps of the channels in `mask` as ONE launch of strip waves (k_lex_strips).
+int lex_run_strips(ccp_grid *g, int iterations, unsigned mask, double *partial)
+{
+    const LexGeom &lg = g->lexg;
+    const int C = g->desc.channels, S = lex_strips(g);
+    int chunk = g->lex_chunk;
+    if (chunk <= 0) chunk = std::min(lg.W, lg.H) <= 1024 ? 8 : (std::min(lg.W, lg.H) <= 4096 ? 16 : 32);
+    chunk = std::max(1, std::min(chunk, kWave));
+    const size_t need = (size_t)C * iterations * S;
+    if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
+    if (!g->lex_ticket.p) CCP_TRY(g->lex_ticket.alloc(kMaxChannels));
+    CCP_HIP(hipMemsetAsync(g->lex_progress.p, 0, need * sizeof(unsigned), g->stream));
+    CCP_HIP(hipMemsetAsync(g->lex_ticket.p, 0, kMaxChannels * sizeof(unsigned), g->stream));
+    dim3 grid((unsigned)((long)iterations * S), (unsigned)C);
+    if (partial)
+        hipLaunchKernelGGL((k_lex_strips<true>), grid, dim3(kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, iterations, S, chunk,
+                           g->lex_progress.p, g->lex_ticket.p, mask, partial);
+    else
+        hipLaunchKernelGGL((k_lex_strips<false>), grid, dim3(kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, iterations, S, chunk,
+                           g->lex_progress.p, g->lex_ticket.p, mask, static_cast<double *>(nullptr));
+    CCP_HIP(hipGetLastError());
+    return CCP_OK;
+}
+
 int lex_run(ccp_grid *g, int iterations, unsigned mask, double *partial)
 {
+    if (g->lex_mode == 1 && iterations > 0) return lex_run_strips(g, iterations, mask, partial);
     const LexGeom &lg = g->lexg;
     const int d_max = lg.n_diag - 1;
     const int C = g->desc.channels;
@@ -1230,14 +1265,14 @@ try {
         // fixed count — or the reference loop never starts (eps = 10 <= epsilon)
         const int n = check_every == 0 ? max_iteration : 0;
         for (int done = 0; done < n;) {                    // gridDim.y carries the sweeps in flight: keep it small
-            const int kb = std::min(32768, n - done);
+            const int kb = std::min(g->lex_mode == 1 ? 4096 : 32768, n - done);   // (strip waves: one progress word per sweep and strip)
             CCP_TRY(lex_run(g, kb, all, nullptr));
             done += kb;
         }
         for (int ch = 0; ch < C; ++ch) iterations_of[ch] = n;
     } else {
         const int batch_max = 128;                                       // sweeps in flight between two looks at the rule
-        const long per = (long)lg.n_diag * lg.nbx;                          // partials per (iteration, channel)
+        const long per = lex_partials_per_sweep(g);                         // partials per (iteration, channel)
         if (g->lex_partial.n != (size_t)per * batch_max * C) CCP_TRY(g->lex_partial.alloc((size_t)per * batch_max * C));
         if (g->lex_eps.n != (size_t)batch_max * C) CCP_TRY(g->lex_eps.alloc((size_t)batch_max * C));
         if (g->lex_snap.n != elems) CCP_TRY(g->lex_snap.alloc(elems));

@@ -19,6 +19,7 @@
 #pragma once
 
 #include "ccp_grid_kernels.hpp"
+#include "ccp_grid_fused.hpp"      // lane_prev / lane_next (DPP)
 
 namespace ccp {
 
@@ -88,6 +89,126 @@ k_lex_plane(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexG
         const double total = block_sum(acc, scratch);
         if (threadIdx.x == 0)
             partial[(((long)k * gridDim.z + ch) * lg.n_diag + d) * lg.nbx + blockIdx.x] = total;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same sweep without a launch per hyperplane: STRIP WAVES.  One wavefront owns a strip of 64 image
+// columns of one sweep k and marches down the diagonals d = x + y: lane l walks down column x0 + l, one row
+// per step, so at step d the wave's 64 pixels are exactly the strip's piece of diagonal d — one 512-byte
+// row of the diagonal-major arrays.  Of the four neighbours of a pixel
+//   up    (x, y-1), new : the lane's own previous result          (register)
+//   left  (x-1, y), new : the left lane's previous result         (DPP wave_shr; lane 0: the strip to the left)
+//   down  (x, y+1), old : row d+1 of x, same column               (coalesced load)
+//   right (x+1, y), old : the right lane's `down` value           (DPP wave_shl; lane 63: the strip to the right)
+// only the two strip-edge values come from another wave, through memory: wave (k, s) at step d needs
+//   (k, s-1) finished through diagonal d-1,  (k-1, s) and (k-1, s+1) finished through diagonal d+1,
+// exactly the hyperplane order restricted to neighbours.  Every wave publishes its progress (diagonals
+// finished) every `chunk` steps — stores drained, agent-scope release, then the counter — and checks its
+// three producers once per chunk (agent-scope acquire, then plain loads; MI355X_MICROARCH.md, correctness
+// boundaries).  In place on the diagonal-major x: a value is overwritten only after every reader of the old
+// one is past it (the readers are the producers this wave waits for, or this wave itself).
+// Work items are handed out by a ticket counter in (sweep, strip) order: a wave only ever waits for tickets
+// smaller than its own, which belong to waves that have already started — no assumption about dispatch
+// order or co-residency, no deadlock.  The whole pipeline of K sweeps is ONE launch: the sweep count no
+// longer multiplies launches, and the rate is the same whether 4 or 4000 sweeps are asked for.
+// grid = (K * S, channels), block = 64.  CHECK: partial[(k*channels + ch)*S + s] = the wave's sum |new - old|.
+constexpr int kLexStripCols = kWave;
+constexpr unsigned kLexDone = 0xffffffffu;
+
+__device__ __forceinline__ void lex_wait(const unsigned *progress, unsigned need)
+{
+    if (progress == nullptr) return;
+    if ((threadIdx.x & (kWave - 1)) == 0) {
+        while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+template <bool CHECK>
+__global__ void __launch_bounds__(kWave)
+k_lex_strips(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int K, int S, int chunk,
+             unsigned *__restrict__ progress, unsigned *__restrict__ ticket, unsigned active_mask, double *__restrict__ partial)
+{
+    const int ch = blockIdx.y;
+    if (!((active_mask >> ch) & 1u)) return;
+    const int lane = threadIdx.x;
+    unsigned t = 0;
+    if (lane == 0) t = atomicAdd(&ticket[ch], 1u);
+    t = (unsigned)__builtin_amdgcn_readfirstlane((int)__shfl((int)t, 0, kWave));
+    const int k = (int)(t / (unsigned)S), s = (int)(t % (unsigned)S);
+    const int x0 = s * kLexStripCols, x = x0 + lane;
+    const bool col_ok = x < lg.W;
+    const int x_last = min(x0 + kLexStripCols - 1, lg.W - 1);
+    const int d_begin = x0, d_end = x_last + lg.H - 1;
+    unsigned *prog = progress + ((long)ch * K + k) * S;
+    unsigned *mine = prog + s;
+    const unsigned *left_p = s > 0 ? prog + (s - 1) : nullptr;
+    const unsigned *prev0_p = k > 0 ? prog - S + s : nullptr;
+    const unsigned *prev1_p = (k > 0 && s + 1 < S) ? prog - S + s + 1 : nullptr;
+    const long plane = (long)ch * lg.plane;
+    double prev_new = 0.0;                                   // the lane's latest result: (x, y-1) for itself, (x-1, y) for the next lane
+    double acc = 0.0;
+    for (int dc = d_begin; dc <= d_end; dc += chunk) {
+        const int de = min(dc + chunk - 1, d_end);
+        // producers: (k, s-1) through diagonal de-1; (k-1, s) and (k-1, s+1) through diagonal de+1
+        lex_wait(left_p, (unsigned)de);
+        lex_wait(prev0_p, (unsigned)(de + 2));
+        if (de + 1 >= x0 + kLexStripCols) lex_wait(prev1_p, (unsigned)(de + 2));
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // the two edge columns of this chunk, one step per lane (chunk <= 64):
+        //   left  edge: pixel (x0-1, y) on diagonal d-1, new   -> element [d-1][x0-1]
+        //   right edge: pixel (x_last+1, y) on diagonal d+1, old -> element [d+1][x_last+1]
+        double edge_left = 0.0, edge_right = 0.0;
+        {
+            const int d = dc + lane;
+            if (d <= de) {
+                if (x0 > 0) {
+                    const int yl = d - 1 - (x0 - 1);
+                    if (yl >= 0 && yl < lg.H) edge_left = xd[plane + (long)(d - 1) * lg.P + (x0 - 1)];
+                }
+                if (x_last + 1 < lg.W) {
+                    const int yr = d + 1 - (x_last + 1);
+                    if (yr >= 0 && yr < lg.H) edge_right = xd[plane + (long)(d + 1) * lg.P + (x_last + 1)];
+                }
+            }
+        }
+        for (int d = dc; d <= de; ++d) {
+            const int y = d - x;
+            const bool on = col_ok && y >= 0 && y < lg.H;
+            const long i = plane + (long)d * lg.P + x;
+            double down = 0.0, bv = 0.0, old = 0.0;
+            if (on) {
+                bv = bd[i];
+                if (y + 1 < lg.H) down = xd[i + lg.P];            // (x, y+1) on diagonal d+1, same column
+                if (CHECK) old = xd[i];
+            }
+            const int j = d - dc;
+            double left = lane_prev(prev_new);
+            const double el = __shfl(edge_left, j, kWave), er = __shfl(edge_right, j, kWave);
+            if (lane == 0) left = el;
+            double right = lane_next(down);
+            if (x == x_last) right = er;
+            if (on) {
+                const Stencil st = classify(g, x, y, y);
+                if (st.diag != 0) {                              // empty row: skipped (sparse-matrix.h:361-363)
+                    double nv;
+                    if (st.up && st.left && st.right && st.down && st.diag == 4) nv = (bv + (((prev_new + left) + right) + down)) * 0.25;
+                    else (void)gs_update(st, bv, prev_new, left, right, down, nv);
+                    if (CHECK) acc += fabs(nv - old);
+                    xd[i] = nv;
+                    prev_new = nv;
+                } else {
+                    prev_new = xd[i];                            // the value the row keeps is what its neighbours see
+                }
+            }
+        }
+        // publish: every lane's stores drained and written back at agent scope, then the counter
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (lane == 0) __hip_atomic_store(mine, de == d_end ? kLexDone : (unsigned)(de + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (CHECK) {
+        const double total = wave_sum(acc);
+        if (lane == 0) partial[((long)k * gridDim.y + ch) * S + s] = total;
     }
 }
 
