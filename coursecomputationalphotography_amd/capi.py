@@ -431,6 +431,7 @@ class Grid:
         self.first_local_row = row_begin - self.layout.ghost_top       # image row of local row 0
         self.local_rows = self.layout.local_rows
         self._comm = None
+        self.stream_handle = 0                                   # the null stream until set_stream says otherwise
         _live_grids.add(self)
         if mask is not None:
             self.set_mask(mask)
@@ -456,6 +457,7 @@ class Grid:
 
     def set_stream(self, stream_handle: int):
         check(self.L.ccp_grid_set_stream(self.h, C.c_void_p(stream_handle)), "ccp_grid_set_stream")
+        self.stream_handle = int(stream_handle or 0)
 
     def synchronize(self):
         check(self.L.ccp_grid_synchronize(self.h), "ccp_grid_synchronize")

@@ -104,17 +104,25 @@ k_lex_plane(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexG
 // only the two strip-edge values come from another wave, through memory: wave (k, s) at step d needs
 //   (k, s-1) finished through diagonal d-1,  (k-1, s) and (k-1, s+1) finished through diagonal d+1,
 // exactly the hyperplane order restricted to neighbours.  Every wave publishes its progress (diagonals
-// finished) every `chunk` steps — stores drained, agent-scope release, then the counter — and checks its
-// three producers once per chunk (agent-scope acquire, then plain loads; MI355X_MICROARCH.md, correctness
-// boundaries).  In place on the diagonal-major x: a value is overwritten only after every reader of the old
-// one is past it (the readers are the producers this wave waits for, or this wave itself).
+// finished) every `chunk` steps and checks its three producers once per chunk.  Hand-off through memory
+// (MI355X_MICROARCH.md, correctness boundaries: the per-XCD L2s are not coherent with each other): every
+// access to x is an agent-scope (sc1) load or store — write-through, never served from a stale line — and a
+// wave drains its stores (s_waitcnt vmcnt(0)) before it publishes the counter.  Cache-wide release/acquire
+// fences instead (buffer_wbl2 / buffer_inv per chunk and wave) were measured 4x slower: thousands of waves
+// flushing and invalidating whole L2s serialise on the caches.  In place on the diagonal-major x: a value is
+// overwritten only after every reader of the old one is past it (the readers are the producers this wave
+// waits for, or this wave itself).
 // Work items are handed out by a ticket counter in (sweep, strip) order: a wave only ever waits for tickets
 // smaller than its own, which belong to waves that have already started — no assumption about dispatch
 // order or co-residency, no deadlock.  The whole pipeline of K sweeps is ONE launch: the sweep count no
 // longer multiplies launches, and the rate is the same whether 4 or 4000 sweeps are asked for.
 // grid = (K * S, channels), block = 64.  CHECK: partial[(k*channels + ch)*S + s] = the wave's sum |new - old|.
 constexpr int kLexStripCols = kWave;
+constexpr int kLexSub = 8;               // steps per software-pipeline block
 constexpr unsigned kLexDone = 0xffffffffu;
+
+__device__ __forceinline__ double lex_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void lex_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __device__ __forceinline__ void lex_wait(const unsigned *progress, unsigned need)
 {
@@ -154,7 +162,7 @@ k_lex_strips(double *__restrict__ xd, const double *__restrict__ bd, Geom g, Lex
         lex_wait(left_p, (unsigned)de);
         lex_wait(prev0_p, (unsigned)(de + 2));
         if (de + 1 >= x0 + kLexStripCols) lex_wait(prev1_p, (unsigned)(de + 2));
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // compiler ordering only: no load of x moves above the waits
         // the two edge columns of this chunk, one step per lane (chunk <= 64):
         //   left  edge: pixel (x0-1, y) on diagonal d-1, new   -> element [d-1][x0-1]
         //   right edge: pixel (x_last+1, y) on diagonal d+1, old -> element [d+1][x_last+1]
@@ -164,46 +172,79 @@ k_lex_strips(double *__restrict__ xd, const double *__restrict__ bd, Geom g, Lex
             if (d <= de) {
                 if (x0 > 0) {
                     const int yl = d - 1 - (x0 - 1);
-                    if (yl >= 0 && yl < lg.H) edge_left = xd[plane + (long)(d - 1) * lg.P + (x0 - 1)];
+                    if (yl >= 0 && yl < lg.H) edge_left = lex_ld(&xd[plane + (long)(d - 1) * lg.P + (x0 - 1)]);
                 }
                 if (x_last + 1 < lg.W) {
                     const int yr = d + 1 - (x_last + 1);
-                    if (yr >= 0 && yr < lg.H) edge_right = xd[plane + (long)(d + 1) * lg.P + (x_last + 1)];
+                    if (yr >= 0 && yr < lg.H) edge_right = lex_ld(&xd[plane + (long)(d + 1) * lg.P + (x_last + 1)]);
                 }
             }
         }
-        for (int d = dc; d <= de; ++d) {
-            const int y = d - x;
-            const bool on = col_ok && y >= 0 && y < lg.H;
-            const long i = plane + (long)d * lg.P + x;
-            double down = 0.0, bv = 0.0, old = 0.0;
-            if (on) {
-                bv = bd[i];
-                if (y + 1 < lg.H) down = xd[i + lg.P];            // (x, y+1) on diagonal d+1, same column
-                if (CHECK) old = xd[i];
-            }
-            const int j = d - dc;
-            double left = lane_prev(prev_new);
-            const double el = __shfl(edge_left, j, kWave), er = __shfl(edge_right, j, kWave);
-            if (lane == 0) left = el;
-            double right = lane_next(down);
-            if (x == x_last) right = er;
-            if (on) {
-                const Stencil st = classify(g, x, y, y);
-                if (st.diag != 0) {                              // empty row: skipped (sparse-matrix.h:361-363)
-                    double nv;
-                    if (st.up && st.left && st.right && st.down && st.diag == 4) nv = (bv + (((prev_new + left) + right) + down)) * 0.25;
-                    else (void)gs_update(st, bv, prev_new, left, right, down, nv);
-                    if (CHECK) acc += fabs(nv - old);
-                    xd[i] = nv;
-                    prev_new = nv;
-                } else {
-                    prev_new = xd[i];                            // the value the row keeps is what its neighbours see
+        // The march, software-pipelined in blocks of kLexSub steps: the loads of a block (the row below, b, and
+        // for the stop rule the old value) are issued a whole block ahead of their use, so a step never waits
+        // for memory — only the two edge gathers above and the first block of a chunk are exposed.
+        double q_down[kLexSub], q_b[kLexSub], q_old[kLexSub], n_down[kLexSub], n_b[kLexSub], n_old[kLexSub];
+        auto fetch = [&](int d0, double (&fd)[kLexSub], double (&fb)[kLexSub], double (&fo)[kLexSub]) {
+#pragma unroll
+            for (int q = 0; q < kLexSub; ++q) {
+                const int d = d0 + q, y = d - x;
+                const long i = plane + (long)d * lg.P + x;
+                const bool in_chunk = d <= de;
+                const bool on = in_chunk && col_ok && y >= 0 && y < lg.H;
+                fd[q] = 0.0;
+                fb[q] = 0.0;
+                fo[q] = 0.0;
+                // (x, y+1) on diagonal d+1, same column: also the RIGHT neighbour of the lane to the left, which is
+                // one row ahead — so it is fetched from the row before this lane's first (y = -1) as well
+                if (in_chunk && col_ok && y + 1 >= 0 && y + 1 < lg.H) fd[q] = lex_ld(&xd[i + lg.P]);
+                if (on) {
+                    fb[q] = bd[i];
+                    if (CHECK) fo[q] = lex_ld(&xd[i]);
                 }
             }
+        };
+        fetch(dc, q_down, q_b, q_old);
+        for (int sb = dc; sb <= de; sb += kLexSub) {
+            if (sb + kLexSub <= de) fetch(sb + kLexSub, n_down, n_b, n_old);
+#pragma unroll
+            for (int q = 0; q < kLexSub; ++q) {
+                const int d = sb + q;
+                if (d <= de) {                                   // (wave-uniform)
+                    const int y = d - x;
+                    const bool on = col_ok && y >= 0 && y < lg.H;
+                    const long i = plane + (long)d * lg.P + x;
+                    const double down = q_down[q], bv = q_b[q], old = q_old[q];
+                    const int j = d - dc;
+                    double left = lane_prev(prev_new);
+                    const double el = __shfl(edge_left, j, kWave), er = __shfl(edge_right, j, kWave);
+                    if (lane == 0) left = el;
+                    double right = lane_next(down);
+                    if (x == x_last) right = er;
+                    if (on) {
+                        const Stencil st = classify(g, x, y, y);
+                        if (st.diag != 0) {                      // empty row: skipped (sparse-matrix.h:361-363)
+                            double nv;
+                            if (st.up && st.left && st.right && st.down && st.diag == 4) nv = (bv + (((prev_new + left) + right) + down)) * 0.25;
+                            else (void)gs_update(st, bv, prev_new, left, right, down, nv);
+                            if (CHECK) acc += fabs(nv - old);
+                            lex_st(&xd[i], nv);
+                            prev_new = nv;
+                        } else {
+                            prev_new = lex_ld(&xd[i]);           // the value the row keeps is what its neighbours see
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kLexSub; ++q) {
+                q_down[q] = n_down[q];
+                q_b[q] = n_b[q];
+                q_old[q] = n_old[q];
+            }
         }
-        // publish: every lane's stores drained and written back at agent scope, then the counter
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        // publish: every lane's (write-through) stores acknowledged, then the counter
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // compiler ordering only
+        __builtin_amdgcn_s_waitcnt(0);
         if (lane == 0) __hip_atomic_store(mine, de == d_end ? kLexDone : (unsigned)(de + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (CHECK) {
