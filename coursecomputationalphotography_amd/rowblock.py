@@ -155,16 +155,14 @@ class RowBlockSolver:
         # gloo cannot move device memory: stage through host copies (CPU tests of the GPU
         # path with several ranks on one card; RCCL sends the device rows directly)
         staged = x.is_cuda and dist.get_backend(self.group) == "gloo"
-        if x.is_cuda and not staged:
+        if x.is_cuda and dist.get_backend(self.group) == "nccl":
             # Stream contract of this (torch.distributed) path: ProcessGroupNCCL orders its send/receive kernels
             # after the CURRENT torch stream, and the grid's kernels run on the handle's stream — the two must be
             # the same stream, which is only the case while the handle is on the null stream (torch's default
             # stream on ROCm).  The path that does not depend on this is halo="abi" (ccp_grid_*_rowblocked).
-            import torch
-            grid_stream = getattr(getattr(blk, "grid", None), "stream_handle", 0)
-            if grid_stream != 0 or torch.cuda.current_stream(x.device).cuda_stream != 0:
-                raise RuntimeError("torch.distributed halo exchange needs the grid handle and torch on the null stream; "
-                                   "use rowblock.make_solver(..., halo='abi') with a stream of your own")
+            if getattr(getattr(blk, "grid", None), "stream_handle", 0) != 0:
+                raise RuntimeError("torch.distributed halo exchange needs the grid handle on the null stream (torch's "
+                                   "default); use rowblock.make_solver(..., halo='abi') with a stream of your own")
         out = [(t.cpu() if staged else t, p) for t, p in sends]
         inn = [((t.new_empty(t.shape, device="cpu") if staged else t), p) for t, p in recvs]
         ops = [dist.P2POp(dist.isend, t, p, self.group) for t, p in out]
