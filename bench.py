@@ -220,10 +220,11 @@ def config0(capi):
     want, _, _ = oracle.Oracle().from_csr(v, c, r).gauss_seidel(b, 0.0, iters)
     ups = W * H * iters / rep.seconds
     return {"workload": "512x512 single-channel Poisson, lexicographic Gauss-Seidel (reference order), 100 iterations",
-            "kernel": "k_lex_plane (one launch per hyperplane x + y + 2k)", "ms": rep.seconds * 1e3,
+            "kernel": "k_lex_strips (strip waves marching down the hyperplanes x + y + 2k, all sweeps in one launch)", "ms": rep.seconds * 1e3,
             "pixel_updates_per_s": ups,
             "bytes_model": "32 B per update (two neighbour diagonals 16 + b 8 + x write 8)",
-            "frac": ups * 32.0 / 1e9 / HBM_PEAK_GBS, "bound_note": "launch-rate bound at this size (W+H+2K launches of a few us)",
+            "frac": ups * 32.0 / 1e9 / HBM_PEAK_GBS,
+            "bound_note": "latency bound at this size: 8 strips x 100 sweeps = 800 waves on a critical path of W+H+(chunk+2)K dependent steps",
             "bit_identical_to_oracle": bool(np.array_equal(x, want)),
             "cpu_baseline": {"value": W * H * iters / secs, "unit": "pixel-updates/s", "cores": 1, "kind": kind,
                              "sample": f"the same system and iteration count, {secs:.3f} s"}}
@@ -428,7 +429,7 @@ def main():
         rep = g.gauss_seidel_lexicographic(0.0, args.reference_order_iters, 0)[0]
         extra["reference_order"] = {
             "what": "lexicographic Gauss-Seidel (the reference's index-order sweep, sparse-matrix.h:357-370), "
-                    "hyperplane-pipelined; iterates bit-identical to the reference's",
+                    "strip waves over the hyperplanes x + y + 2k, one launch; iterates bit-identical to the reference's",
             "iterations": rep.iterations, "seconds": rep.seconds,
             "pixel_updates_per_s": float(W) * H * C * rep.iterations / rep.seconds,
             "rel_residual_after": float(solver.rel_residual().max())}

@@ -69,25 +69,36 @@ if not a.no_mask:
     v, c, r, colour, ys, xs = synth.masked_laplacian_csr(mask)
     nn = len(ys)
     b = np.ones(nn)
-    m = capi.CsrMatrix()
-    t0 = time.perf_counter()
-    m.upload_compressed(v, c, r)
-    m.set_colouring(colour, 2)
-    m.gauss_seidel(b, 0.0, 1, check_every=0)
-    t_first = time.perf_counter() - t0
     rows = np.repeat(np.arange(nn, dtype=np.int64), np.diff(r))
     rng = np.random.Generator(np.random.MT19937(5))
     pick = rng.choice(len(v), a.mask_edits, replace=False)
-    t0 = time.perf_counter()
-    for k in pick:
-        m.insert(float(v[k]) * 0.5, int(rows[k]), int(c[k]))
-    t_edit = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    _, rep = m.gauss_seidel(b, 0.0, 1, check_every=0)
-    t_solve = time.perf_counter() - t0
-    st = m.edit_stats()
-    m.close()
-    out["mask_8192_brush_edits"] = {"unknowns": nn, "edits": int(a.mask_edits), "upload_schedule_first_solve_s": t_first,
-                                    "edit_calls_ms": t_edit * 1e3, "flush_plus_one_sweep_incl_host_vectors_ms": t_solve * 1e3,
-                                    "sweep_device_ms": rep.seconds * 1e3, "stats": st}
+    # (a) the matrix on the general (sliced-ELL) path: every edit is a patch of the resident image.
+    # (b) the matrix recognised as a raster region: the FIRST edit ends the matrix-free form (its stencil is no
+    #     longer uniform) and the general image is built once; later edits are patches as in (a).
+    for label, env in (("general_path", "0"), ("from_region_grid", "1")):
+        os.environ["CCP_GS_MASKED"] = env
+        m = capi.CsrMatrix()
+        t0 = time.perf_counter()
+        m.upload_compressed(v, c, r)
+        m.set_colouring(colour, 2)
+        m.gauss_seidel(b, 0.0, 1, check_every=0)
+        t_first = time.perf_counter() - t0
+        path0 = m.last_path()
+        t0 = time.perf_counter()
+        m.insert_many(v[pick] * 0.5, rows[pick], c[pick])
+        t_edit = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        _, rep = m.gauss_seidel(b, 0.0, 1, check_every=0)
+        t_solve = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        m.insert_many(v[pick] * 0.25, rows[pick], c[pick])
+        _, rep2 = m.gauss_seidel(b, 0.0, 1, check_every=0)
+        t_again = time.perf_counter() - t0
+        st = m.edit_stats()
+        out["mask_8192_brush_edits_" + label] = {
+            "unknowns": nn, "edits_per_batch": int(a.mask_edits), "path_before": path0, "path_after": m.last_path(),
+            "upload_setup_first_solve_s": t_first, "edit_calls_ms": t_edit * 1e3,
+            "first_batch_flush_plus_one_sweep_incl_host_vectors_ms": t_solve * 1e3,
+            "second_batch_edit_flush_sweep_incl_host_vectors_ms": t_again * 1e3, "sweep_device_ms": rep2.seconds * 1e3, "stats": st}
+        m.close()
 print(json.dumps(out))
