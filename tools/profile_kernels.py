@@ -3,14 +3,18 @@
 one PMC counter per run; tools/profile_round.sh drives the passes):
   apply   k_sell_apply     SpMV of the 8192^2 mask matrix (applyToVector)
   gs      k_sell_gs        multi-colour Gauss-Seidel sweeps of the same matrix
+  region  k_fused_sweep_masked   the same matrix recognised as a raster region (Dirichlet-mask grid)
   pipe    k_sell_gs_pipe   the same matrix in the reference's own order (pipelined level schedule)
-  lex     k_lex_plane      reference-order sweeps of the 16384^2 grid (hyperplane pipeline)
+  lex     k_lex_strips     reference-order sweeps of the 16384^2 grid (strip waves; CCP_GS_LEX_MODE=planes: k_lex_plane)
+  edge    k_fused_sweep<8,0,2,true>   one interior row block of an 8-GPU run: intervals with the in-launch edge hand-off
 usage: profile_kernels.py [--canvas N] [--grid N] [--sweeps K] [apply] [gs] [pipe] [lex]   (default: all four)
 Under --pmc the two launch-bound kernels issue tens of thousands of tiny dispatches, each serialised by the
 counter collection: use a smaller --canvas / --grid there."""
 import argparse
 import os
 import sys
+
+import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from coursecomputationalphotography_amd import capi, synth  # noqa: E402
@@ -21,11 +25,20 @@ ap.add_argument("--grid", type=int, default=16384)
 ap.add_argument("--sweeps", type=int, default=16)
 ap.add_argument("what", nargs="*")
 a = ap.parse_args()
-what = set(a.what) or {"apply", "gs", "pipe", "lex"}
-if what & {"apply", "gs", "pipe"}:
+what = set(a.what) or {"apply", "gs", "pipe", "lex", "region"}
+if what & {"apply", "gs", "pipe", "region"}:
     mask = synth.disc_mask(a.canvas, a.canvas, seed=4321)
     v, c, r, colour, ys, xs = synth.masked_laplacian_csr(mask)
     n = len(ys)
+    if "region" in what:                                   # first, while CCP_GS_MASKED is as the caller set it
+        m = capi.CsrMatrix().upload_compressed(v, c, r)
+        m.set_colouring(colour, 2)
+        bb = np.ones(n)
+        m.gauss_seidel(bb, 0.0, 14, check_every=0)
+        m.gauss_seidel(bb, 0.0, 70, check_every=0)
+        print(f"region: {m.last_path()}", flush=True)
+        m.close()
+    os.environ["CCP_GS_MASKED"] = "0"                      # the kernels below are the stored-matrix ones
     m = capi.CsrMatrix().upload_compressed(v, c, r)
     m.set_colouring(colour, 2)
     xt = synth.x_true(n, 4321)
@@ -50,4 +63,22 @@ if "lex" in what:
     g.fill_x(1.0)
     rep = g.gauss_seidel_lexicographic(0.0, a.sweeps, 0)[0]
     print(f"lex: {rep.iterations} sweeps of {W}x{H} in {rep.seconds:.3f} s", flush=True)
+    g.close()
+if "edge" in what:
+    W = H = 16384
+    rows, ghost = H // 8, 64
+    g = capi.Grid(W, H, 1, rows * 4, rows, ghost, 0)
+    g.randomize_x(1)
+    g.b_from_x()
+    g.fill_x(1.0)
+    g.tune(8)
+    for mode in ("plain", "edges"):
+        for _ in range(6):
+            g.halo_refreshed()
+            if mode == "edges":
+                g.sweep_edges_first(ghost // 2, ghost)
+            else:
+                g.sweep(ghost // 2)
+            g.synchronize()
+    print("edge done", flush=True)
     g.close()
