@@ -73,7 +73,10 @@ struct ccp_grid {
     // lexicographic (reference-order) path: diagonal-major copies of x and b, snapshot, step sums
     DevBuf<double> lex_x, lex_b, lex_snap, lex_partial, lex_eps;
     DevBuf<unsigned> lex_progress, lex_ticket;   // strip-wave pipeline: diagonals finished per (channel, sweep, strip); work tickets
-    int lex_mode = 1;            // 1: strip waves, one launch for all sweeps (default); 0: one launch per hyperplane (CCP_GS_LEX_MODE=planes)
+    DevBuf<double> lex_edges;    // time-skewed strips: results of each strip's lanes 62/63 per step and sweep (read by the strip to its right)
+    int lex_mode = 2;            // 2: time-skewed strip waves, T sweeps per pass (default); 1: strip waves, one sweep per wave
+                                 // (CCP_GS_LEX_MODE=strips); 0: one launch per hyperplane (CCP_GS_LEX_MODE=planes)
+    int lex_tmax = 8;            // deepest time-skewed pass (CCP_GS_LEX_T: 1, 2, 4 or 8)
     int lex_chunk = 0;           // diagonals between two progress publications (CCP_GS_LEX_CHUNK; 0 = by size)
     LexGeom lexg{};
     DevBuf<double> stage;        // natural-order staging rows for host transfers
@@ -646,7 +649,8 @@ try {
     if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SHORT_EDGES")) g->short_edges = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SIDE_ROWS")) g->side_rows_override = atoi(e);
-    if (const char *e = getenv("CCP_GS_LEX_MODE")) g->lex_mode = strcmp(e, "planes") == 0 ? 0 : 1;
+    if (const char *e = getenv("CCP_GS_LEX_MODE")) g->lex_mode = strcmp(e, "planes") == 0 ? 0 : (strcmp(e, "strips") == 0 ? 1 : 2);
+    if (const char *e = getenv("CCP_GS_LEX_T")) g->lex_tmax = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("CCP_GS_LEX_CHUNK")) g->lex_chunk = atoi(e);
     if (const char *e = getenv("CCP_GS_TMAX")) g->fuse_tmax = std::max(1, std::min(kFusedMaxT, atoi(e)));
     if (const char *e = getenv("CCP_GS_ALL_BORDER")) g->all_border = atoi(e) != 0;
@@ -1175,7 +1179,13 @@ namespace {
 int lex_strips(const ccp_grid *g) { return (g->desc.width + kLexStripCols - 1) / kLexStripCols; }
 
 // partial sums one checked sweep writes per channel
-long lex_partials_per_sweep(const ccp_grid *g) { return g->lex_mode == 1 ? (long)lex_strips(g) : (long)g->lexg.n_diag * g->lexg.nbx; }
+// (time-skewed strips: the strip count depends on the depth; the partial layout uses the largest, depth 8's —
+// slots a shallower launch does not write must read as zero, so the buffer is cleared per batch)
+long lex_partials_per_sweep(const ccp_grid *g)
+{
+    if (g->lex_mode == 2) return (long)((g->desc.width - 1 + 2 * 7) / kLexSkewCols + 1);
+    return g->lex_mode == 1 ? (long)lex_strips(g) : (long)g->lexg.n_diag * g->lexg.nbx;
+}
 
 // `iterations` lexicographic sweeps of the channels in `mask` as ONE launch of strip waves (k_lex_strips).
 int lex_run_strips(ccp_grid *g, int iterations, unsigned mask, double *partial)
@@ -1201,8 +1211,59 @@ int lex_run_strips(ccp_grid *g, int iterations, unsigned mask, double *partial)
     return CCP_OK;
 }
 
+// `iterations` lexicographic sweeps as time-skewed strip waves: groups of T sweeps per pass through memory
+// (k_lex_skew), T = 8, 4, 2, 1 for what is left over; every depth is one launch holding all its groups.
+extern "C++" {
+template <int T>
+int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
+{
+    const LexGeom &lg = g->lexg;
+    const int C = g->desc.channels;
+    const int S = (lg.W - 1 + 2 * (T - 1)) / kLexSkewCols + 1;
+    const long edge_steps = kWave + lg.H + 2 * (T - 1);
+    int chunk = g->lex_chunk;
+    if (chunk <= 0) chunk = std::min(lg.W, lg.H) <= 1024 ? 8 : 16;
+    chunk = std::max(4, std::min(chunk, kWave));
+    const size_t need = (size_t)C * groups * S, edges = (size_t)C * S * edge_steps * 2 * T;
+    if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
+    if (g->lex_edges.n < edges) CCP_TRY(g->lex_edges.alloc(edges));
+    if (!g->lex_ticket.p) CCP_TRY(g->lex_ticket.alloc(kMaxChannels));
+    CCP_HIP(hipMemsetAsync(g->lex_progress.p, 0, need * sizeof(unsigned), g->stream));
+    CCP_HIP(hipMemsetAsync(g->lex_ticket.p, 0, kMaxChannels * sizeof(unsigned), g->stream));
+    dim3 grid((unsigned)((long)groups * S), (unsigned)C);
+    if (partial)
+        hipLaunchKernelGGL((k_lex_skew<T, true>), grid, dim3(kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S, chunk,
+                           g->lex_progress.p, g->lex_ticket.p, g->lex_edges.p, edge_steps, mask, partial, lex_partials_per_sweep(g));
+    else
+        hipLaunchKernelGGL((k_lex_skew<T, false>), grid, dim3(kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S, chunk,
+                           g->lex_progress.p, g->lex_ticket.p, g->lex_edges.p, edge_steps, mask, static_cast<double *>(nullptr), 0L);
+    CCP_HIP(hipGetLastError());
+    return CCP_OK;
+}
+}  // extern "C++"
+
+int lex_run_skew(ccp_grid *g, int iterations, unsigned mask, double *partial)
+{
+    const int C = g->desc.channels;
+    const long per_sweep = (long)C * lex_partials_per_sweep(g);          // partial doubles per sweep (all channels)
+    int left = iterations, done = 0;
+    for (int T = 8; T >= 1; T >>= 1) {
+        if (T > g->lex_tmax || left < T) continue;
+        const int groups = left / T;
+        double *p = partial ? partial + (long)done * per_sweep : nullptr;
+        if (T == 8) CCP_TRY(lex_launch_skew<8>(g, groups, mask, p));
+        else if (T == 4) CCP_TRY(lex_launch_skew<4>(g, groups, mask, p));
+        else if (T == 2) CCP_TRY(lex_launch_skew<2>(g, groups, mask, p));
+        else CCP_TRY(lex_launch_skew<1>(g, groups, mask, p));
+        done += groups * T;
+        left -= groups * T;
+    }
+    return CCP_OK;
+}
+
 int lex_run(ccp_grid *g, int iterations, unsigned mask, double *partial)
 {
+    if (g->lex_mode == 2 && iterations > 0) return lex_run_skew(g, iterations, mask, partial);
     if (g->lex_mode == 1 && iterations > 0) return lex_run_strips(g, iterations, mask, partial);
     const LexGeom &lg = g->lexg;
     const int d_max = lg.n_diag - 1;
@@ -1265,7 +1326,7 @@ try {
         // fixed count — or the reference loop never starts (eps = 10 <= epsilon)
         const int n = check_every == 0 ? max_iteration : 0;
         for (int done = 0; done < n;) {                    // gridDim.y carries the sweeps in flight: keep it small
-            const int kb = std::min(g->lex_mode == 1 ? 4096 : 32768, n - done);   // (strip waves: one progress word per sweep and strip)
+            const int kb = std::min(g->lex_mode != 0 ? 4096 : 32768, n - done);   // (strip waves: one progress word per sweep and strip)
             CCP_TRY(lex_run(g, kb, all, nullptr));
             done += kb;
         }
@@ -1282,6 +1343,7 @@ try {
         while (mask && done < max_iteration) {
             const int kb = std::min(batch_max, max_iteration - done);
             CCP_HIP(hipMemcpyAsync(g->lex_snap.p, g->lex_x.p, elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+            if (g->lex_mode == 2) CCP_HIP(hipMemsetAsync(g->lex_partial.p, 0, sizeof(double) * (size_t)per * kb * C, g->stream));
             CCP_TRY(lex_run(g, kb, mask, g->lex_partial.p));
             hipLaunchKernelGGL(k_lex_reduce, dim3((unsigned)kb, (unsigned)C), dim3(kBlock), 0, g->stream, g->lex_partial.p, per,
                                g->lex_eps.p);

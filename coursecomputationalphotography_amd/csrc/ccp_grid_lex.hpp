@@ -253,6 +253,130 @@ k_lex_strips(double *__restrict__ xd, const double *__restrict__ bd, Geom g, Lex
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Temporal blocking of the reference-order sweep: T sweeps per pass through memory (k_lex_skew).
+// A red-black pass can recompute halos redundantly; the index-order sweep cannot (the left neighbour is the
+// NEW value of the same sweep, which depends on the whole row to its left).  What it can do is SKEW: with
+//     x' = x + 2t,  y' = y + 2t      (t = sweep inside the group of T)
+// the four dependences of point (x', y', t)
+//     (x-1, y, t) -> (x'-1, y',   t)      (x, y-1, t)   -> (x',   y'-1, t)
+//     (x+1, y, t-1) -> (x'-1, y'-2, t-1)  (x, y+1, t-1) -> (x'-2, y'-1, t-1)
+// all point to smaller x' (or equal x' and smaller y'): strips in x' depend on the strip to their LEFT only.
+// A wavefront owns 64 skewed columns and marches down the skewed diagonals d' = x' + y'; at every step each
+// lane updates its pixel of ALL T sweeps (pixel (x'-2t, y'-2t) of sweep t) — T independent updates — from
+// registers: its own results of the last three steps per sweep (h1..h3; h4 for the stop rule's old value)
+// and its left neighbours' by DPP:
+//     up = h1[t]   left = shr1(h1[t])   right = shr1(h3[t-1])   down = shr2(h3[t-1])   old = shr2(h4[t-1]).
+// Only sweep 0 reads x (the previous group's result: rows d'+1 and, for the stop rule, d') and only sweep T-1
+// writes it: 16/T B per update plus b (8 B, re-read by every sweep) instead of 32 B.
+// Lanes 0 and 1 are GHOST lanes: they carry the results of the left strip's lanes 62 and 63 (2T doubles per
+// step, written by that strip to `edges`, read back here) so every DPP shift is uniform; a strip therefore
+// advances 62 skewed columns.  Producers of wave (group, s): (group, s-1) through the same step; (group-1, s)
+// and (group-1, s+1) through step + 1 + 4(T-1) (they wrote the x this group's sweep 0 reads).  Progress
+// counters, tickets, sc1 hand-off as in k_lex_strips.
+// grid = (G * S, channels), block = 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
+constexpr int kLexSkewCols = kWave - 2;
+
+__device__ __forceinline__ double lane_prev2(double v) { return lane_prev(lane_prev(v)); }
+
+template <int T, bool CHECK>
+__global__ void __launch_bounds__(kWave)
+k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S, int chunk,
+           unsigned *__restrict__ progress, unsigned *__restrict__ ticket, double *__restrict__ edges, long edge_steps,
+           unsigned active_mask, double *__restrict__ partial, long partial_stride)
+{
+    const int ch = blockIdx.y;
+    if (!((active_mask >> ch) & 1u)) return;
+    const int lane = threadIdx.x;
+    unsigned tk = 0;
+    if (lane == 0) tk = atomicAdd(&ticket[ch], 1u);
+    tk = (unsigned)__builtin_amdgcn_readfirstlane((int)__shfl((int)tk, 0, kWave));
+    const int grp = (int)(tk / (unsigned)S), s = (int)(tk % (unsigned)S);
+    const int HS = lg.H + 2 * (T - 1);                        // skewed rows
+    const int xs0 = kLexSkewCols * s - 2;                     // skewed column of lane 0 (a ghost lane)
+    const int xp = xs0 + lane;
+    const bool ghost = lane < 2;
+    const int d_begin = xs0, d_end = xs0 + (kWave - 1) + HS - 1;
+    unsigned *prog = progress + ((long)ch * G + grp) * S;
+    unsigned *mine = prog + s;
+    const unsigned *left_p = s > 0 ? prog + (s - 1) : nullptr;
+    const unsigned *prev0_p = grp > 0 ? prog - S + s : nullptr;
+    const unsigned *prev1_p = (grp > 0 && s + 1 < S) ? prog - S + s + 1 : nullptr;
+    const long plane = (long)ch * lg.plane;
+    double *e_mine = edges + ((long)ch * S + s) * edge_steps * (2 * T);
+    const double *e_left = s > 0 ? edges + ((long)ch * S + s - 1) * edge_steps * (2 * T) : nullptr;
+    const int left_begin = xs0 - kLexSkewCols, left_end = left_begin + (kWave - 1) + HS - 1;
+    double h1[T], h2[T], h3[T], h4[T], acc[T];
+#pragma unroll
+    for (int t = 0; t < T; ++t) h1[t] = h2[t] = h3[t] = h4[t] = acc[t] = 0.0;
+    for (int dc = d_begin; dc <= d_end; dc += chunk) {
+        const int de = min(dc + chunk - 1, d_end);
+        lex_wait(left_p, (unsigned)(de + 1));                               // the left strip through step de
+        lex_wait(prev0_p, (unsigned)(de + 2 + 4 * (T - 1)));               // the previous group's x, rows up to de+1
+        lex_wait(prev1_p, (unsigned)(de + 2 + 4 * (T - 1)));
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             // compiler ordering only
+        for (int d = dc; d <= de; ++d) {
+            const int yp = d - xp;
+            // sweep 0's inputs from x: (xp, yp+1) and (xp+1, yp) on diagonal d+1; for the stop rule (xp, yp) itself
+            double dn0 = 0.0, rt0 = 0.0, old0 = 0.0;
+            if (xp >= 0 && xp < lg.W && yp + 1 >= 0 && yp + 1 < lg.H) dn0 = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp]);
+            if (xp + 1 >= 0 && xp + 1 < lg.W && yp >= 0 && yp < lg.H) rt0 = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp + 1]);
+            if (CHECK && xp >= 0 && xp < lg.W && yp >= 0 && yp < lg.H) old0 = lex_ld(&xd[plane + (long)d * lg.P + xp]);
+            double nh[T];
+            const bool left_live = e_left != nullptr && d >= left_begin && d <= left_end;
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int x = xp - 2 * t, y = yp - 2 * t;
+                const bool on = !ghost && x >= 0 && x < lg.W && y >= 0 && y < lg.H;
+                const double up = h1[t];
+                const double left = lane_prev(h1[t]);
+                const double right = t == 0 ? rt0 : lane_prev(h3[t > 0 ? t - 1 : 0]);
+                const double down = t == 0 ? dn0 : lane_prev2(h3[t > 0 ? t - 1 : 0]);
+                double nv = 0.0;
+                if (on) {
+                    const double bv = bd[plane + (long)(x + y) * lg.P + x];
+                    const Stencil st = classify(g, x, y, y);
+                    if (st.diag != 0) {
+                        if (st.up && st.left && st.right && st.down && st.diag == 4) nv = (bv + (((up + left) + right) + down)) * 0.25;
+                        else (void)gs_update(st, bv, up, left, right, down, nv);
+                        if (CHECK) {
+                            const double old = t == 0 ? old0 : lane_prev2(h4[t > 0 ? t - 1 : 0]);
+                            acc[t] += fabs(nv - old);
+                        }
+                        if (t == T - 1) lex_st(&xd[plane + (long)(x + y) * lg.P + x], nv);
+                    }
+                }
+                if (ghost) {                                                 // the left strip's lanes 62 / 63 of this step
+                    nv = 0.0;
+                    if (left_live) nv = lex_ld(&e_left[((long)(d - left_begin) * T + t) * 2 + lane]);
+                }
+                nh[t] = nv;
+            }
+            if (lane >= kWave - 2) {
+#pragma unroll
+                for (int t = 0; t < T; ++t) lex_st(&e_mine[((long)(d - d_begin) * T + t) * 2 + (lane - (kWave - 2))], nh[t]);
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                if (CHECK) h4[t] = h3[t];
+                h3[t] = h2[t];
+                h2[t] = h1[t];
+                h1[t] = nh[t];
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // compiler ordering only
+        __builtin_amdgcn_s_waitcnt(0);
+        if (lane == 0) __hip_atomic_store(mine, de == d_end ? kLexDone : (unsigned)(de + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (CHECK) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const double total = wave_sum(acc[t]);
+            if (lane == 0) partial[(((long)grp * T + t) * gridDim.y + ch) * partial_stride + s] = total;
+        }
+    }
+}
+
 // eps[k*channels + ch] = sum of the partials of iteration k in a fixed order.  grid = (iterations, channels)
 __global__ void __launch_bounds__(kBlock)
 k_lex_reduce(const double *__restrict__ partial, long per_iteration_channel, double *__restrict__ eps)
