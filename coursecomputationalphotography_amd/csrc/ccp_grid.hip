@@ -74,8 +74,8 @@ struct ccp_grid {
     DevBuf<double> lex_x, lex_b, lex_snap, lex_partial, lex_eps;
     DevBuf<unsigned> lex_progress, lex_ticket;   // strip-wave pipeline: diagonals finished per (channel, sweep, strip); work tickets
     DevBuf<double> lex_edges;    // time-skewed strips: results of each strip's lanes 62/63 per step and sweep (read by the strip to its right)
-    int lex_mode = 2;            // 2: time-skewed strip waves, T sweeps per pass (default); 1: strip waves, one sweep per wave
-                                 // (CCP_GS_LEX_MODE=strips); 0: one launch per hyperplane (CCP_GS_LEX_MODE=planes)
+    int lex_mode = 1;            // 1: strip waves, one sweep per wave, all sweeps in one launch (default); 2: time-skewed strip
+                                 // waves, T sweeps per pass (CCP_GS_LEX_MODE=skew, experimental); 0: one launch per hyperplane (=planes)
     int lex_tmax = 8;            // deepest time-skewed pass (CCP_GS_LEX_T: 1, 2, 4 or 8)
     int lex_chunk = 0;           // diagonals between two progress publications (CCP_GS_LEX_CHUNK; 0 = by size)
     LexGeom lexg{};
@@ -649,7 +649,7 @@ try {
     if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SHORT_EDGES")) g->short_edges = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SIDE_ROWS")) g->side_rows_override = atoi(e);
-    if (const char *e = getenv("CCP_GS_LEX_MODE")) g->lex_mode = strcmp(e, "planes") == 0 ? 0 : (strcmp(e, "strips") == 0 ? 1 : 2);
+    if (const char *e = getenv("CCP_GS_LEX_MODE")) g->lex_mode = strcmp(e, "planes") == 0 ? 0 : (strcmp(e, "skew") == 0 ? 2 : 1);
     if (const char *e = getenv("CCP_GS_LEX_T")) g->lex_tmax = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("CCP_GS_LEX_CHUNK")) g->lex_chunk = atoi(e);
     if (const char *e = getenv("CCP_GS_TMAX")) g->fuse_tmax = std::max(1, std::min(kFusedMaxT, atoi(e)));

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Randomised parity soak (GPU): the temporally blocked pass against the in-place kernels on random shapes,
 iteration counts, tilings and channel counts, every pixel; the reference-order sweep against the oracle on
-small random shapes; row-blocked runs against the single block.  Prints one line per failure, exit 1 if any."""
+small random shapes; row-blocked runs against the single block; (round 2) irregular regions through the mask
+grid / the raster-region dispatch / the sliced-ELL kernels against the oracle, incremental inserts, the three
+reference-order implementations, the RCCL entry points at world size 1.  One line per failure, exit 1 if any."""
 import os
 import sys
 import threading
@@ -300,7 +302,161 @@ def run(n, seed):
             print("MISMATCH row blocks", W, H, world, ghost, iters, overlap, errs[:1], flush=True)
     for k in ("CCP_GS_FUSE", "CCP_GS_CHUNK", "CCP_GS_TMAX", "CCP_GS_SIDE_ROWS", "CCP_GS_SHORT_EDGES", "SOAK_TUNE"):
         os.environ.pop(k, None)
+    bad += run_round2(n, rng, orc)
     print("soak done, failures:", bad, flush=True)
+    return bad
+
+
+def random_mask(rng, W, H):
+    kind = rng.integers(0, 4)
+    if kind == 0:
+        return synth.disc_mask(W, H, seed=int(rng.integers(1, 10000)), n_discs=int(rng.integers(1, 30)))
+    if kind == 1:
+        return rng.uniform(size=(H, W)) < rng.uniform(0.3, 0.9)          # salt and pepper: many components, one-pixel bridges
+    if kind == 2:
+        m = np.zeros((H, W), dtype=bool)                                   # staircases and L-corners: the ambiguous run turns
+        for _ in range(int(rng.integers(1, 12))):
+            x0, y0 = int(rng.integers(0, W)), int(rng.integers(0, H))
+            w, h = int(rng.integers(1, max(2, W // 2))), int(rng.integers(1, max(2, H // 2)))
+            m[y0:y0 + h, x0:x0 + w] ^= True
+        return m
+    return np.ones((H, W), dtype=bool)
+
+
+def run_round2(n, rng, orc):
+    """Region grids and the raster-region dispatch, incremental inserts, the reference-order modes, the RCCL
+    entry points at world size 1."""
+    import scipy.sparse as sp
+    bad = 0
+    # ---- irregular regions: mask grid == region dispatch == sliced ELL == oracle --------------------------
+    for t in range(max(6, n // 2)):
+        W, H = int(rng.integers(3, 500)), int(rng.integers(3, 400))
+        mask = random_mask(rng, W, H)
+        if mask.sum() < 2:
+            continue
+        v, c, r, colour, ys, xs = synth.masked_laplacian_csr(mask)
+        nn = len(ys)
+        iters = int(rng.integers(1, 30))
+        b = rng.uniform(-40, 40, nn)
+        x0 = rng.uniform(0, 255, nn)
+        if rng.random() < 0.3:
+            colour = 1 - colour
+        want, _, _ = orc.multicolour_gauss_seidel(v, c, r, colour, b, 0.0, iters, x0=x0)
+        outs = {}
+        for label, env in (("region", "1"), ("ell", "0")):
+            os.environ["CCP_GS_MASKED"] = env
+            try:
+                m = capi.CsrMatrix().upload_compressed(v, c, r)
+                m.set_colouring(colour, 2)
+                outs[label], _ = m.gauss_seidel(b, 0.0, iters, x0=x0, check_every=0)
+                outs[label + "_path"] = m.last_path()
+                m.close()
+            except Exception as e:
+                bad += 1
+                print("ERROR region", label, W, H, iters, repr(e), flush=True)
+        os.environ.pop("CCP_GS_MASKED", None)
+        for label in ("region", "ell"):
+            if label in outs and not np.array_equal(outs[label], want):
+                bad += 1
+                print("MISMATCH region", label, outs.get(label + "_path"), W, H, iters, float(np.abs(outs[label] - want).max()), flush=True)
+        if colour[0] == ((xs[0] + ys[0]) & 1):                            # the mask grid directly (its colour 0 is (x+y) even)
+            os.environ["CCP_GS_TMAX"] = str(int(rng.integers(1, 8)))
+            os.environ["CCP_GS_CHUNK"] = str(int(rng.integers(8, 200)))
+            g = capi.Grid(W, H, 1, mask=mask)
+            cb, cx = np.zeros((H, W)), np.zeros((H, W))
+            cb[ys, xs], cx[ys, xs] = b, x0
+            g.set_b(cb)
+            g.set_x(cx)
+            g.sweep(iters)
+            got = g.get_x()
+            g.close()
+            os.environ.pop("CCP_GS_TMAX", None)
+            os.environ.pop("CCP_GS_CHUNK", None)
+            if not np.array_equal(got[ys, xs], want) or np.any(got[~mask]):
+                bad += 1
+                print("MISMATCH mask grid", W, H, iters, flush=True)
+    # ---- incremental inserts on random matrices -----------------------------------------------------------
+    for t in range(max(3, n // 6)):
+        nn = int(rng.integers(20, 900))
+        a = sp.random(nn, nn, density=float(rng.uniform(0.005, 0.05)), random_state=np.random.RandomState(int(rng.integers(1, 1 << 30)))).tocsr()
+        a = a + a.T
+        a.setdiag(0.0)
+        a.eliminate_zeros()
+        a = (a + sp.diags(np.asarray(abs(a).sum(axis=1)).ravel() + 1.0)).tocsr()
+        a.sort_indices()
+        b = rng.uniform(-5, 5, nn)
+        m = capi.CsrMatrix().upload_compressed(a.data, a.indices.astype(np.int32), a.indptr.astype(np.int32))
+        m.gauss_seidel(b, 0.0, 1, check_every=0)
+        m.gauss_seidel(b, 0.0, 1, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+        m.apply_to_vector(b)
+        lil = a.tolil()
+        for _ in range(int(rng.integers(1, 120))):
+            i, j = int(rng.integers(0, nn)), int(rng.integers(0, nn))
+            kind = rng.random()
+            val = 0.0 if (kind < 0.3 and i != j) else float(rng.uniform(0.05, 2.0)) * (1.0 if i != j else 5.0 + nn * 0.05)
+            m.insert(val, i, j)
+            lil[i, j] = val
+        e = lil.tocsr()
+        e.eliminate_zeros()
+        e.sort_indices()
+        ev, ec, er = e.data.astype(np.float64), e.indices.astype(np.int32), e.indptr.astype(np.int32)
+        om = orc.from_csr(ev, ec, er)
+        k = int(rng.integers(1, 6))
+        x, _ = m.gauss_seidel(b, 0.0, k, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+        ok = np.array_equal(x, om.gauss_seidel(b, 0.0, k)[0]) and np.array_equal(m.apply_to_vector(b), om.apply_to_vector(b))
+        col, nc = m.get_colouring()
+        x, _ = m.gauss_seidel(b, 0.0, k, check_every=0)
+        ok = ok and np.array_equal(x, orc.multicolour_gauss_seidel(ev, ec, er, col, b, 0.0, k)[0])
+        m.close()
+        if not ok:
+            bad += 1
+            print("MISMATCH insert", nn, flush=True)
+    # ---- reference order: the three implementations agree with the oracle ----------------------------------
+    for t in range(max(4, n // 4)):
+        W, H, C = int(rng.integers(1, 900)), int(rng.integers(1, 600)), int(rng.choice([1, 3]))
+        if W * H < 2:
+            continue
+        iters = int(rng.integers(1, 20))
+        bs = [synth.poisson_system(W, H, int(rng.integers(1, 1000)))[0] for _ in range(C)]
+        om = orc.from_csr(*synth.poisson_csr(W, H))
+        wants = [om.gauss_seidel(b, 0.0, iters)[0] for b in bs]
+        for mode in ("skew", "strips", "planes"):
+            os.environ["CCP_GS_LEX_MODE"] = mode
+            os.environ["CCP_GS_LEX_CHUNK"] = str(int(rng.choice([0, 4, 8, 16, 33, 64])))
+            g = capi.Grid(W, H, C)
+            for ch in range(C):
+                g.set_b(bs[ch], ch)
+            g.fill_x(1.0)
+            g.gauss_seidel_lexicographic(0.0, iters, 0)
+            for ch in range(C):
+                if not np.array_equal(g.get_x(ch).ravel(), wants[ch]):
+                    bad += 1
+                    print("MISMATCH reference order", mode, os.environ["CCP_GS_LEX_CHUNK"], W, H, C, iters, ch, flush=True)
+            g.close()
+        os.environ.pop("CCP_GS_LEX_MODE", None)
+        os.environ.pop("CCP_GS_LEX_CHUNK", None)
+    # ---- RCCL entry points at world size 1 ------------------------------------------------------------------
+    comm = capi.Comm(capi.comm_unique_id(), 0, 1, 0)
+    for t in range(3):
+        W, H, C, iters = int(rng.integers(2, 1500)), int(rng.integers(2, 900)), int(rng.choice([1, 3])), int(rng.integers(1, 40))
+        ref, g = capi.Grid(W, H, C), capi.Grid(W, H, C)
+        for h in (ref, g):
+            h.randomize_x(5, 0.0, 255.0)
+            h.b_from_x()
+            h.fill_x(1.0)
+        g.attach_comm(comm)
+        ref.sweep(iters)
+        g.gauss_seidel_rowblocked(0.0, iters, 0)
+        same = all(np.array_equal(ref.get_x(ch), g.get_x(ch)) for ch in range(C))
+        rr, bb = g.residual_norm2_global()
+        rr2, bb2 = ref.residual_norm2()
+        if not (same and np.array_equal(rr, rr2) and np.array_equal(bb, bb2)):
+            bad += 1
+            print("MISMATCH rowblocked world 1", W, H, C, iters, flush=True)
+        g.attach_comm(None)
+        g.close()
+        ref.close()
+    comm.close()
     return bad
 
 
