@@ -867,7 +867,7 @@ bool row_still_fits(const ccp_csr *m, const Schedule &sc, int kind, int i, const
         } else {
             const int lo = std::min(i, c), hi = std::max(i, c);
             const int d = sc.group_of[hi] - sc.group_of[lo];
-            if (d <= 0 || d > std::max(sc.level_span, 1)) return false;
+            if (d <= 0 || d > sc.level_span) return false;
         }
     }
     return true;
@@ -891,6 +891,8 @@ int flush_edits(ccp_csr *m)
         std::vector<double> pv;
         std::vector<std::pair<int, double>> tmp;
         bool drop = false;
+        // pass 1: does every touched row keep its place, and how many entry columns does each touched slice need?
+        std::unordered_map<int, int> slice_need;
         for (int i : m->touched) {
             const RowView r = row_view(m, i);
             if (!row_still_fits(m, sc, kind, i, r)) {
@@ -899,42 +901,57 @@ int flush_edits(ccp_csr *m)
             }
             int s, lane;
             locate(sc, i, s, lane);
-            if (r.len > sc.h_scap[s]) {                       // the slice needs more entry columns: move it to the reserve
-                const int new_cap = (int)r.len + kSliceSlack;
-                if (sc.entries_used + (long)new_cap * kWave > sc.entries_cap) {
-                    drop = true;
-                    break;
-                }
-                const long dst = sc.entries_used;
-                hipLaunchKernelGGL(k_move_slice, dim3(1), dim3(kWave), 0, m->stream, sc.cols.p, sc.vals.p, sc.h_soff[s], dst,
-                                   sc.h_swidth[s], new_cap);
-                CCP_HIP(hipGetLastError());
-                CCP_HIP(hipMemcpyAsync(sc.slice_off.p + s, &dst, sizeof(long), hipMemcpyHostToDevice, m->stream));
-                CCP_HIP(hipStreamSynchronize(m->stream));     // `dst` lives on this stack frame
-                sc.h_soff[s] = dst;
-                sc.h_scap[s] = new_cap;
-                sc.entries_used += (long)new_cap * kWave;
-                m->stat_slices_relocated++;
-            }
-            if (r.len > sc.h_swidth[s]) {                     // the live width only ever grows (padding is skipped by the kernels)
-                sc.h_swidth[s] = (int)r.len;
-                CCP_HIP(hipMemcpyAsync(sc.slice_width.p + s, &sc.h_swidth[s], sizeof(int), hipMemcpyHostToDevice, m->stream));
-            }
-            tmp.clear();
-            for (long k = 0; k < r.len; ++k) {
-                const int c = r.col[k];
-                tmp.emplace_back((c >= 0 && c < m->n_rows) ? sc.inv[c] : c, r.val[k]);
-            }
-            if (sc.sort_by_permuted) std::stable_sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
-            base.push_back(sc.h_soff[s] + lane);
-            cap.push_back(sc.h_scap[s]);
-            off.push_back((long)pc.size());
-            for (int k = 0; k < sc.h_scap[s]; ++k) {
-                const bool live = k < (int)tmp.size();
-                pc.push_back(live ? tmp[k].first : -1);
-                pv.push_back(live ? tmp[k].second : 0.0);
-            }
+            int &need = slice_need[s];
+            need = std::max(need, (int)r.len);
         }
+        // a slice that needs more than its spare columns moves to the reserve ONCE, before any of its rows is patched
+        // (a patch carries the slice's final offset)
+        if (!drop)
+            for (const auto &kv : slice_need) {
+                const int s = kv.first, need = kv.second;
+                if (need > sc.h_scap[s]) {
+                    const int new_cap = need + kSliceSlack;
+                    if (sc.entries_used + (long)new_cap * kWave > sc.entries_cap) {
+                        drop = true;
+                        break;
+                    }
+                    const long dst = sc.entries_used;
+                    hipLaunchKernelGGL(k_move_slice, dim3(1), dim3(kWave), 0, m->stream, sc.cols.p, sc.vals.p, sc.h_soff[s], dst,
+                                       sc.h_swidth[s], new_cap);
+                    CCP_HIP(hipGetLastError());
+                    CCP_HIP(hipMemcpyAsync(sc.slice_off.p + s, &dst, sizeof(long), hipMemcpyHostToDevice, m->stream));
+                    CCP_HIP(hipStreamSynchronize(m->stream));     // `dst` lives on this stack frame
+                    sc.h_soff[s] = dst;
+                    sc.h_scap[s] = new_cap;
+                    sc.entries_used += (long)new_cap * kWave;
+                    m->stat_slices_relocated++;
+                }
+                if (need > sc.h_swidth[s]) {                      // the live width only ever grows (padding is skipped by the kernels)
+                    sc.h_swidth[s] = need;
+                    CCP_HIP(hipMemcpyAsync(sc.slice_width.p + s, &sc.h_swidth[s], sizeof(int), hipMemcpyHostToDevice, m->stream));
+                }
+            }
+        // pass 2: the patches
+        if (!drop)
+            for (int i : m->touched) {
+                const RowView r = row_view(m, i);
+                int s, lane;
+                locate(sc, i, s, lane);
+                tmp.clear();
+                for (long k = 0; k < r.len; ++k) {
+                    const int c = r.col[k];
+                    tmp.emplace_back((c >= 0 && c < m->n_rows) ? sc.inv[c] : c, r.val[k]);
+                }
+                if (sc.sort_by_permuted) std::stable_sort(tmp.begin(), tmp.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+                base.push_back(sc.h_soff[s] + lane);
+                cap.push_back(sc.h_scap[s]);
+                off.push_back((long)pc.size());
+                for (int k = 0; k < sc.h_scap[s]; ++k) {
+                    const bool live = k < (int)tmp.size();
+                    pc.push_back(live ? tmp[k].first : -1);
+                    pv.push_back(live ? tmp[k].second : 0.0);
+                }
+            }
         if (drop) {
             sc.reset();
             m->stat_schedule_rebuilds++;

@@ -103,12 +103,13 @@ def test_random_edits_small_matrix(capi, orc, seed):
     check_all_solvers(capi, orc, m, a, b)
     st2 = m.edit_stats()
     assert st2["image_rebuilds"] >= 1 and st2["image_uploads"] == 3 + st2["image_rebuilds"]
-    # batch 3: one row grows far beyond the spare columns of its slice -> the slice moves to the reserve
-    row = 123
-    cols_free = [j for j in range(n) if a[row, j] == 0 and j != row][:300]
+    # batch 3: rows grow far beyond the spare columns of their slice -> the slice moves to the reserve, once, even
+    # when several of its rows outgrow it in the same batch (three neighbouring rows: one slice of the SpMV image)
     col, _ = m.get_colouring()
-    cols_ok = [j for j in cols_free if col[j] != col[row]][:40]
-    edits = [(0.01, row, j) for j in cols_ok]
+    edits = []
+    for row, count in ((123, 40), (124, 55), (125, 25)):
+        cols_free = [j for j in range(n) if a[row, j] == 0 and j != row][:400]
+        edits += [(0.01, row, j) for j in [j for j in cols_free if col[j] != col[row]][:count]]
     for e in edits:
         m.insert(*e)
     a = apply_edits(a, edits)
