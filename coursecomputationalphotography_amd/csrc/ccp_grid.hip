@@ -1223,7 +1223,7 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     const long edge_steps = kWave + lg.H + 2 * (T - 1);
     int chunk = g->lex_chunk;
     if (chunk <= 0) chunk = std::min(lg.W, lg.H) <= 1024 ? 8 : 16;
-    chunk = std::max(4, std::min(chunk, kWave));
+    chunk = std::max(kLexSkewAhead, std::min(chunk, kWave)) / kLexSkewAhead * kLexSkewAhead;   // whole ring turns per chunk
     const size_t need = (size_t)C * groups * S, edges = (size_t)C * S * edge_steps * 2 * T;
     if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
     if (g->lex_edges.n < edges) CCP_TRY(g->lex_edges.alloc(edges));

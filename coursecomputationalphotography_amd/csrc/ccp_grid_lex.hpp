@@ -276,6 +276,7 @@ k_lex_strips(double *__restrict__ xd, const double *__restrict__ bd, Geom g, Lex
 // counters, tickets, sc1 hand-off as in k_lex_strips.
 // grid = (G * S, channels), block = 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
 constexpr int kLexSkewCols = kWave - 2;
+constexpr int kLexSkewAhead = 4;         // steps the loads run ahead of the computation (ring of register slots)
 
 __device__ __forceinline__ double lane_prev2(double v) { return lane_prev(lane_prev(v)); }
 
@@ -309,59 +310,94 @@ k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGe
     double h1[T], h2[T], h3[T], h4[T], acc[T];
 #pragma unroll
     for (int t = 0; t < T; ++t) h1[t] = h2[t] = h3[t] = h4[t] = acc[t] = 0.0;
+    // Everything a step reads from memory is independent of the computation, so it is fetched kLexSkewAhead steps
+    // early into a ring of registers (slot = step mod kLexSkewAhead, refilled as soon as it has been consumed):
+    // sweep 0's two x values (and the old value for the stop rule), and per sweep one value that is b for a real
+    // lane and the left strip's result for a ghost lane.
+    constexpr int PF = kLexSkewAhead;
+    double q_dn[PF], q_rt[PF], q_old[PF], q_v[PF][T];
+    auto fetch = [&](int d, double &dn0, double &rt0, double &old0, double (&v)[T]) {
+        const int yp = d - xp;
+        dn0 = 0.0;
+        rt0 = 0.0;
+        old0 = 0.0;
+        const bool live = d <= d_end;
+        // sweep 0's inputs from x: (xp, yp+1) and (xp+1, yp) on diagonal d+1; for the stop rule (xp, yp) itself
+        if (live && xp >= 0 && xp < lg.W && yp + 1 >= 0 && yp + 1 < lg.H) dn0 = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp]);
+        if (live && xp + 1 >= 0 && xp + 1 < lg.W && yp >= 0 && yp < lg.H) rt0 = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp + 1]);
+        if (CHECK && live && xp >= 0 && xp < lg.W && yp >= 0 && yp < lg.H) old0 = lex_ld(&xd[plane + (long)d * lg.P + xp]);
+        const bool left_live = live && e_left != nullptr && d >= left_begin && d <= left_end;
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+            const int x = xp - 2 * t, y = yp - 2 * t;
+            v[t] = 0.0;
+            if (ghost) {                                                     // the left strip's lanes 62 / 63 of this step
+                if (left_live) v[t] = lex_ld(&e_left[((long)(d - left_begin) * T + t) * 2 + lane]);
+            } else if (live && x >= 0 && x < lg.W && y >= 0 && y < lg.H) {
+                v[t] = bd[plane + (long)(x + y) * lg.P + x];
+            }
+        }
+    };
+    bool primed = false;
     for (int dc = d_begin; dc <= d_end; dc += chunk) {
         const int de = min(dc + chunk - 1, d_end);
-        lex_wait(left_p, (unsigned)(de + 1));                               // the left strip through step de
-        lex_wait(prev0_p, (unsigned)(de + 2 + 4 * (T - 1)));               // the previous group's x, rows up to de+1
-        lex_wait(prev1_p, (unsigned)(de + 2 + 4 * (T - 1)));
+        // producers, PF steps beyond the chunk (the ring is refilled that far ahead)
+        lex_wait(left_p, (unsigned)(de + PF + 1));                         // the left strip through step de + PF
+        lex_wait(prev0_p, (unsigned)(de + PF + 2 + 4 * (T - 1)));          // the previous group's x, rows up to de + PF + 1
+        lex_wait(prev1_p, (unsigned)(de + PF + 2 + 4 * (T - 1)));
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             // compiler ordering only
-        for (int d = dc; d <= de; ++d) {
-            const int yp = d - xp;
-            // sweep 0's inputs from x: (xp, yp+1) and (xp+1, yp) on diagonal d+1; for the stop rule (xp, yp) itself
-            double dn0 = 0.0, rt0 = 0.0, old0 = 0.0;
-            if (xp >= 0 && xp < lg.W && yp + 1 >= 0 && yp + 1 < lg.H) dn0 = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp]);
-            if (xp + 1 >= 0 && xp + 1 < lg.W && yp >= 0 && yp < lg.H) rt0 = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp + 1]);
-            if (CHECK && xp >= 0 && xp < lg.W && yp >= 0 && yp < lg.H) old0 = lex_ld(&xd[plane + (long)d * lg.P + xp]);
-            double nh[T];
-            const bool left_live = e_left != nullptr && d >= left_begin && d <= left_end;
+        if (!primed) {
 #pragma unroll
-            for (int t = 0; t < T; ++t) {
-                const int x = xp - 2 * t, y = yp - 2 * t;
-                const bool on = !ghost && x >= 0 && x < lg.W && y >= 0 && y < lg.H;
-                const double up = h1[t];
-                const double left = lane_prev(h1[t]);
-                const double right = t == 0 ? rt0 : lane_prev(h3[t > 0 ? t - 1 : 0]);
-                const double down = t == 0 ? dn0 : lane_prev2(h3[t > 0 ? t - 1 : 0]);
-                double nv = 0.0;
-                if (on) {
-                    const double bv = bd[plane + (long)(x + y) * lg.P + x];
-                    const Stencil st = classify(g, x, y, y);
-                    if (st.diag != 0) {
-                        if (st.up && st.left && st.right && st.down && st.diag == 4) nv = (bv + (((up + left) + right) + down)) * 0.25;
-                        else (void)gs_update(st, bv, up, left, right, down, nv);
-                        if (CHECK) {
-                            const double old = t == 0 ? old0 : lane_prev2(h4[t > 0 ? t - 1 : 0]);
-                            acc[t] += fabs(nv - old);
+            for (int j = 0; j < PF; ++j) fetch(d_begin + j, q_dn[j], q_rt[j], q_old[j], q_v[j]);
+            primed = true;
+        }
+        for (int db = dc; db <= de; db += PF) {
+#pragma unroll
+            for (int j = 0; j < PF; ++j) {
+                const int d = db + j;
+                if (d <= de) {                                               // (wave-uniform; chunk is a multiple of PF)
+                    const int yp = d - xp;
+                    const double dn0 = q_dn[j], rt0 = q_rt[j], old0 = q_old[j];
+                    double vv[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) vv[t] = q_v[j][t];
+                    fetch(d + PF, q_dn[j], q_rt[j], q_old[j], q_v[j]);     // the slot is free again: refill it for step d + PF
+                    double nh[T];
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        const int x = xp - 2 * t, y = yp - 2 * t;
+                        const bool on = !ghost && x >= 0 && x < lg.W && y >= 0 && y < lg.H;
+                        const double up = h1[t];
+                        const double left = lane_prev(h1[t]);
+                        const double right = t == 0 ? rt0 : lane_prev(h3[t > 0 ? t - 1 : 0]);
+                        const double down = t == 0 ? dn0 : lane_prev2(h3[t > 0 ? t - 1 : 0]);
+                        // (every DPP read happens here, with all lanes active: a source lane masked out by a branch reads as 0)
+                        const double old = !CHECK ? 0.0 : (t == 0 ? old0 : lane_prev2(h4[t > 0 ? t - 1 : 0]));
+                        double nv = ghost ? vv[t] : 0.0;
+                        if (on) {
+                            const double bv = vv[t];
+                            const Stencil st = classify(g, x, y, y);
+                            if (st.diag != 0) {
+                                if (st.up && st.left && st.right && st.down && st.diag == 4) nv = (bv + (((up + left) + right) + down)) * 0.25;
+                                else (void)gs_update(st, bv, up, left, right, down, nv);
+                                if (CHECK) acc[t] += fabs(nv - old);
+                                if (t == T - 1) lex_st(&xd[plane + (long)(x + y) * lg.P + x], nv);
+                            }
                         }
-                        if (t == T - 1) lex_st(&xd[plane + (long)(x + y) * lg.P + x], nv);
+                        nh[t] = nv;
+                    }
+                    if (lane >= kWave - 2) {
+#pragma unroll
+                        for (int t = 0; t < T; ++t) lex_st(&e_mine[((long)(d - d_begin) * T + t) * 2 + (lane - (kWave - 2))], nh[t]);
+                    }
+#pragma unroll
+                    for (int t = 0; t < T; ++t) {
+                        if (CHECK) h4[t] = h3[t];
+                        h3[t] = h2[t];
+                        h2[t] = h1[t];
+                        h1[t] = nh[t];
                     }
                 }
-                if (ghost) {                                                 // the left strip's lanes 62 / 63 of this step
-                    nv = 0.0;
-                    if (left_live) nv = lex_ld(&e_left[((long)(d - left_begin) * T + t) * 2 + lane]);
-                }
-                nh[t] = nv;
-            }
-            if (lane >= kWave - 2) {
-#pragma unroll
-                for (int t = 0; t < T; ++t) lex_st(&e_mine[((long)(d - d_begin) * T + t) * 2 + (lane - (kWave - 2))], nh[t]);
-            }
-#pragma unroll
-            for (int t = 0; t < T; ++t) {
-                if (CHECK) h4[t] = h3[t];
-                h3[t] = h2[t];
-                h2[t] = h1[t];
-                h1[t] = nh[t];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // compiler ordering only
