@@ -55,9 +55,6 @@ struct ccp_grid {
     int live_T = -1, live_R = -1, live_lo = -1, live_hi = -1;
     long unknowns = 0;           // mask bytes set (owned rows), for the statistics
     bool fuse = true;            // use k_fused_sweep for unchecked sweeps
-    int merge_pass = -1;         // ordinary and border tiles of an unchecked pass in one launch: 1 yes, 0 no, -1 by pass size
-                                 // (CCP_GS_MERGE_PASS; ccp_grid_tune decides per depth: tune_merge[])
-    bool tune_merge[kFusedMaxT + 1] = {false};
     bool short_edges = true;     // chunk rows at an image edge are short (CCP_GS_SHORT_EDGES=0 turns it off)
     int side_rows_override = 0;  // CCP_GS_SIDE_ROWS
     int fuse_tmax = kFusedMaxT;  // iterations fused per launch (<= kFusedMaxT)
@@ -372,23 +369,6 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     }
     if (signalled) *signalled = edge;
     constexpr int TC = T <= kFusedMaxCheckedT ? T : 1;       // per-sweep sums exist up to kFusedMaxCheckedT
-    // One launch for both kinds of tile where that is faster (no event hand-shake between two streams at the
-    // pass boundary): depth 8 only — there both bodies run at 2 waves per SIMD anyway.
-    bool merged = false;
-    if (T == kFusedMaxT && l1 == 0 && !edge && active == nullptr && n_border && any_plain && !g->all_border) {
-        merged = g->merge_pass == 1 || (g->merge_pass < 0 && (g->tuned ? g->tune_merge[T] : false));
-    }
-    if (merged) {
-        constexpr int TM = T == kFusedMaxT ? T : kFusedMaxT;
-        const unsigned gx = grid.x, gy = grid.y;
-        dim3 mgrid(bgrid.x + gx * gy, 1, (unsigned)g->desc.channels);
-        hipLaunchKernelGGL((k_fused_pass<TM, kFusedUnroll>), mgrid, dim3(kBlock), 0, g->stream, P, g->force_border ? 1 : 0, (int)bgrid.x, (int)gx);
-        CCP_HIP(hipGetLastError());
-        g->last_launches++;
-        g->region_launches++;
-        g->region_iterations += T;
-        return CCP_OK;
-    }
     hipStream_t bstream = g->stream2;
     // The border launch sees everything queued on the main stream so far, runs beside the ordinary
     // tiles, and whatever comes next on the main stream waits for it.
@@ -669,7 +649,6 @@ try {
     if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SHORT_EDGES")) g->short_edges = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SIDE_ROWS")) g->side_rows_override = atoi(e);
-    if (const char *e = getenv("CCP_GS_MERGE_PASS")) g->merge_pass = atoi(e) != 0 ? 1 : 0;
     if (const char *e = getenv("CCP_GS_LEX_MODE")) g->lex_mode = strcmp(e, "planes") == 0 ? 0 : (strcmp(e, "skew") == 0 ? 2 : 1);
     if (const char *e = getenv("CCP_GS_LEX_T")) g->lex_tmax = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("CCP_GS_LEX_CHUNK")) g->lex_chunk = atoi(e);
@@ -927,7 +906,6 @@ try {
     g->tuned = false;                                  // candidates below set rows_per_chunk directly
     float tab_ms[kFusedMaxT + 1] = {0};
     int tab_rows[kFusedMaxT + 1] = {0};
-    bool tab_merge[kFusedMaxT + 1] = {false};
     const int rows = g->geom.local_rows;
     const int fixed_candidates[] = {32, 48, 64, 80, 96, 112, 128, 160, 192, 256};
     int cus = 256;
@@ -988,30 +966,6 @@ try {
                 best_r = R;
             }
         }
-        // depth 8: is one launch for ordinary + border tiles faster than two launches side by side?  (two PAIRS of
-        // launches each, so that the hand-shake between passes is part of what is timed)
-        tab_merge[T] = false;
-        if (T == kFusedMaxT && status == CCP_OK && tab_rows[T] > 0 && !g->masked && g->merge_pass < 0) {
-            g->rows_per_chunk = tab_rows[T];
-            float ms2[2] = {0.f, 0.f};
-            for (int variant = 0; variant < 2 && status == CCP_OK; ++variant) {
-                g->merge_pass = variant;
-                auto once = [&]() -> int { return FusedDepth<kFusedMaxT>::launch(T, g, g->x.p, g->x_alt.p, 0, rows, nullptr, 0, nullptr); };
-                status = once();
-                (void)hipEventRecord(e0, g->stream);
-                for (int k = 0; k < 4 && status == CCP_OK; ++k) status = once();
-                (void)hipEventRecord(e1, g->stream);
-                if (status == CCP_OK && hipEventSynchronize(e1) != hipSuccess) status = CCP_ERR_HIP;
-                (void)hipEventElapsedTime(&ms2[variant], e0, e1);
-            }
-            g->merge_pass = -1;
-            if (status == CCP_OK && ms2[1] < ms2[0]) {
-                tab_merge[T] = true;
-                tab_ms[T] = std::min(tab_ms[T], ms2[1] / 4.0f);
-            }
-            if (getenv("CCP_GS_DEBUG"))
-                fprintf(stderr, "[ccp_gs] tune T=%d rows/chunk=%d: two launches %.4f ms/pass, one launch %.4f ms/pass\n", T, tab_rows[T], ms2[0] / 4, ms2[1] / 4);
-        }
     }
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
@@ -1024,7 +978,6 @@ try {
     for (int T = 1; T <= kFusedMaxT; ++T) {
         g->tune_ms[T] = tab_ms[T];
         g->tune_rows[T] = tab_rows[T];
-        g->tune_merge[T] = tab_merge[T];
     }
     g->tuned = true;
     g->fuse_tmax = max_t;

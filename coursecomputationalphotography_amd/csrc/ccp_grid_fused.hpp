@@ -523,60 +523,6 @@ k_fused_sweep(FusedParams P)
     fused_write_partials<L1, AN>(acc, P.partial, ch, scratch);
 }
 
-// Both kinds of tile in ONE launch (unchecked passes): the border tiles take the first n_border_blocks
-// workgroups — dispatched first, they start first, which is what their slower march needs — the ordinary
-// tiles the rest.  Two launches on two streams have to hand-shake through events at every pass boundary,
-// which leaves the chip idle for ~18 us per pass (profiles/r02_edge_pass_trace.json): 10 % of a pass of a
-// 2048-row block, 1.5 % of a 16384^2 pass.  Register budget = the border body's (250 VGPRs at T = 8), the same
-// 2 waves per SIMD the ordinary body runs at.
-template <int T, int UNR>
-__global__ void __launch_bounds__(kBlock, fused_border_waves_per_simd(T, 0))
-k_fused_pass(FusedParams P, int force_border, int n_border_blocks, int plain_gx)
-{
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int ch = blockIdx.z;
-    double acc[1] = {0.0};
-    const Geom &g = P.g;
-    const long off = (long)ch * g.ch_stride;
-    if ((int)blockIdx.x < n_border_blocks) {
-        const int id = blockIdx.x * (kBlock / kWave) + wave;
-        const int edge_chunks = min(P.nb_top + P.nb_bot, P.n_chunks);
-        const int edge_strips = min(P.ns_left + P.ns_right, P.n_strips);
-        const int inner = P.n_strips - edge_strips;
-        const int n_full = edge_chunks * inner;
-        const int n_side = P.n_chunks * edge_strips * P.side_subs;
-        if (id < n_full + n_side) {
-            int chunk, sx, ra, rb;
-            if (id < n_full) {
-                const int e = id / inner;
-                sx = P.ns_left + id % inner;
-                chunk = e < P.nb_top ? e : P.n_chunks - edge_chunks + e;
-                fused_chunk_rows(P, chunk, ra, rb);
-            } else {
-                int k = id - n_full;
-                const int sub = k % P.side_subs;
-                k /= P.side_subs;
-                const int e = k % edge_strips;
-                chunk = k / edge_strips;
-                sx = e < P.ns_left ? e : P.n_strips - edge_strips + e;
-                int c0, c1;
-                fused_chunk_rows(P, chunk, c0, c1);
-                ra = c0 + sub * P.side_rows;
-                rb = min(ra + P.side_rows, c1);
-            }
-            if (ra < rb) fused_wave<T, true, 0, UNR, 1>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc, force_border != 0);
-        }
-    } else {
-        const int bid = (int)blockIdx.x - n_border_blocks;
-        const int sx = (bid % plain_gx) * (kBlock / kWave) + wave;
-        const int chunk = bid / plain_gx;
-        int ra, rb;
-        fused_chunk_rows(P, chunk, ra, rb);
-        if (sx < P.n_strips && ra < rb && !fused_is_border_tile(P, chunk, sx))
-            fused_wave<T, false, 0, UNR, 1>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc);
-    }
-}
-
 // Dirichlet-mask grid: every tile is an ordinary tile (rows and columns outside the block read as zero
 // through the buffer range check, and zero is what lies outside a Dirichlet region); a tile whose extended
 // region holds no unknown at all leaves at once (its pixels are zero in both ping-pong buffers and stay so).

@@ -95,9 +95,7 @@ def test_every_pixel_fused_equals_in_place_unstructured(capi, monkeypatch, W, H,
 
 @pytest.mark.parametrize("env", [{"CCP_GS_ALL_BORDER": "1"}, {"CCP_GS_ALL_BORDER": "1", "CCP_GS_FORCE_BORDER": "1"},
                                  {"CCP_GS_SHORT_EDGES": "0"}, {"CCP_GS_SIDE_ROWS": "10"}, {"CCP_GS_TMAX": "3"},
-                                 {"CCP_GS_TMAX": "5", "CCP_GS_CHUNK": "40"}, {"CCP_GS_CHUNK": "1000"},
-                                 {"CCP_GS_MERGE_PASS": "1"}, {"CCP_GS_MERGE_PASS": "1", "CCP_GS_CHUNK": "64", "CCP_GS_SIDE_ROWS": "12"},
-                                 {"CCP_GS_MERGE_PASS": "0"}])
+                                 {"CCP_GS_TMAX": "5", "CCP_GS_CHUNK": "40"}, {"CCP_GS_CHUNK": "1000"}])
 def test_tiling_switches_never_change_results(capi, monkeypatch, env):
     """Every debugging / tiling switch of DESIGN section 8 on a grid with several strips and chunks: the
     temporally blocked pass must reproduce the in-place kernels bit for bit whatever the tiling."""
