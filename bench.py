@@ -332,7 +332,25 @@ def main():
     ghost = args.ghost if world > 1 else 0
     blk = rowblock.GridBlock(W, H, C, row_begin, row_count, ghost, local_rank)
     halo = args.halo if (world > 1 and args.backend == "nccl") else "torch"
-    solver = rowblock.make_solver(blk, rank, world, max(ghost, 2), dist, parts, H, halo=halo, overlap=not args.no_overlap)
+    halo_note = None
+    solver = None
+    if halo == "abi":
+        # the library's own RCCL communicator; should any rank fail to set it up, ALL ranks fall back to the
+        # torch.distributed exchange (decided together), so that a scaling run still produces its line
+        err = None
+        try:
+            solver = rowblock.make_solver(blk, rank, world, max(ghost, 2), dist, parts, H, halo="abi", overlap=not args.no_overlap)
+        except Exception as e:                                        # CcpError (CCP_ERR_RCCL ...), OSError
+            err = f"{type(e).__name__}: {e}"
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        if int(flag.item()) != 0:
+            if solver is not None:
+                solver.close()
+            solver, halo = None, "torch"
+            halo_note = f"ccp_comm_* setup failed on at least one rank ({err or 'another rank'}): torch.distributed halo exchange used instead"
+    if solver is None:
+        solver = rowblock.make_solver(blk, rank, world, max(ghost, 2), dist, parts, H, halo="torch", overlap=False)
     g = blk.grid
 
     # synthetic system, generated on device: x_true -> b = A x_true -> x0 = 1.0
@@ -446,7 +464,8 @@ def main():
                                     f"{W}x{H} {C}-channel Poisson blend, red-black Gauss-Seidel"),
                        "iters_per_step": ips, "channels": C,
                        "tiling": {"fused_depth": T, "rows_per_chunk": R, "tuned": tuned},
-                       "partition": "single block" if world == 1 else solver.describe()},
+                       "partition": "single block" if world == 1 else solver.describe(),
+                       **({"halo_note": halo_note} if halo_note else {})},
             "roofline": roofline,
         }
         out.update(extra)
