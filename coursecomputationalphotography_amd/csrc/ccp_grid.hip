@@ -74,9 +74,12 @@ struct ccp_grid {
     DevBuf<double> lex_x, lex_b, lex_snap, lex_partial, lex_eps;
     DevBuf<unsigned> lex_progress, lex_ticket;   // strip-wave pipeline: diagonals finished per (channel, sweep, strip); work tickets
     DevBuf<double> lex_edges;    // time-skewed strips: results of each strip's lanes 62/63 per step and sweep (read by the strip to its right)
-    int lex_mode = 1;            // 1: strip waves, one sweep per wave, all sweeps in one launch (default); 2: time-skewed strip
-                                 // waves, T sweeps per pass (CCP_GS_LEX_MODE=skew, experimental); 0: one launch per hyperplane (=planes)
+    int lex_mode = 3;            // 3: time-skewed strips, the T sweeps of a pass on the T waves of a workgroup (k_lex_wg, default);
+                                 // CCP_GS_LEX_MODE=strips -> 1: one sweep per wave, all sweeps in one launch; =skew -> 2: the T sweeps
+                                 // of a pass in one wave's registers; =planes -> 0: one launch per hyperplane
     int lex_tmax = 8;            // deepest time-skewed pass (CCP_GS_LEX_T: 1, 2, 4 or 8)
+    DevBuf<unsigned> lex_order;  // k_lex_wg: ticket -> group * strips + strip, in wavefront order
+    int lex_order_groups = 0, lex_order_strips = 0;
     int lex_chunk = 0;           // diagonals between two progress publications (CCP_GS_LEX_CHUNK; 0 = by size)
     LexGeom lexg{};
     DevBuf<double> stage;        // natural-order staging rows for host transfers
@@ -649,7 +652,7 @@ try {
     if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SHORT_EDGES")) g->short_edges = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SIDE_ROWS")) g->side_rows_override = atoi(e);
-    if (const char *e = getenv("CCP_GS_LEX_MODE")) g->lex_mode = strcmp(e, "planes") == 0 ? 0 : (strcmp(e, "skew") == 0 ? 2 : 1);
+    if (const char *e = getenv("CCP_GS_LEX_MODE")) g->lex_mode = strcmp(e, "planes") == 0 ? 0 : (strcmp(e, "strips") == 0 ? 1 : (strcmp(e, "skew") == 0 ? 2 : 3));
     if (const char *e = getenv("CCP_GS_LEX_T")) g->lex_tmax = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("CCP_GS_LEX_CHUNK")) g->lex_chunk = atoi(e);
     if (const char *e = getenv("CCP_GS_TMAX")) g->fuse_tmax = std::max(1, std::min(kFusedMaxT, atoi(e)));
@@ -1183,7 +1186,7 @@ int lex_strips(const ccp_grid *g) { return (g->desc.width + kLexStripCols - 1) /
 // slots a shallower launch does not write must read as zero, so the buffer is cleared per batch)
 long lex_partials_per_sweep(const ccp_grid *g)
 {
-    if (g->lex_mode == 2) return (long)((g->desc.width - 1 + 2 * 7) / kLexSkewCols + 1);
+    if (g->lex_mode >= 2) return (long)((g->desc.width - 1 + 2 * 7) / kLexSkewCols + 1);
     return g->lex_mode == 1 ? (long)lex_strips(g) : (long)g->lexg.n_diag * g->lexg.nbx;
 }
 
@@ -1224,13 +1227,42 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     int chunk = g->lex_chunk;
     if (chunk <= 0) chunk = std::min(lg.W, lg.H) <= 1024 ? 8 : 16;
     chunk = std::max(kLexSkewAhead, std::min(chunk, kWave)) / kLexSkewAhead * kLexSkewAhead;   // whole ring turns per chunk
-    const size_t need = (size_t)C * groups * S, edges = (size_t)C * S * edge_steps * 2 * T;
+    const bool wg = g->lex_mode == 3 && T >= 2;
+    const size_t need = (size_t)C * groups * S * (wg ? T : 1), edges = (size_t)C * S * edge_steps * 2 * T;
     if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
+    if (wg && (g->lex_order_groups != groups || g->lex_order_strips != S)) {
+        // Tickets in wavefront order: strip s of group k starts about (s + 3k) strip-lags after the first one, and
+        // a workgroup that is resident but waiting keeps a slot from one that could run.  Everything (k, s) waits
+        // for — (k, s-1), (k-1, s), (k-1, s+1) — sorts before it.
+        std::vector<unsigned> order((size_t)groups * S);
+        size_t n = 0;
+        for (long key = 0; key <= (long)(S - 1) + 3L * (groups - 1); ++key)
+            for (long k = std::max(0L, (key - (S - 1) + 2) / 3); k <= std::min<long>(groups - 1, key / 3); ++k)
+                order[n++] = (unsigned)(k * S + (key - 3 * k));
+        if (n != order.size()) return CCP_ERR_STATE;
+        if (g->lex_order.n < order.size()) CCP_TRY(g->lex_order.alloc(order.size()));
+        CCP_HIP(hipMemcpyAsync(g->lex_order.p, order.data(), order.size() * sizeof(unsigned), hipMemcpyHostToDevice, g->stream));
+        CCP_HIP(hipStreamSynchronize(g->stream));               // (the vector goes out of scope)
+        g->lex_order_groups = groups;
+        g->lex_order_strips = S;
+    }
     if (g->lex_edges.n < edges) CCP_TRY(g->lex_edges.alloc(edges));
     if (!g->lex_ticket.p) CCP_TRY(g->lex_ticket.alloc(kMaxChannels));
     CCP_HIP(hipMemsetAsync(g->lex_progress.p, 0, need * sizeof(unsigned), g->stream));
     CCP_HIP(hipMemsetAsync(g->lex_ticket.p, 0, kMaxChannels * sizeof(unsigned), g->stream));
     dim3 grid((unsigned)((long)groups * S), (unsigned)C);
+    if constexpr (T >= 2) {
+    if (g->lex_mode == 3) {                                  // the T sweeps of a group on the T waves of a workgroup
+        if (partial)
+            hipLaunchKernelGGL((k_lex_wg<T, true>), grid, dim3(T * kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,
+                               g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, partial, lex_partials_per_sweep(g));
+        else
+            hipLaunchKernelGGL((k_lex_wg<T, false>), grid, dim3(T * kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,
+                               g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, static_cast<double *>(nullptr), 0L);
+        CCP_HIP(hipGetLastError());
+        return CCP_OK;
+    }
+    }
     if (partial)
         hipLaunchKernelGGL((k_lex_skew<T, true>), grid, dim3(kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S, chunk,
                            g->lex_progress.p, g->lex_ticket.p, g->lex_edges.p, edge_steps, mask, partial, lex_partials_per_sweep(g));
@@ -1263,7 +1295,7 @@ int lex_run_skew(ccp_grid *g, int iterations, unsigned mask, double *partial)
 
 int lex_run(ccp_grid *g, int iterations, unsigned mask, double *partial)
 {
-    if (g->lex_mode == 2 && iterations > 0) return lex_run_skew(g, iterations, mask, partial);
+    if (g->lex_mode >= 2 && iterations > 0) return lex_run_skew(g, iterations, mask, partial);
     if (g->lex_mode == 1 && iterations > 0) return lex_run_strips(g, iterations, mask, partial);
     const LexGeom &lg = g->lexg;
     const int d_max = lg.n_diag - 1;
@@ -1343,7 +1375,7 @@ try {
         while (mask && done < max_iteration) {
             const int kb = std::min(batch_max, max_iteration - done);
             CCP_HIP(hipMemcpyAsync(g->lex_snap.p, g->lex_x.p, elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
-            if (g->lex_mode == 2) CCP_HIP(hipMemsetAsync(g->lex_partial.p, 0, sizeof(double) * (size_t)per * kb * C, g->stream));
+            if (g->lex_mode >= 2) CCP_HIP(hipMemsetAsync(g->lex_partial.p, 0, sizeof(double) * (size_t)per * kb * C, g->stream));
             CCP_TRY(lex_run(g, kb, mask, g->lex_partial.p));
             hipLaunchKernelGGL(k_lex_reduce, dim3((unsigned)kb, (unsigned)C), dim3(kBlock), 0, g->stream, g->lex_partial.p, per,
                                g->lex_eps.p);

@@ -413,6 +413,283 @@ k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGe
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// The skewed pass with the T sweeps spread over the T WAVES of a workgroup (k_lex_wg).  Same skew, same
+// strips, ghost lanes, edge buffer, progress counters and tickets as k_lex_skew — but wave t owns sweep t
+// alone: a handful of registers per lane instead of a 255-VGPR window, T times as many waves in flight, and
+// the sweep-to-sweep hand-off (the results of sweep t-1 three and four steps back, one and two lanes to the
+// left) goes through a ring of the last 8 result rows per sweep in LDS instead of DPP over register history.
+// The waves march in lock-step, one workgroup barrier per step: what wave t reads at step d was written by
+// wave t-1 at step d-3 / d-4, at least three barriers earlier, and is overwritten at step d+4 at the
+// earliest.  Only wave 0 reads x, only wave T-1 writes it.
+//
+// Three bodies per step, chosen per wave (uniformly):
+//   A  every real lane of the wave is an interior pixel (4 neighbours, diagonal 4): no classification, no
+//      bounds tests, row bases in scalar registers — the body nearly every step of nearly every strip takes;
+//   B  every real lane has 1 <= y <= H-2 but the strip touches the left / right image border: the stencil of a
+//      lane does not change from step to step, so it is classified once, outside the loop (the first and last
+//      strips must keep pace with the rest — every strip waits on its left neighbour);
+//   C  anything else (the first and last ~64 steps of a strip): the general body of k_lex_skew.
+// grid = (G * S, channels), block = T * 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
+constexpr int kLexRing = 8;
+constexpr int kLexWgAhead = 8;                     // prefetch distance in steps (= the unroll, = the ring)
+
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the global loads this
+// wave has in flight (the prefetch ring) at every step.
+__device__ __forceinline__ void lex_lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// What a wave of k_lex_wg carries from block to block.
+struct LexWgWave {
+    double h1 = 0.0, acc = 0.0;          // last result of this lane (its `up`; the next lane's `left`), sum |dx|
+    unsigned known = 0;                  // lanes 0..2: the newest progress value seen of the watched wave
+    const unsigned *watch = nullptr;     // lanes 0..2: whose progress to watch (own cell when there is nothing to wait for)
+    int need_off = 0;                    // ... which has to reach block start + need_off (INT_MIN/2: nothing to wait for)
+    unsigned *mine = nullptr;
+};
+
+// Blocks [db0, db1] (steps db0 .. db1+7) of one wave with every step in body A (BORDER = false) or B (true).
+// ROLE 0: the group's first sweep (reads x), 1: a middle one, 2: its last (writes x).  Straight-line steps:
+// nothing conditional around the loads, every address a running pointer, the prefetch ring in registers with
+// static indices — the 8 steps of a block are the 8 slots of the LDS ring and of the prefetch ring.
+template <int T, bool CHECK, int ROLE, bool BORDER>
+__device__ __forceinline__ void lex_wg_run(LexWgWave &w, double (*ring)[kLexRing][kWave], int t, int lane, int db0, int db1,
+                                           const double *pv, long v_stride, const double *px_dn, long dn_stride, const double *px_rt, long rt_stride,
+                                           const double *px_old, double *ps, double *pe, long P, bool lane_on, Stencil st_b)
+{
+    const bool ghost = lane < 2;
+    const int lds1 = max(lane - 1, 0), lds2 = max(lane - 2, 0);
+    double qv[8], qd[8], qr[8], qo[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        qv[j] = lex_ld(pv);
+        pv += v_stride;
+        qd[j] = qr[j] = qo[j] = 0.0;
+        if (ROLE == 0) {
+            qd[j] = lex_ld(px_dn);
+            qr[j] = lex_ld(px_rt);
+            if (CHECK) qo[j] = lex_ld(px_old);
+            px_dn += dn_stride;
+            px_rt += rt_stride;
+            px_old += dn_stride;
+        }
+    }
+    unsigned polled = 0;
+    for (int db = db0; db <= db1; db += 8) {
+        {                                                                    // inputs of this block published?
+            w.known = max(w.known, polled);
+            const int need = db + w.need_off;
+            bool ok = (int)min(w.known, 0x7fffffffu) >= need;
+            while (!__all(ok)) {
+                if (!ok) {
+                    w.known = __hip_atomic_load(w.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (int)min(w.known, 0x7fffffffu) >= need;
+                }
+                if (!__all(ok)) __builtin_amdgcn_s_sleep(4);
+            }
+            polled = __hip_atomic_load(w.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // looked at in the next block
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double vv = qv[j];
+            double down = qd[j], right = qr[j], old = qo[j];
+            qv[j] = lex_ld(pv);                                              // step d + 8
+            pv += v_stride;
+            if (ROLE == 0) {
+                qd[j] = lex_ld(px_dn);
+                qr[j] = lex_ld(px_rt);
+                if (CHECK) qo[j] = lex_ld(px_old);
+                px_dn += dn_stride;
+                px_rt += rt_stride;
+                px_old += dn_stride;
+            } else {
+                right = ring[t - 1][(j + 5) & 7][lds1];
+                down = ring[t - 1][(j + 5) & 7][lds2];
+                if (CHECK) old = ring[t - 1][(j + 4) & 7][lds2];
+            }
+            const double up = w.h1;
+            const double left = lane_prev(w.h1);
+            double nv;
+            bool wrote;
+            if (!BORDER) {
+                nv = (vv + (((up + left) + right) + down)) * 0.25;
+                nv = ghost ? vv : nv;
+                wrote = !ghost;
+            } else {
+                double r = 0.0;
+                wrote = gs_update(st_b, vv, up, left, right, down, r) && lane_on;
+                nv = ghost ? vv : (wrote ? r : 0.0);
+            }
+            if (CHECK) w.acc += wrote ? fabs(nv - old) : 0.0;
+            if (ROLE == 2) {
+                // body A stores from the ghost lanes too: they carry the left strip's results of the same sweep
+                // for exactly these pixels, so it is the value already there — and a store that is not
+                // conditional keeps the compiler's count of operations in flight (the vmcnt waits) exact
+                if (!BORDER || wrote) lex_st(ps, nv);
+                ps += P;
+            }
+            ring[t][j][lane] = nv;
+            w.h1 = nv;
+            lex_lds_barrier();
+        }
+        if (lane < 16) lex_st(pe, ring[t][lane >> 1][kWave - 2 + (lane & 1)]);            // the block's 8 x 2 edge values
+        pe += 8 * 2 * T;
+        // Vector-memory operations complete in issue order: the value consumed in the last step was loaded in
+        // step db-1, so every store of the steps up to db-2 has been acknowledged — publish those, no drain.
+        asm volatile("" ::"v"(w.h1) : "memory");
+        if (lane == 0 && db > db0 && db - 1 > 0) __hip_atomic_store(w.mine, (unsigned)(db - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+template <int T, bool CHECK>
+__global__ void __launch_bounds__(T * kWave)
+k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S,
+         unsigned *__restrict__ progress, unsigned *__restrict__ ticket, const unsigned *__restrict__ order,
+         double *__restrict__ edges, long edge_steps, unsigned active_mask, double *__restrict__ partial, long partial_stride)
+{
+    static_assert(kLexRing == 8 && T >= 2, "the unrolled step index is the ring slot; wave 0 reads x, wave T-1 writes it");
+    __shared__ double ring[T][kLexRing][kWave];
+    __shared__ unsigned s_ticket;
+    const int ch = blockIdx.y;
+    if (!((active_mask >> ch) & 1u)) return;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int t = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));      // this wave's sweep inside the group
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&ticket[ch], 1u);
+#pragma unroll
+    for (int q = 0; q < kLexRing; ++q) ring[t][q][lane] = 0.0;
+    __syncthreads();
+    const unsigned tk = order[s_ticket];                     // (group, strip) in wavefront order
+    const int grp = (int)(tk / (unsigned)S), s = (int)(tk % (unsigned)S);
+    const int HS = lg.H + 2 * (T - 1);
+    const int xs0 = kLexSkewCols * s - 2;
+    const int xp = xs0 + lane;
+    const int xl = xp - 2 * t;                               // this lane's image column
+    const bool ghost = lane < 2;
+    const int d_begin = xs0, d_end = xs0 + (kWave - 1) + HS - 1;
+    const int d_base = d_begin & ~7;                         // (floor to a multiple of 8, also when negative)
+    const long plane = (long)ch * lg.plane;
+    double *e_mine = edges + ((long)ch * S + s) * edge_steps * (2 * T);
+    const double *e_left = s > 0 ? edges + ((long)ch * S + s - 1) * edge_steps * (2 * T) : nullptr;
+    const int left_begin = xs0 - kLexSkewCols, left_end = left_begin + (kWave - 1) + HS - 1;
+    const bool lane_on = !ghost && xl >= 0 && xl < lg.W;
+    const bool ok_dn = xp >= 0 && xp < lg.W, ok_rt = xp + 1 >= 0 && xp + 1 < lg.W;
+    const bool ghost_live = ghost && e_left != nullptr;
+    const int lds1 = max(lane - 1, 0), lds2 = max(lane - 2, 0);
+
+    // progress is kept per wave: wave t of a strip feeds wave t of the strip to its right (edge values) and
+    // wave T-1 feeds wave 0 of the next group (x).  Lane 0 watches the left strip, lanes 1 and 2 of wave 0 the
+    // two strips of the previous group this one reads x from.
+    LexWgWave w;
+    w.mine = progress + ((((long)ch * G + grp) * S + s) * T + t);
+    w.watch = w.mine;
+    w.need_off = INT_MIN / 2;
+    if (lane == 0 && s > 0) {
+        w.watch = w.mine - T;
+        w.need_off = 16;                                     // before block [db, db+7], prefetching to db+15
+    }
+    if (t == 0 && grp > 0 && (lane == 1 || (lane == 2 && s + 1 < S))) {
+        w.watch = progress + ((((long)ch * G + grp - 1) * S + s + (lane - 1)) * T + (T - 1));
+        w.need_off = 17 + 4 * (T - 1);
+    }
+
+    // blocks in which every real lane of this wave has 1 <= y <= H-2 at every step, prefetches included
+    const int d_in_lo = xs0 + 64 + 2 * t, d_in_hi = xs0 + 2 * t + lg.H;
+    const bool strip_interior = s > 0 && xs0 + 2 - 2 * t >= 1 && xs0 + 63 - 2 * t <= lg.W - 2;
+    const int run0 = (max(d_in_lo, d_begin) + 7) & ~7;
+    const int run1 = (min(d_in_hi - 15, d_end - 7)) & ~7;                   // last block of the run (may be < run0: none)
+
+    auto general_block = [&](int db) {                                       // C: one step at a time, nothing in flight
+        {
+            const int need = db + w.need_off;
+            bool ok = (int)min(w.known, 0x7fffffffu) >= need;
+            while (!__all(ok)) {
+                if (!ok) {
+                    w.known = __hip_atomic_load(w.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = (int)min(w.known, 0x7fffffffu) >= need;
+                }
+                if (!__all(ok)) __builtin_amdgcn_s_sleep(4);
+            }
+        }
+#pragma unroll 1
+        for (int d = db; d < db + 8; ++d) {
+            if (d < d_begin || d > d_end) continue;                          // (uniform over the workgroup)
+            const int yp = d - xp, y = yp - 2 * t;
+            double right = 0.0, down = 0.0, old = 0.0, vv = 0.0;
+            if (t == 0) {                                     // sweep 0's inputs from x (the previous group's result)
+                if (ok_dn && yp + 1 >= 0 && yp + 1 < lg.H) down = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp]);
+                if (ok_rt && yp >= 0 && yp < lg.H) right = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp + 1]);
+                if (CHECK && ok_dn && yp >= 0 && yp < lg.H) old = lex_ld(&xd[plane + (long)d * lg.P + xp]);
+            } else {
+                right = ring[t - 1][(d - 3) & 7][lds1];
+                down = ring[t - 1][(d - 3) & 7][lds2];
+                if (CHECK) old = ring[t - 1][(d - 4) & 7][lds2];
+            }
+            const bool on = lane_on && y >= 0 && y < lg.H;
+            if (ghost) {
+                if (ghost_live && d >= left_begin && d <= left_end) vv = lex_ld(&e_left[((long)(d - left_begin) * T + t) * 2 + lane]);
+            } else if (on) {
+                vv = bd[plane + (long)(xl + y) * lg.P + xl];
+            }
+            const double up = w.h1;
+            const double left = lane_prev(w.h1);
+            double nv = ghost ? vv : 0.0;
+            if (on) {
+                const Stencil st = classify(g, xl, y, y);
+                if (st.diag != 0) {
+                    (void)gs_update(st, vv, up, left, right, down, nv);
+                    if (CHECK) w.acc += fabs(nv - old);
+                    if (t == T - 1) lex_st(&xd[plane + (long)(xl + y) * lg.P + xl], nv);
+                }
+            }
+            ring[t][d & 7][lane] = nv;
+            if (lane >= kWave - 2) lex_st(&e_mine[((long)(d - d_begin) * T + t) * 2 + (lane - (kWave - 2))], nv);
+            w.h1 = nv;
+            lex_lds_barrier();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // compiler ordering only
+        __builtin_amdgcn_s_waitcnt(0);                                       // this wave's (write-through) stores acknowledged
+        if (lane == 0 && db + 7 < d_end) __hip_atomic_store(w.mine, (unsigned)max(db + 8, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    };
+
+    int db = d_base;
+    for (; db <= d_end && (db < run0 || run1 < run0); db += 8) general_block(db);
+    if (run1 >= run0) {
+        // running pointers of bodies A / B at step run0; lanes with nothing to load read their own edge slot
+        // (stride 0, value unused) so that no load of the run is conditional
+        const bool v_live = ghost ? ghost_live : lane_on;
+        const double *pv = !v_live ? e_mine
+                           : ghost ? e_left + ((long)(run0 - left_begin) * T + t) * 2 + lane
+                                   : bd + plane + (long)(run0 - 4 * t) * lg.P + xl;
+        const long v_stride = !v_live ? 0 : (ghost ? 2L * T : (long)lg.P);
+        const double *px_dn = ok_dn ? xd + plane + (long)(run0 + 1) * lg.P + xp : e_mine;
+        const double *px_rt = ok_rt ? xd + plane + (long)(run0 + 1) * lg.P + xp + 1 : e_mine;
+        const double *px_old = ok_dn ? px_dn - lg.P : e_mine;
+        const long dn_stride = ok_dn ? (long)lg.P : 0, rt_stride = ok_rt ? (long)lg.P : 0;
+        double *ps = xd + plane + (long)(run0 - 4 * t) * lg.P + xl;
+        double *pe = e_mine + ((long)(run0 - d_begin + (lane >> 1)) * T + t) * 2 + (lane & 1);    // lanes 0..15: step lane/2, edge lane%2
+        const Stencil st_b = classify(g, lane_on ? xl : 0, 1, 1);
+        if (strip_interior) {
+            if (t == 0) lex_wg_run<T, CHECK, 0, false>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
+            else if (t == T - 1) lex_wg_run<T, CHECK, 2, false>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
+            else lex_wg_run<T, CHECK, 1, false>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
+        } else {
+            if (t == 0) lex_wg_run<T, CHECK, 0, true>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
+            else if (t == T - 1) lex_wg_run<T, CHECK, 2, true>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
+            else lex_wg_run<T, CHECK, 1, true>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
+        }
+        for (db = run1 + 8; db <= d_end; db += 8) general_block(db);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                   // compiler ordering only
+    __builtin_amdgcn_s_waitcnt(0);                                           // this wave's (write-through) stores acknowledged
+    if (lane == 0) __hip_atomic_store(w.mine, kLexDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (CHECK) {
+        const double total = wave_sum(w.acc);
+        if (lane == 0) partial[(((long)grp * T + t) * gridDim.y + ch) * partial_stride + s] = total;
+    }
+}
+
 // eps[k*channels + ch] = sum of the partials of iteration k in a fixed order.  grid = (iterations, channels)
 __global__ void __launch_bounds__(kBlock)
 k_lex_reduce(const double *__restrict__ partial, long per_iteration_channel, double *__restrict__ eps)

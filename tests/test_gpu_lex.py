@@ -54,6 +54,34 @@ def test_vs_oracle_seeded(capi, orc, W, H):
         assert np.array_equal(x[0], want), (W, H, k, np.abs(x[0] - want).max())
 
 
+@pytest.mark.parametrize("engine", ["wg", "strips", "skew", "planes"])
+def test_every_engine_of_the_reference_order(capi, orc, engine, monkeypatch):
+    """The four implementations of the reference-order sweep (CCP_GS_LEX_MODE, read when the handle is made;
+    default wg) give the oracle's bits and stop where it stops — on grids tall enough that the workgroup
+    kernel runs its straight-line bodies (interior strips and both border strips), 1 and 3 channels,
+    sweep counts that leave passes of 8, 4, 2 and 1."""
+    from coursecomputationalphotography_amd import synth
+    monkeypatch.setenv("CCP_GS_LEX_MODE", engine)
+    for W, H, C, k in ((130, 200, 1, 15), (700, 300, 3, 23), (61, 90, 1, 8), (250, 64, 1, 9), (2, 150, 1, 6)):
+        m = orc.from_csr(*synth.poisson_csr(W, H))
+        bs = np.stack([synth.poisson_system(W, H, 40 + ch)[0] * 1e-3 for ch in range(C)])
+        x, reps = run_lex(capi, W, H, bs, 0.0, k, 0, channels=C)
+        wants = [m.gauss_seidel(bs[ch], 0.0, k) for ch in range(C)]
+        for ch in range(C):
+            assert np.array_equal(x[ch], wants[ch][0]), (engine, W, H, ch, np.abs(x[ch] - wants[ch][0]).max())
+        # the stop rule, looked at after every sweep, from a start close to the solution (eps below its
+        # initial 10, so the reference loop runs): stops where the oracle stops
+        b0, xt = synth.poisson_system(W, H, 77)
+        x0 = xt.ravel() + 1e-6 * np.cos(np.arange(W * H) * 0.37)
+        eps_stop = m.gauss_seidel(b0, 0.0, k - 2, x0=x0)[2]
+        assert eps_stop < 10.0
+        want, it_want, eps_want = m.gauss_seidel(b0, eps_stop * (1.0 + 1e-9), 1000, x0=x0)
+        assert it_want == k - 2
+        x, reps = run_lex(capi, W, H, b0, eps_stop * (1.0 + 1e-9), 1000, 1, x0=x0.reshape(1, H, W))
+        assert reps[0].iterations == it_want and abs(reps[0].last_l1_step - eps_want) <= 1e-12 * eps_want, (engine, W, H)
+        assert np.array_equal(x[0], want), (engine, W, H, "stopped")
+
+
 @pytest.mark.parametrize("stop_at", [1, 5, 127, 128, 129, 200])
 def test_stop_rule_is_the_references(capi, orc, stop_at):
     """`while (eps > epsilon && cnt < max_iteration)` (sparse-matrix.h:356): epsilon is set just above the

@@ -420,7 +420,7 @@ def run_round2(n, rng, orc):
         bs = [synth.poisson_system(W, H, int(rng.integers(1, 1000)))[0] for _ in range(C)]
         om = orc.from_csr(*synth.poisson_csr(W, H))
         wants = [om.gauss_seidel(b, 0.0, iters)[0] for b in bs]
-        for mode in ("skew", "strips", "planes"):
+        for mode in ("wg", "skew", "strips", "planes"):
             os.environ["CCP_GS_LEX_MODE"] = mode
             os.environ["CCP_GS_LEX_CHUNK"] = str(int(rng.choice([0, 4, 8, 16, 33, 64])))
             g = capi.Grid(W, H, C)
