@@ -1336,9 +1336,12 @@ try {
     lg.plane = (long)lg.n_diag * lg.P;
     lg.nbx = (std::min(W, H) + kLexTile - 1) / kLexTile;
     const size_t elems = (size_t)lg.plane * C;
-    if (g->lex_x.n != elems) {
-        CCP_TRY(g->lex_x.alloc(elems));
-        CCP_TRY(g->lex_b.alloc(elems));
+    const size_t slack = (size_t)64 * lg.P;                  // k_lex_wg prefetches a few diagonals past the last one (never used)
+    if (g->lex_x.n != elems + slack) {
+        CCP_TRY(g->lex_x.alloc(elems + slack));
+        CCP_TRY(g->lex_b.alloc(elems + slack));
+        CCP_HIP(hipMemsetAsync(g->lex_x.p + elems, 0, slack * sizeof(double), g->stream));
+        CCP_HIP(hipMemsetAsync(g->lex_b.p + elems, 0, slack * sizeof(double), g->stream));
     }
     CCP_TRY(begin_timing(g));
     dim3 cgrid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, (unsigned)C);

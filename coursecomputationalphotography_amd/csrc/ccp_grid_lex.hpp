@@ -438,7 +438,11 @@ constexpr int kLexWgAhead = 8;                     // prefetch distance in steps
 // wave has in flight (the prefetch ring) at every step.
 __device__ __forceinline__ void lex_lds_barrier()
 {
+#if defined(CCP_EXP) && CCP_EXP == 3
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // What a wave of k_lex_wg carries from block to block.
@@ -450,36 +454,87 @@ struct LexWgWave {
     unsigned *mine = nullptr;
 };
 
+// b goes through LDS as well: sweep t needs diagonal row d - 4t of b at step d, so the T waves read the same
+// row four steps apart, each two columns further left.  Every wave loads a 1/T slice of row d+9 at step d and
+// writes the slice it loaded eight steps earlier (row d+1) into a ring of 32 rows; after the barrier of step d
+// rows d-30 .. d+1 are there.  b is read from memory once per PASS, not once per sweep.
+constexpr int kLexBRows = 32;
+template <int T>
+struct LexWgShape {
+    static constexpr int kCols = kLexSkewCols + 2 * (T - 1);                 // image columns the T sweeps of a strip touch
+    static constexpr int kSlice = (kCols + T - 1) / T;                       // ... of which every wave loads this many
+    static constexpr int kBW = kSlice * T;
+};
+
+__device__ __forceinline__ double lane_next_rot(double v)                    // lane i <- lane i+1, lane 63 <- lane 0
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, 0x134, 0xf, 0xf, true);          // wave_rol:1
+    hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// a / 3, correctly rounded, without the division sequence (body B does it at every step in the strip that
+// holds column 0, and every other strip waits on that one).  y = RN(1/3) = (1/3)(1 - 2^-54); q0 = RN(a y) is
+// within 1.5 ulp of a/3; r = a - 3 q0 is exact in an fma; a/3 = q0 + r/3 exactly, and q0 + r y differs from
+// it by |r/3| 2^-54 < 2^-106 |a|.  a/3 is never closer than ulp/6 to the midpoint of two doubles (a - 3m is a
+// non-zero multiple of ulp/2 for a midpoint m), so rounding q0 + r y — one rounding, in the fma — gives
+// RN(a/3).  r == 0 means q0 is the quotient itself (this keeps the sign of a zero).  Outside the exponent
+// range where none of this can underflow or overflow the caller divides (`safe` false).
+__device__ __forceinline__ double lex_div3(double a, bool &safe)
+{
+    const double y = 0x1.5555555555555p-2;
+    const double aa = fabs(a);
+    safe = (aa >= 0x1p-900 && aa <= 0x1p1000) || a == 0.0;
+    const double q0 = a * y;
+    const double r = __builtin_fma(-3.0, q0, a);
+    const double q1 = __builtin_fma(r, y, q0);
+    return r == 0.0 ? q0 : q1;
+}
+
 // Blocks [db0, db1] (steps db0 .. db1+7) of one wave with every step in body A (BORDER = false) or B (true).
 // ROLE 0: the group's first sweep (reads x), 1: a middle one, 2: its last (writes x).  Straight-line steps:
-// nothing conditional around the loads, every address a running pointer, the prefetch ring in registers with
-// static indices — the 8 steps of a block are the 8 slots of the LDS ring and of the prefetch ring.
+// nothing conditional around the loads, every address a running pointer, the prefetch rings in registers with
+// static indices — the 8 steps of a block are the 8 slots of the LDS result ring and of the prefetch rings.
+//   pb     this lane's element of the b slice of row db0+1 (lanes beyond the slice repeat its last element)
+//   pg     lanes 0..15: the left strip's edge value of step db0 + lane/2, edge lane%2 (the ghost lanes' input)
+//   px_dn  ROLE 0: x one row below this lane's pixel — lane 0 (a ghost lane) fetches the column right of lane 63
+//          instead, so `right` is `down` rotated by one lane
 template <int T, bool CHECK, int ROLE, bool BORDER>
-__device__ __forceinline__ void lex_wg_run(LexWgWave &w, double (*ring)[kLexRing][kWave], int t, int lane, int db0, int db1,
-                                           const double *pv, long v_stride, const double *px_dn, long dn_stride, const double *px_rt, long rt_stride,
-                                           const double *px_old, double *ps, double *pe, long P, bool lane_on, Stencil st_b)
+__device__ __forceinline__ void lex_wg_run(LexWgWave &w, double (*ring)[kLexRing][kWave], double (*brow)[LexWgShape<T>::kBW],
+                                           double (*gring)[8][2], int t, int lane, int db0, int db1, const double *pb, const double *pg,
+                                           bool ghost_live, const double *px_dn, long dn_stride, const double *px_old, long old_stride, double *ps,
+                                           double *pe, long P, bool lane_on, Stencil st_b)
 {
+    constexpr int SL = LexWgShape<T>::kSlice;
     const bool ghost = lane < 2;
     const int lds1 = max(lane - 1, 0), lds2 = max(lane - 2, 0);
-    double qv[8], qd[8], qr[8], qo[8];
+    const int ci = max(lane - 2 - 2 * t + 2 * (T - 1), 0);                   // this lane's column of a b row in LDS
+    const int ld_col = t * SL + min(lane, SL - 1);
+    // body B: this lane's kind of row (st_b: classify() of its column at an interior y)
+    const bool c_off = !lane_on || st_b.diag == 0;
+    const bool c_x0 = !c_off && !st_b.left, c_xl = !c_off && !st_b.right;
+    const bool any_x0 = BORDER && __any(c_x0), any_xl = BORDER && __any(c_xl);
+    double qb[8], qd[8], qo[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        qv[j] = lex_ld(pv);
-        pv += v_stride;
-        qd[j] = qr[j] = qo[j] = 0.0;
+        qb[j] = lex_ld(pb);
+        pb += P;
+        qd[j] = qo[j] = 0.0;
         if (ROLE == 0) {
             qd[j] = lex_ld(px_dn);
-            qr[j] = lex_ld(px_rt);
             if (CHECK) qo[j] = lex_ld(px_old);
             px_dn += dn_stride;
-            px_rt += rt_stride;
-            px_old += dn_stride;
+            px_old += old_stride;
         }
     }
-    unsigned polled = 0;
+    {                                                                        // the ghost lanes' values of block db0
+        const double g0 = lex_ld(pg);
+        pg += 8 * 2 * T;
+        if (lane < 16) gring[t][lane >> 1][lane & 1] = ghost_live ? g0 : 0.0;
+    }
     for (int db = db0; db <= db1; db += 8) {
         {                                                                    // inputs of this block published?
-            w.known = max(w.known, polled);
             const int need = db + w.need_off;
             bool ok = (int)min(w.known, 0x7fffffffu) >= need;
             while (!__all(ok)) {
@@ -489,39 +544,51 @@ __device__ __forceinline__ void lex_wg_run(LexWgWave &w, double (*ring)[kLexRing
                 }
                 if (!__all(ok)) __builtin_amdgcn_s_sleep(4);
             }
-            polled = __hip_atomic_load(w.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);         // looked at in the next block
         }
+        // issued here, looked at after the block's last step: no loaded value but the prefetch slots lives across
+        // the loop's back edge (one that does is waited for there with vmcnt(0), draining the slots with it)
+        const unsigned polled = __hip_atomic_load(w.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const double qg = lex_ld(pg);                                        // the ghost lanes' values of block db + 8
+        pg += 8 * 2 * T;
+        const int sb = (db - 4 * t) & (kLexBRows - 1);
+        int tag = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const double vv = qv[j];
-            double down = qd[j], right = qr[j], old = qo[j];
-            qv[j] = lex_ld(pv);                                              // step d + 8
-            pv += v_stride;
+            const double bl = qb[j];                                         // slice of row d + 1
+            if (lane < SL) brow[(db + j + 1) & (kLexBRows - 1)][ld_col] = bl;
+            if (j == 7) asm volatile("v_mov_b32 %0, %1" : "=v"(tag) : "v"(__double2loint(bl)));   // (a copy, made before the slot is refilled)
+            double down = qd[j], old = qo[j], right;
             if (ROLE == 0) {
-                qd[j] = lex_ld(px_dn);
-                qr[j] = lex_ld(px_rt);
-                if (CHECK) qo[j] = lex_ld(px_old);
-                px_dn += dn_stride;
-                px_rt += rt_stride;
-                px_old += dn_stride;
+                right = lane_next_rot(down);
             } else {
                 right = ring[t - 1][(j + 5) & 7][lds1];
                 down = ring[t - 1][(j + 5) & 7][lds2];
                 if (CHECK) old = ring[t - 1][(j + 4) & 7][lds2];
             }
+            const double *src = ghost ? &gring[t][j][lane & 1] : &brow[(sb + j) & (kLexBRows - 1)][ci];
+            const double vv = *src;
             const double up = w.h1;
             const double left = lane_prev(w.h1);
             double nv;
             bool wrote;
-            if (!BORDER) {
-                nv = (vv + (((up + left) + right) + down)) * 0.25;
-                nv = ghost ? vv : nv;
-                wrote = !ghost;
-            } else {
-                double r = 0.0;
-                wrote = gs_update(st_b, vv, up, left, right, down, r) && lane_on;
-                nv = ghost ? vv : (wrote ? r : 0.0);
+            nv = (vv + (((up + left) + right) + down)) * 0.25;               // (sparse-matrix.h:361-376 on a full row)
+            wrote = !ghost;
+            if (BORDER) {
+                // 1 <= y <= H-2 for every lane: the row of a pixel depends on its column alone — column 0 has no
+                // left neighbour (diagonal 3), column W-1 only its left one (diagonal 1), a 1-pixel-wide image
+                // and the lanes off the image have no row at all
+                if (any_x0) {
+                    const double a = vv + ((up + right) + down);
+                    bool safe;
+                    double q = lex_div3(a, safe);
+                    if (__any(c_x0 && !safe)) q = a / 3.0;
+                    nv = c_x0 ? q : nv;
+                }
+                if (any_xl) nv = c_xl ? vv + left : nv;
+                nv = c_off ? 0.0 : nv;
+                wrote = !ghost && !c_off;
             }
+            nv = ghost ? vv : nv;
             if (CHECK) w.acc += wrote ? fabs(nv - old) : 0.0;
             if (ROLE == 2) {
                 // body A stores from the ghost lanes too: they carry the left strip's results of the same sweep
@@ -532,13 +599,27 @@ __device__ __forceinline__ void lex_wg_run(LexWgWave &w, double (*ring)[kLexRing
             }
             ring[t][j][lane] = nv;
             w.h1 = nv;
+            // the slots are refilled only now, when their old contents are dead: a load issued while the old
+            // value is still live lands in another register and costs a copy — and a full vmcnt drain — at the
+            // loop's back edge
+            asm volatile("" ::: "memory");
+            qb[j] = lex_ld(pb);                                              // ... of row d + 9
+            pb += P;
+            if (ROLE == 0) {
+                qd[j] = lex_ld(px_dn);
+                if (CHECK) qo[j] = lex_ld(px_old);
+                px_dn += dn_stride;
+                px_old += old_stride;
+            }
             lex_lds_barrier();
         }
         if (lane < 16) lex_st(pe, ring[t][lane >> 1][kWave - 2 + (lane & 1)]);            // the block's 8 x 2 edge values
         pe += 8 * 2 * T;
-        // Vector-memory operations complete in issue order: the value consumed in the last step was loaded in
+        if (lane < 16) gring[t][lane >> 1][lane & 1] = ghost_live ? qg : 0.0;              // (this block's were read in its steps)
+        w.known = max(w.known, polled);
+        // Vector-memory operations complete in issue order: the slice written in the last step was loaded in
         // step db-1, so every store of the steps up to db-2 has been acknowledged — publish those, no drain.
-        asm volatile("" ::"v"(w.h1) : "memory");
+        asm volatile("" ::"v"(tag) : "memory");
         if (lane == 0 && db > db0 && db - 1 > 0) __hip_atomic_store(w.mine, (unsigned)(db - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -550,7 +631,11 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
          double *__restrict__ edges, long edge_steps, unsigned active_mask, double *__restrict__ partial, long partial_stride)
 {
     static_assert(kLexRing == 8 && T >= 2, "the unrolled step index is the ring slot; wave 0 reads x, wave T-1 writes it");
+    static_assert(4 * (T - 1) + 4 <= kLexBRows, "a b row stays in LDS from step r-1 to step r+4(T-1)");
+    constexpr int SL = LexWgShape<T>::kSlice, BW = LexWgShape<T>::kBW;
     __shared__ double ring[T][kLexRing][kWave];
+    __shared__ double brow[kLexBRows][BW];
+    __shared__ double gring[T][8][2];
     __shared__ unsigned s_ticket;
     const int ch = blockIdx.y;
     if (!((active_mask >> ch) & 1u)) return;
@@ -577,6 +662,9 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
     const bool ok_dn = xp >= 0 && xp < lg.W, ok_rt = xp + 1 >= 0 && xp + 1 < lg.W;
     const bool ghost_live = ghost && e_left != nullptr;
     const int lds1 = max(lane - 1, 0), lds2 = max(lane - 2, 0);
+    // the b slice this wave loads: columns cb + t*SL + lane of a row (cb: the leftmost column any sweep touches)
+    const int b_col = xs0 + 2 - 2 * (T - 1) + t * SL + min(lane, SL - 1);
+    const int b_col_c = min(max(b_col, 0), lg.W - 1);        // (clamped: what lies outside the image is never used)
 
     // progress is kept per wave: wave t of a strip feeds wave t of the strip to its right (edge values) and
     // wave T-1 feeds wave 0 of the next group (x).  Lane 0 watches the left strip, lanes 1 and 2 of wave 0 the
@@ -615,6 +703,10 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
 #pragma unroll 1
         for (int d = db; d < db + 8; ++d) {
             if (d < d_begin || d > d_end) continue;                          // (uniform over the workgroup)
+            if (lane < SL) {                                                 // this wave's share of b row d + 1
+                const int r = d + 1;
+                brow[r & (kLexBRows - 1)][t * SL + lane] = (r >= 0 && r < lg.n_diag && b_col >= 0 && b_col < lg.W) ? bd[plane + (long)r * lg.P + b_col] : 0.0;
+            }
             const int yp = d - xp, y = yp - 2 * t;
             double right = 0.0, down = 0.0, old = 0.0, vv = 0.0;
             if (t == 0) {                                     // sweep 0's inputs from x (the previous group's result)
@@ -658,27 +750,29 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
     if (run1 >= run0) {
         // running pointers of bodies A / B at step run0; lanes with nothing to load read their own edge slot
         // (stride 0, value unused) so that no load of the run is conditional
-        const bool v_live = ghost ? ghost_live : lane_on;
-        const double *pv = !v_live ? e_mine
-                           : ghost ? e_left + ((long)(run0 - left_begin) * T + t) * 2 + lane
-                                   : bd + plane + (long)(run0 - 4 * t) * lg.P + xl;
-        const long v_stride = !v_live ? 0 : (ghost ? 2L * T : (long)lg.P);
-        const double *px_dn = ok_dn ? xd + plane + (long)(run0 + 1) * lg.P + xp : e_mine;
-        const double *px_rt = ok_rt ? xd + plane + (long)(run0 + 1) * lg.P + xp + 1 : e_mine;
-        const double *px_old = ok_dn ? px_dn - lg.P : e_mine;
-        const long dn_stride = ok_dn ? (long)lg.P : 0, rt_stride = ok_rt ? (long)lg.P : 0;
+        const double *pb = bd + plane + (long)(run0 + 1) * lg.P + b_col_c;
+        const int gl = min(lane, 15);
+        const double *pg = s > 0 ? e_left + ((long)(run0 - left_begin + (gl >> 1)) * T + t) * 2 + (gl & 1) : e_mine;
+        const bool dn_live = lane == 0 ? xs0 + 64 < lg.W : ok_dn;            // lane 0: the column right of lane 63's
+        const double *px_dn = !dn_live ? e_mine : xd + plane + (long)(run0 + 1) * lg.P + (lane == 0 ? xs0 + 64 : xp);
+        const double *px_old = ok_dn ? xd + plane + (long)run0 * lg.P + xp : e_mine;
+        const long dn_stride = dn_live ? (long)lg.P : 0, old_stride = ok_dn ? (long)lg.P : 0;
         double *ps = xd + plane + (long)(run0 - 4 * t) * lg.P + xl;
         double *pe = e_mine + ((long)(run0 - d_begin + (lane >> 1)) * T + t) * 2 + (lane & 1);    // lanes 0..15: step lane/2, edge lane%2
         const Stencil st_b = classify(g, lane_on ? xl : 0, 1, 1);
+        const bool gl_live = s > 0;
+#define CCP_LEX_WG_RUN(ROLE, BORDER) \
+    lex_wg_run<T, CHECK, ROLE, BORDER>(w, ring, brow, gring, t, lane, run0, run1, pb, pg, gl_live, px_dn, dn_stride, px_old, old_stride, ps, pe, lg.P, lane_on, st_b)
         if (strip_interior) {
-            if (t == 0) lex_wg_run<T, CHECK, 0, false>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
-            else if (t == T - 1) lex_wg_run<T, CHECK, 2, false>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
-            else lex_wg_run<T, CHECK, 1, false>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
+            if (t == 0) CCP_LEX_WG_RUN(0, false);
+            else if (t == T - 1) CCP_LEX_WG_RUN(2, false);
+            else CCP_LEX_WG_RUN(1, false);
         } else {
-            if (t == 0) lex_wg_run<T, CHECK, 0, true>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
-            else if (t == T - 1) lex_wg_run<T, CHECK, 2, true>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
-            else lex_wg_run<T, CHECK, 1, true>(w, ring, t, lane, run0, run1, pv, v_stride, px_dn, dn_stride, px_rt, rt_stride, px_old, ps, pe, lg.P, lane_on, st_b);
+            if (t == 0) CCP_LEX_WG_RUN(0, true);
+            else if (t == T - 1) CCP_LEX_WG_RUN(2, true);
+            else CCP_LEX_WG_RUN(1, true);
         }
+#undef CCP_LEX_WG_RUN
         for (db = run1 + 8; db <= d_end; db += 8) general_block(db);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                   // compiler ordering only

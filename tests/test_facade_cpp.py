@@ -19,6 +19,14 @@ def driver():
     return EXE
 
 
+def test_division_free_third_is_correctly_rounded(driver):
+    """The three IEEE operations k_lex_wg's border body uses for a/3 (lex_div3, ccp_grid_lex.hpp) against the
+    host's correctly rounded division: 30 million cases — random significands over 1800 binades, binade
+    edges, exact quotients, signed zeros.  Host arithmetic only."""
+    out = subprocess.run([os.path.join(CPP, "div3_check")], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.startswith("ok "), out.stdout + out.stderr
+
+
 def test_host_side_insert_and_ingest_semantics(driver):
     """Five insert cases of main6.cc:193-231 + 400 seeded inserts against a dense mirror."""
     out = subprocess.run([driver, "host"], capture_output=True, text=True)
