@@ -1228,7 +1228,7 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     if (chunk <= 0) chunk = std::min(lg.W, lg.H) <= 1024 ? 8 : 16;
     chunk = std::max(kLexSkewAhead, std::min(chunk, kWave)) / kLexSkewAhead * kLexSkewAhead;   // whole ring turns per chunk
     const bool wg = g->lex_mode == 3 && T >= 2;
-    const size_t need = (size_t)C * groups * S * (wg ? T : 1), edges = (size_t)C * S * edge_steps * 2 * T;
+    const size_t need = (size_t)C * groups * S * (wg ? kLexWordStride : 1), edges = (size_t)C * S * edge_steps * 2 * T;
     if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
     if (wg && (g->lex_order_groups != groups || g->lex_order_strips != S)) {
         // Tickets in wavefront order: strip s of group k starts about (s + 3k) strip-lags after the first one, and
@@ -1253,11 +1253,12 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     dim3 grid((unsigned)((long)groups * S), (unsigned)C);
     if constexpr (T >= 2) {
     if (g->lex_mode == 3) {                                  // the T sweeps of a group on the T waves of a workgroup
+        static const int pad = getenv("CCP_GS_LEX_PAD_LDS") ? atoi(getenv("CCP_GS_LEX_PAD_LDS")) : 0;   // (occupancy experiments: extra LDS per workgroup)
         if (partial)
-            hipLaunchKernelGGL((k_lex_wg<T, true>), grid, dim3(T * kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,
+            hipLaunchKernelGGL((k_lex_wg<T, true>), grid, dim3((T + 2) * kWave), pad, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,
                                g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, partial, lex_partials_per_sweep(g));
         else
-            hipLaunchKernelGGL((k_lex_wg<T, false>), grid, dim3(T * kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,
+            hipLaunchKernelGGL((k_lex_wg<T, false>), grid, dim3((T + 2) * kWave), pad, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,
                                g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, static_cast<double *>(nullptr), 0L);
         CCP_HIP(hipGetLastError());
         return CCP_OK;

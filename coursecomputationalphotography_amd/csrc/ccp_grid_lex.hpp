@@ -414,165 +414,92 @@ k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGe
 }
 
 // ---------------------------------------------------------------------------------------------
-// The skewed pass with the T sweeps spread over the T WAVES of a workgroup (k_lex_wg).  Same skew, same
-// strips, ghost lanes, edge buffer, progress counters and tickets as k_lex_skew — but wave t owns sweep t
-// alone: a handful of registers per lane instead of a 255-VGPR window, T times as many waves in flight, and
-// the sweep-to-sweep hand-off (the results of sweep t-1 three and four steps back, one and two lanes to the
-// left) goes through a ring of the last 8 result rows per sweep in LDS instead of DPP over register history.
-// The waves march in lock-step, one workgroup barrier per step: what wave t reads at step d was written by
-// wave t-1 at step d-3 / d-4, at least three barriers earlier, and is overwritten at step d+4 at the
-// earliest.  Only wave 0 reads x, only wave T-1 writes it.
+// The skewed pass with the T sweeps spread over the waves of a workgroup (k_lex_wg).  Same skew, strips, ghost
+// lanes, edge buffer, progress words and tickets as k_lex_skew, but a workgroup of T + 2 waves per strip:
 //
-// Three bodies per step, chosen per wave (uniformly):
-//   A  every real lane of the wave is an interior pixel (4 neighbours, diagonal 4): no classification, no
-//      bounds tests, row bases in scalar registers — the body nearly every step of nearly every strip takes;
-//   B  every real lane has 1 <= y <= H-2 but the strip touches the left / right image border: the stencil of a
-//      lane does not change from step to step, so it is classified once, outside the loop (the first and last
-//      strips must keep pace with the rest — every strip waits on its left neighbour);
-//   C  anything else (the first and last ~64 steps of a strip): the general body of k_lex_skew.
-// grid = (G * S, channels), block = T * 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
+//   waves 0 .. T-1   one sweep each.  Wave t reads its inputs from LDS only — the results of sweep t-1 three and
+//                    four steps back (one and two lanes to the left) from a ring of the last 8 result rows per
+//                    sweep, b from a ring of 32 diagonal rows — and writes its result row into the ring.  No
+//                    global memory operation, ~20 instructions per step.
+//   wave T           the loader: everything the pass reads from memory, eight steps ahead in registers — the
+//                    next row of b (read once per PASS: sweep t uses row d-4t at step d), the next row of x for
+//                    sweep 0 (written into ring[0], so sweep 0 looks like every other sweep), the left strip's
+//                    edge values for the ghost lanes (a batch per 8 steps, into spare columns of the b rows).
+//                    It also watches the progress of the strips this one depends on, and so gates the others.
+//   wave T+1         the storer: sweep T-1's row to x and the edge values of all sweeps, one step behind; it
+//                    publishes the strip's progress.  Loads never queue behind stores (vmcnt is in order).
+//
+// The waves march in lock-step, one workgroup barrier per step (an isolated step of this shape costs 131 ns,
+// tools/step_bench.hip).  Three bodies:
+//   A  every real lane of the wave is an interior pixel (4 neighbours, diagonal 4);
+//   B  every real lane has 1 <= y <= H-2 but the strip touches the left / right image border: the row of a
+//      lane depends on its column alone and is classified once (the first and last strips must keep pace with
+//      the rest — every strip waits on its left neighbour);
+//   C  anything else (the first and last ~80 steps of a strip): the general body of k_lex_skew, one step at a
+//      time, every compute wave doing its own loads and stores.
+// grid = (G * S, channels), block = (T + 2) * 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
 constexpr int kLexRing = 8;
-constexpr int kLexWgAhead = 8;                     // prefetch distance in steps (= the unroll, = the ring)
+constexpr int kLexBRows = 32;
+constexpr int kLexWordStride = 32;                 // progress words of k_lex_wg: one per 128-byte line (the word a strip's
+                                                   // storer writes is polled by its neighbours' loaders)
 
-// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the global loads this
-// wave has in flight (the prefetch ring) at every step.
+// Workgroup barrier that orders LDS traffic only: __syncthreads() would also drain the global loads a wave
+// has in flight (the loader's prefetch ring) at every step.
 __device__ __forceinline__ void lex_lds_barrier()
 {
-#if defined(CCP_EXP) && CCP_EXP == 3
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
 }
 
-// What a wave of k_lex_wg carries from block to block.
-struct LexWgWave {
-    double h1 = 0.0, acc = 0.0;          // last result of this lane (its `up`; the next lane's `left`), sum |dx|
-    unsigned known = 0;                  // lanes 0..2: the newest progress value seen of the watched wave
-    const unsigned *watch = nullptr;     // lanes 0..2: whose progress to watch (own cell when there is nothing to wait for)
-    int need_off = 0;                    // ... which has to reach block start + need_off (INT_MIN/2: nothing to wait for)
-    unsigned *mine = nullptr;
-};
-
-// b goes through LDS as well: sweep t needs diagonal row d - 4t of b at step d, so the T waves read the same
-// row four steps apart, each two columns further left.  Every wave loads a 1/T slice of row d+9 at step d and
-// writes the slice it loaded eight steps earlier (row d+1) into a ring of 32 rows; after the barrier of step d
-// rows d-30 .. d+1 are there.  b is read from memory once per PASS, not once per sweep.
-constexpr int kLexBRows = 32;
 template <int T>
 struct LexWgShape {
     static constexpr int kCols = kLexSkewCols + 2 * (T - 1);                 // image columns the T sweeps of a strip touch
-    static constexpr int kSlice = (kCols + T - 1) / T;                       // ... of which every wave loads this many
-    static constexpr int kBW = kSlice * T;
+    static constexpr int kGhost = (kCols + 1) / 2 * 2;                       // first of the 2T ghost columns of a row in LDS
+    static constexpr int kRowW = kGhost + 2 * T;
 };
-
-__device__ __forceinline__ double lane_next_rot(double v)                    // lane i <- lane i+1, lane 63 <- lane 0
-{
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, 0x134, 0xf, 0xf, true);          // wave_rol:1
-    hi = __builtin_amdgcn_update_dpp(0, hi, 0x134, 0xf, 0xf, true);
-    return __hiloint2double(hi, lo);
-}
 
 // a / 3, correctly rounded, without the division sequence (body B does it at every step in the strip that
 // holds column 0, and every other strip waits on that one).  y = RN(1/3) = (1/3)(1 - 2^-54); q0 = RN(a y) is
 // within 1.5 ulp of a/3; r = a - 3 q0 is exact in an fma; a/3 = q0 + r/3 exactly, and q0 + r y differs from
 // it by |r/3| 2^-54 < 2^-106 |a|.  a/3 is never closer than ulp/6 to the midpoint of two doubles (a - 3m is a
 // non-zero multiple of ulp/2 for a midpoint m), so rounding q0 + r y — one rounding, in the fma — gives
-// RN(a/3).  r == 0 means q0 is the quotient itself (this keeps the sign of a zero).  Outside the exponent
-// range where none of this can underflow or overflow the caller divides (`safe` false).
+// RN(a/3).  r == 0 means q0 is the quotient itself.  Where the residual could underflow, and for zeros,
+// infinities and NaNs, the caller divides (`safe` false).  Checked on the host
+// against the machine's division: tests/cpp/div3_check.cpp.
 __device__ __forceinline__ double lex_div3(double a, bool &safe)
 {
     const double y = 0x1.5555555555555p-2;
-    const double aa = fabs(a);
-    safe = (aa >= 0x1p-900 && aa <= 0x1p1000) || a == 0.0;
+    safe = __builtin_amdgcn_class(a, 0x108) /* +-normal */ && fabs(a) >= 0x1p-900;      // (3 q0 ~ a: no overflow)
     const double q0 = a * y;
     const double r = __builtin_fma(-3.0, q0, a);
     const double q1 = __builtin_fma(r, y, q0);
     return r == 0.0 ? q0 : q1;
 }
 
-// Blocks [db0, db1] (steps db0 .. db1+7) of one wave with every step in body A (BORDER = false) or B (true).
-// ROLE 0: the group's first sweep (reads x), 1: a middle one, 2: its last (writes x).  Straight-line steps:
-// nothing conditional around the loads, every address a running pointer, the prefetch rings in registers with
-// static indices — the 8 steps of a block are the 8 slots of the LDS result ring and of the prefetch rings.
-//   pb     this lane's element of the b slice of row db0+1 (lanes beyond the slice repeat its last element)
-//   pg     lanes 0..15: the left strip's edge value of step db0 + lane/2, edge lane%2 (the ghost lanes' input)
-//   px_dn  ROLE 0: x one row below this lane's pixel — lane 0 (a ghost lane) fetches the column right of lane 63
-//          instead, so `right` is `down` rotated by one lane
-template <int T, bool CHECK, int ROLE, bool BORDER>
-__device__ __forceinline__ void lex_wg_run(LexWgWave &w, double (*ring)[kLexRing][kWave], double (*brow)[LexWgShape<T>::kBW],
-                                           double (*gring)[8][2], int t, int lane, int db0, int db1, const double *pb, const double *pg,
-                                           bool ghost_live, const double *px_dn, long dn_stride, const double *px_old, long old_stride, double *ps,
-                                           double *pe, long P, bool lane_on, Stencil st_b)
+// Blocks [db0, db1] (steps db0 .. db1+7) of compute wave t, every step in body A (BORDER = false) or B (true).
+// ring[t] holds sweep t's INPUT rows (ring[0]: x, filled by the loader), ring[t+1] its results.
+template <int T, bool CHECK, bool BORDER>
+__device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (*ring)[kLexRing][kWave],
+                                               const double (*brow)[LexWgShape<T>::kRowW], int t, int lane, int db0, int db1,
+                                               bool lane_on, Stencil st_b)
 {
-    constexpr int SL = LexWgShape<T>::kSlice;
     const bool ghost = lane < 2;
     const int lds1 = max(lane - 1, 0), lds2 = max(lane - 2, 0);
-    const int ci = max(lane - 2 - 2 * t + 2 * (T - 1), 0);                   // this lane's column of a b row in LDS
-    const int ld_col = t * SL + min(lane, SL - 1);
+    const int col = ghost ? LexWgShape<T>::kGhost + 2 * t + lane : lane - 2 - 2 * t + 2 * (T - 1);   // of a b row in LDS
     // body B: this lane's kind of row (st_b: classify() of its column at an interior y)
     const bool c_off = !lane_on || st_b.diag == 0;
     const bool c_x0 = !c_off && !st_b.left, c_xl = !c_off && !st_b.right;
     const bool any_x0 = BORDER && __any(c_x0), any_xl = BORDER && __any(c_xl);
-    double qb[8], qd[8], qo[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        qb[j] = lex_ld(pb);
-        pb += P;
-        qd[j] = qo[j] = 0.0;
-        if (ROLE == 0) {
-            qd[j] = lex_ld(px_dn);
-            if (CHECK) qo[j] = lex_ld(px_old);
-            px_dn += dn_stride;
-            px_old += old_stride;
-        }
-    }
-    {                                                                        // the ghost lanes' values of block db0
-        const double g0 = lex_ld(pg);
-        pg += 8 * 2 * T;
-        if (lane < 16) gring[t][lane >> 1][lane & 1] = ghost_live ? g0 : 0.0;
-    }
     for (int db = db0; db <= db1; db += 8) {
-        {                                                                    // inputs of this block published?
-            const int need = db + w.need_off;
-            bool ok = (int)min(w.known, 0x7fffffffu) >= need;
-            while (!__all(ok)) {
-                if (!ok) {
-                    w.known = __hip_atomic_load(w.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = (int)min(w.known, 0x7fffffffu) >= need;
-                }
-                if (!__all(ok)) __builtin_amdgcn_s_sleep(4);
-            }
-        }
-        // issued here, looked at after the block's last step: no loaded value but the prefetch slots lives across
-        // the loop's back edge (one that does is waited for there with vmcnt(0), draining the slots with it)
-        const unsigned polled = __hip_atomic_load(w.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const double qg = lex_ld(pg);                                        // the ghost lanes' values of block db + 8
-        pg += 8 * 2 * T;
         const int sb = (db - 4 * t) & (kLexBRows - 1);
-        int tag = 0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const double bl = qb[j];                                         // slice of row d + 1
-            if (lane < SL) brow[(db + j + 1) & (kLexBRows - 1)][ld_col] = bl;
-            if (j == 7) asm volatile("v_mov_b32 %0, %1" : "=v"(tag) : "v"(__double2loint(bl)));   // (a copy, made before the slot is refilled)
-            double down = qd[j], old = qo[j], right;
-            if (ROLE == 0) {
-                right = lane_next_rot(down);
-            } else {
-                right = ring[t - 1][(j + 5) & 7][lds1];
-                down = ring[t - 1][(j + 5) & 7][lds2];
-                if (CHECK) old = ring[t - 1][(j + 4) & 7][lds2];
-            }
-            const double *src = ghost ? &gring[t][j][lane & 1] : &brow[(sb + j) & (kLexBRows - 1)][ci];
-            const double vv = *src;
-            const double up = w.h1;
-            const double left = lane_prev(w.h1);
-            double nv;
-            bool wrote;
-            nv = (vv + (((up + left) + right) + down)) * 0.25;               // (sparse-matrix.h:361-376 on a full row)
-            wrote = !ghost;
+            const double right = ring[t][(j + 5) & 7][lds1];
+            const double down = ring[t][(j + 5) & 7][lds2];
+            const double vv = brow[(sb + j) & (kLexBRows - 1)][col];
+            const double up = h1;
+            const double left = lane_prev(h1);
+            double nv = (vv + (((up + left) + right) + down)) * 0.25;        // (sparse-matrix.h:361-376 on a full row)
+            bool wrote = !ghost;
             if (BORDER) {
                 // 1 <= y <= H-2 for every lane: the row of a pixel depends on its column alone — column 0 has no
                 // left neighbour (diagonal 3), column W-1 only its left one (diagonal 1), a 1-pixel-wide image
@@ -581,69 +508,183 @@ __device__ __forceinline__ void lex_wg_run(LexWgWave &w, double (*ring)[kLexRing
                     const double a = vv + ((up + right) + down);
                     bool safe;
                     double q = lex_div3(a, safe);
-                    if (__any(c_x0 && !safe)) q = a / 3.0;
+                    if (__any(c_x0 && !safe)) {
+                        asm volatile("" ::: "memory");                       // (keeps the division out of the common path)
+                        q = a / 3.0;
+                    }
                     nv = c_x0 ? q : nv;
                 }
                 if (any_xl) nv = c_xl ? vv + left : nv;
-                nv = c_off ? 0.0 : nv;
+                // (lanes off the image keep whatever the full-row formula gave: no row of the matrix reads them)
                 wrote = !ghost && !c_off;
             }
             nv = ghost ? vv : nv;
-            if (CHECK) w.acc += wrote ? fabs(nv - old) : 0.0;
-            if (ROLE == 2) {
-                // body A stores from the ghost lanes too: they carry the left strip's results of the same sweep
-                // for exactly these pixels, so it is the value already there — and a store that is not
-                // conditional keeps the compiler's count of operations in flight (the vmcnt waits) exact
-                if (!BORDER || wrote) lex_st(ps, nv);
-                ps += P;
+            if (CHECK) {
+                const double old = ring[t][(j + 4) & 7][lds2];
+                acc += wrote ? fabs(nv - old) : 0.0;
             }
-            ring[t][j][lane] = nv;
-            w.h1 = nv;
-            // the slots are refilled only now, when their old contents are dead: a load issued while the old
-            // value is still live lands in another register and costs a copy — and a full vmcnt drain — at the
-            // loop's back edge
-            asm volatile("" ::: "memory");
-            qb[j] = lex_ld(pb);                                              // ... of row d + 9
-            pb += P;
-            if (ROLE == 0) {
-                qd[j] = lex_ld(px_dn);
-                if (CHECK) qo[j] = lex_ld(px_old);
-                px_dn += dn_stride;
-                px_old += old_stride;
-            }
+            ring[t + 1][j][lane] = nv;
+            h1 = nv;
             lex_lds_barrier();
         }
-        if (lane < 16) lex_st(pe, ring[t][lane >> 1][kWave - 2 + (lane & 1)]);            // the block's 8 x 2 edge values
-        pe += 8 * 2 * T;
-        if (lane < 16) gring[t][lane >> 1][lane & 1] = ghost_live ? qg : 0.0;              // (this block's were read in its steps)
-        w.known = max(w.known, polled);
-        // Vector-memory operations complete in issue order: the slice written in the last step was loaded in
-        // step db-1, so every store of the steps up to db-2 has been acknowledged — publish those, no drain.
-        asm volatile("" ::"v"(tag) : "memory");
-        if (lane == 0 && db > db0 && db - 1 > 0) __hip_atomic_store(w.mine, (unsigned)(db - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// What the loader and the storer know about the strip.
+struct LexWgStrip {
+    const unsigned *watch;               // lanes 0..2 of the loader: whose progress to watch (own word: nothing to wait for)
+    int need_off;                        // ... which has to reach block start + need_off
+    unsigned known;
+    unsigned *mine;                      // this strip's progress word: steps < value are complete and visible
+};
+
+__device__ __forceinline__ void lex_wg_gate(LexWgStrip &st, int db)
+{
+    const int need = db + st.need_off;
+    bool ok = (int)min(st.known, 0x7fffffffu) >= need;
+    while (!__all(ok)) {
+        if (!ok) {
+            st.known = __hip_atomic_load(st.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            ok = (int)min(st.known, 0x7fffffffu) >= need;
+        }
+        if (!__all(ok)) __builtin_amdgcn_s_sleep(16);        // ~1000 cycles: the word is being written by the strip polled
+    }
+}
+
+// The loader's side of blocks [db0, db1].  pb: this lane's column of b row db0+1 (pb1: the columns past 64),
+// px: this lane's column of x row db0 (columns xs0+2 ..., as sweep 0's lanes 2.. read them one and two places to
+// their left), pg: lanes 0 .. 16T-1: the left strip's edge value of sweep lane/16, step db0 + (lane%16)/2, edge
+// lane%2 (a second load covers sweeps 4..7: 8 doubles further on).  Every slot of the register rings is refilled only after its old contents have been used (a load
+// issued while the old value is live lands in another register and costs a copy and a full drain at the
+// loop's back edge).
+template <int T>
+__device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexRing][kWave], double (*brow)[LexWgShape<T>::kRowW], int lane,
+                                            int db0, int db1, const double *pb, const double *pb1, const double *px, const double *pg,
+                                            bool ghost_live, long P)
+{
+    constexpr int kCols = LexWgShape<T>::kCols, kGhost = LexWgShape<T>::kGhost;
+    constexpr int kGhostOps = (16 * T + kWave - 1) / kWave;                  // 64-lane loads per ghost batch
+    // where lane's ghost value(s) of a block go: sweep gt, step gk/2, edge gk%2 -> row (d - 4 gt), column kGhost + 2 gt + e
+    int g_t[kGhostOps], g_step[kGhostOps], g_col[kGhostOps];
+    bool g_on[kGhostOps];
+#pragma unroll
+    for (int q = 0; q < kGhostOps; ++q) {
+        const int idx = q * kWave + lane;
+        g_on[q] = idx < 16 * T;
+        g_t[q] = min(idx >> 4, T - 1);
+        g_step[q] = (idx & 15) >> 1;
+        g_col[q] = kGhost + 2 * g_t[q] + (idx & 1);
+    }
+    lex_wg_gate(st, db0);
+    {   // what the first steps of the run read before the rings are rolling: x rows db0, db0+1, db0+2 and the
+        // ghost values of block db0
+#pragma unroll
+        for (int q = 0; q < 3; ++q) ring[0][(db0 + q - 4) & 7][lane] = lex_ld(px + (long)q * P);
+#pragma unroll
+        for (int q = 0; q < kGhostOps; ++q) {
+            const double v = ghost_live ? lex_ld(pg + 8 * q) : 0.0;
+            if (g_on[q]) brow[(db0 + g_step[q] - 4 * g_t[q]) & (kLexBRows - 1)][g_col[q]] = v;
+        }
+    }
+    px += 3 * P;
+    pg += 16 * T;
+    double qb[8], qb1[8], qx[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        qb[j] = lex_ld(pb);                                                  // b row db0 + 1 + j
+        qb1[j] = kCols > kWave ? lex_ld(pb1) : 0.0;
+        qx[j] = lex_ld(px);                                                  // x row db0 + 3 + j
+        pb += P;
+        pb1 += P;
+        px += P;
+    }
+    lex_lds_barrier();                                                       // (every wave of the workgroup comes here)
+    for (int db = db0; db <= db1; db += 8) {
+        if (db > db0) lex_wg_gate(st, db);
+        // issued here, looked at after the block's last step: no loaded value but the prefetch slots lives across
+        // the loop's back edge
+        const unsigned polled = __hip_atomic_load(st.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        double qg[kGhostOps];
+#pragma unroll
+        for (int q = 0; q < kGhostOps; ++q) qg[q] = ghost_live ? lex_ld(pg + 8 * q) : 0.0;       // block db + 8
+        pg += 16 * T;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = (db + j + 1) & (kLexBRows - 1);
+            brow[r][lane] = qb[j];                                           // b row d + 1
+            if (kCols > kWave && lane < kCols - kWave) brow[r][kWave + lane] = qb1[j];
+            ring[0][(j + 7) & 7][lane] = qx[j];                              // x row d + 3: read by sweep 0 at steps d+2, d+3
+            if (j == 7) {
+#pragma unroll
+                for (int q = 0; q < kGhostOps; ++q)
+                    if (g_on[q]) brow[(db + 8 + g_step[q] - 4 * g_t[q]) & (kLexBRows - 1)][g_col[q]] = qg[q];
+            }
+            asm volatile("" ::: "memory");
+            qb[j] = lex_ld(pb);                                              // b row d + 9
+            if (kCols > kWave) qb1[j] = lex_ld(pb1);
+            qx[j] = lex_ld(px);                                              // x row d + 11
+            pb += P;
+            pb1 += P;
+            px += P;
+            lex_lds_barrier();
+        }
+        st.known = max(st.known, polled);
+    }
+}
+
+// The storer's side of blocks [db0, db1]: after the barrier of step d, sweep T-1's row of that step goes to x
+// and the 2T edge values of the step to the edge buffer.  ps: this lane's pixel of sweep T-1 at step db0,
+// pe: lanes 0..2T-1: this strip's edge slot (step db0, sweep lane/2, edge lane%2).
+template <int T, bool BORDER>
+__device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLexRing][kWave], int lane, int db0, int db1, double *ps,
+                                             double *pe, long P, bool wrote)
+{
+    const int e_t = min(lane >> 1, T - 1) + 1, e_lane = kWave - 2 + (lane & 1);
+    lex_lds_barrier();                                                       // (the loader's priming barrier)
+    for (int db = db0; db <= db1; db += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            lex_lds_barrier();                                               // step d is in the rings
+            const double v = ring[T][j][lane];
+            const double ev = ring[e_t][j][e_lane];
+            // body A stores from the ghost lanes too: they carry the left strip's results of the same sweep for
+            // exactly these pixels, so it is the value already there
+            if (!BORDER || wrote) lex_st(ps, v);
+            if (lane < 2 * T) lex_st(pe, ev);
+            ps += P;
+            pe += 2 * T;
+        }
+        // Stores complete in issue order: once at most the 48 youngest are outstanding (16 per block and a
+        // publication: this block, the one before, most of a third), every store of the blocks before those
+        // has been acknowledged — publish their steps, without draining.
+        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
+        if (lane == 0 && db - 16 > db0) __hip_atomic_store(st.mine, (unsigned)(db - 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
 template <int T, bool CHECK>
-__global__ void __launch_bounds__(T * kWave)
+__global__ void __launch_bounds__((T + 2) * kWave)
 k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S,
          unsigned *__restrict__ progress, unsigned *__restrict__ ticket, const unsigned *__restrict__ order,
          double *__restrict__ edges, long edge_steps, unsigned active_mask, double *__restrict__ partial, long partial_stride)
 {
-    static_assert(kLexRing == 8 && T >= 2, "the unrolled step index is the ring slot; wave 0 reads x, wave T-1 writes it");
+    static_assert(kLexRing == 8 && T >= 2, "the unrolled step index is the ring slot");
     static_assert(4 * (T - 1) + 4 <= kLexBRows, "a b row stays in LDS from step r-1 to step r+4(T-1)");
-    constexpr int SL = LexWgShape<T>::kSlice, BW = LexWgShape<T>::kBW;
-    __shared__ double ring[T][kLexRing][kWave];
-    __shared__ double brow[kLexBRows][BW];
-    __shared__ double gring[T][8][2];
+    constexpr int kCols = LexWgShape<T>::kCols, kRowW = LexWgShape<T>::kRowW;
+    __shared__ double ring[T + 1][kLexRing][kWave];
+    __shared__ double brow[kLexBRows][kRowW];
     __shared__ unsigned s_ticket;
     const int ch = blockIdx.y;
     if (!((active_mask >> ch) & 1u)) return;
     const int lane = threadIdx.x & (kWave - 1);
-    const int t = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));      // this wave's sweep inside the group
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));     // 0..T-1: sweeps, T: loader, T+1: storer
+    const bool is_compute = wv < T, is_loader = wv == T, is_storer = wv == T + 1;
+    const int t = min(wv, T - 1);                            // (the storer works on sweep T-1's geometry)
     if (threadIdx.x == 0) s_ticket = atomicAdd(&ticket[ch], 1u);
+    if (wv <= T) {
 #pragma unroll
-    for (int q = 0; q < kLexRing; ++q) ring[t][q][lane] = 0.0;
+        for (int q = 0; q < kLexRing; ++q) ring[wv][q][lane] = 0.0;
+    }
     __syncthreads();
     const unsigned tk = order[s_ticket];                     // (group, strip) in wavefront order
     const int grp = (int)(tk / (unsigned)S), s = (int)(tk % (unsigned)S);
@@ -662,124 +703,120 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
     const bool ok_dn = xp >= 0 && xp < lg.W, ok_rt = xp + 1 >= 0 && xp + 1 < lg.W;
     const bool ghost_live = ghost && e_left != nullptr;
     const int lds1 = max(lane - 1, 0), lds2 = max(lane - 2, 0);
-    // the b slice this wave loads: columns cb + t*SL + lane of a row (cb: the leftmost column any sweep touches)
-    const int b_col = xs0 + 2 - 2 * (T - 1) + t * SL + min(lane, SL - 1);
-    const int b_col_c = min(max(b_col, 0), lg.W - 1);        // (clamped: what lies outside the image is never used)
+    const int cb = xs0 + 2 - 2 * (T - 1);                    // the leftmost image column any sweep of the strip touches
 
-    // progress is kept per wave: wave t of a strip feeds wave t of the strip to its right (edge values) and
-    // wave T-1 feeds wave 0 of the next group (x).  Lane 0 watches the left strip, lanes 1 and 2 of wave 0 the
-    // two strips of the previous group this one reads x from.
-    LexWgWave w;
-    w.mine = progress + ((((long)ch * G + grp) * S + s) * T + t);
-    w.watch = w.mine;
-    w.need_off = INT_MIN / 2;
+    // One progress word per strip, written by the storer.  The loader watches: lane 0 the left strip (edge
+    // values), lanes 1 and 2 the two strips of the previous group sweep 0 reads x from.
+    LexWgStrip st;
+    st.mine = progress + (((long)ch * G + grp) * S + s) * kLexWordStride;
+    st.watch = st.mine;
+    st.need_off = INT_MIN / 2;
+    st.known = 0;
     if (lane == 0 && s > 0) {
-        w.watch = w.mine - T;
-        w.need_off = 16;                                     // before block [db, db+7], prefetching to db+15
+        st.watch = st.mine - kLexWordStride;
+        st.need_off = 16;                                    // before block [db, db+7]: the ghost batch of block db+8
     }
-    if (t == 0 && grp > 0 && (lane == 1 || (lane == 2 && s + 1 < S))) {
-        w.watch = progress + ((((long)ch * G + grp - 1) * S + s + (lane - 1)) * T + (T - 1));
-        w.need_off = 17 + 4 * (T - 1);
+    if (grp > 0 && (lane == 1 || (lane == 2 && s + 1 < S))) {
+        st.watch = progress + (((long)ch * G + grp - 1) * S + s + (lane - 1)) * kLexWordStride;
+        st.need_off = 19 + 4 * (T - 1);                      // x row db+18, written by sweep T-1 at step db+18+4(T-1)
     }
 
-    // blocks in which every real lane of this wave has 1 <= y <= H-2 at every step, prefetches included
-    const int d_in_lo = xs0 + 64 + 2 * t, d_in_hi = xs0 + 2 * t + lg.H;
+    // blocks in which every real lane of every sweep has 1 <= y <= H-2 at every step (sweep t: steps
+    // xs0+64+2t .. xs0+2t+H), the same blocks for all waves
+    const int run0 = (max(xs0 + 64 + 2 * (T - 1), d_begin) + 7) & ~7;
+    const int run1 = (min(xs0 + lg.H, d_end) - 7) & ~7;                      // last block of the run (< run0: none)
     const bool strip_interior = s > 0 && xs0 + 2 - 2 * t >= 1 && xs0 + 63 - 2 * t <= lg.W - 2;
-    const int run0 = (max(d_in_lo, d_begin) + 7) & ~7;
-    const int run1 = (min(d_in_hi - 15, d_end - 7)) & ~7;                   // last block of the run (may be < run0: none)
+    double h1 = 0.0, acc = 0.0;
 
     auto general_block = [&](int db) {                                       // C: one step at a time, nothing in flight
-        {
-            const int need = db + w.need_off;
-            bool ok = (int)min(w.known, 0x7fffffffu) >= need;
-            while (!__all(ok)) {
-                if (!ok) {
-                    w.known = __hip_atomic_load(w.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = (int)min(w.known, 0x7fffffffu) >= need;
-                }
-                if (!__all(ok)) __builtin_amdgcn_s_sleep(4);
-            }
-        }
+        if (is_loader) lex_wg_gate(st, db);
+        lex_lds_barrier();
 #pragma unroll 1
         for (int d = db; d < db + 8; ++d) {
             if (d < d_begin || d > d_end) continue;                          // (uniform over the workgroup)
-            if (lane < SL) {                                                 // this wave's share of b row d + 1
+            if (is_loader) {                                                 // b row d + 1 into the ring
                 const int r = d + 1;
-                brow[r & (kLexBRows - 1)][t * SL + lane] = (r >= 0 && r < lg.n_diag && b_col >= 0 && b_col < lg.W) ? bd[plane + (long)r * lg.P + b_col] : 0.0;
+                const bool r_ok = r >= 0 && r < lg.n_diag;
+                const int c0 = cb + lane, c1 = cb + kWave + lane;
+                brow[r & (kLexBRows - 1)][lane] = (r_ok && c0 >= 0 && c0 < lg.W) ? bd[plane + (long)r * lg.P + c0] : 0.0;
+                if (kCols > kWave && lane < kCols - kWave)
+                    brow[r & (kLexBRows - 1)][kWave + lane] = (r_ok && c1 >= 0 && c1 < lg.W) ? bd[plane + (long)r * lg.P + c1] : 0.0;
             }
-            const int yp = d - xp, y = yp - 2 * t;
-            double right = 0.0, down = 0.0, old = 0.0, vv = 0.0;
-            if (t == 0) {                                     // sweep 0's inputs from x (the previous group's result)
-                if (ok_dn && yp + 1 >= 0 && yp + 1 < lg.H) down = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp]);
-                if (ok_rt && yp >= 0 && yp < lg.H) right = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp + 1]);
-                if (CHECK && ok_dn && yp >= 0 && yp < lg.H) old = lex_ld(&xd[plane + (long)d * lg.P + xp]);
-            } else {
-                right = ring[t - 1][(d - 3) & 7][lds1];
-                down = ring[t - 1][(d - 3) & 7][lds2];
-                if (CHECK) old = ring[t - 1][(d - 4) & 7][lds2];
-            }
-            const bool on = lane_on && y >= 0 && y < lg.H;
-            if (ghost) {
-                if (ghost_live && d >= left_begin && d <= left_end) vv = lex_ld(&e_left[((long)(d - left_begin) * T + t) * 2 + lane]);
-            } else if (on) {
-                vv = bd[plane + (long)(xl + y) * lg.P + xl];
-            }
-            const double up = w.h1;
-            const double left = lane_prev(w.h1);
-            double nv = ghost ? vv : 0.0;
-            if (on) {
-                const Stencil st = classify(g, xl, y, y);
-                if (st.diag != 0) {
-                    (void)gs_update(st, vv, up, left, right, down, nv);
-                    if (CHECK) w.acc += fabs(nv - old);
-                    if (t == T - 1) lex_st(&xd[plane + (long)(xl + y) * lg.P + xl], nv);
+            if (is_compute) {
+                const int yp = d - xp, y = yp - 2 * t;
+                double right = 0.0, down = 0.0, old = 0.0, vv = 0.0;
+                if (t == 0) {                                 // sweep 0's inputs from x (the previous group's result)
+                    if (ok_dn && yp + 1 >= 0 && yp + 1 < lg.H) down = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp]);
+                    if (ok_rt && yp >= 0 && yp < lg.H) right = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp + 1]);
+                    if (CHECK && ok_dn && yp >= 0 && yp < lg.H) old = lex_ld(&xd[plane + (long)d * lg.P + xp]);
+                } else {
+                    right = ring[t][(d - 3) & 7][lds1];
+                    down = ring[t][(d - 3) & 7][lds2];
+                    if (CHECK) old = ring[t][(d - 4) & 7][lds2];
                 }
+                const bool on = lane_on && y >= 0 && y < lg.H;
+                if (ghost) {
+                    if (ghost_live && d >= left_begin && d <= left_end) vv = lex_ld(&e_left[((long)(d - left_begin) * T + t) * 2 + lane]);
+                } else if (on) {
+                    vv = bd[plane + (long)(xl + y) * lg.P + xl];
+                }
+                const double up = h1;
+                const double left = lane_prev(h1);
+                double nv = ghost ? vv : 0.0;
+                if (on) {
+                    const Stencil sc = classify(g, xl, y, y);
+                    if (sc.diag != 0) {
+                        (void)gs_update(sc, vv, up, left, right, down, nv);
+                        if (CHECK) acc += fabs(nv - old);
+                        if (t == T - 1) lex_st(&xd[plane + (long)(xl + y) * lg.P + xl], nv);
+                    }
+                }
+                ring[t + 1][d & 7][lane] = nv;
+                if (lane >= kWave - 2) lex_st(&e_mine[((long)(d - d_begin) * T + t) * 2 + (lane - (kWave - 2))], nv);
+                h1 = nv;
             }
-            ring[t][d & 7][lane] = nv;
-            if (lane >= kWave - 2) lex_st(&e_mine[((long)(d - d_begin) * T + t) * 2 + (lane - (kWave - 2))], nv);
-            w.h1 = nv;
             lex_lds_barrier();
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // compiler ordering only
         __builtin_amdgcn_s_waitcnt(0);                                       // this wave's (write-through) stores acknowledged
-        if (lane == 0 && db + 7 < d_end) __hip_atomic_store(w.mine, (unsigned)max(db + 8, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lex_lds_barrier();                                                   // ... and every other wave's
+        if (is_storer && lane == 0 && db + 7 < d_end)
+            __hip_atomic_store(st.mine, (unsigned)max(db + 8, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     };
 
     int db = d_base;
     for (; db <= d_end && (db < run0 || run1 < run0); db += 8) general_block(db);
     if (run1 >= run0) {
-        // running pointers of bodies A / B at step run0; lanes with nothing to load read their own edge slot
-        // (stride 0, value unused) so that no load of the run is conditional
-        const double *pb = bd + plane + (long)(run0 + 1) * lg.P + b_col_c;
-        const int gl = min(lane, 15);
-        const double *pg = s > 0 ? e_left + ((long)(run0 - left_begin + (gl >> 1)) * T + t) * 2 + (gl & 1) : e_mine;
-        const bool dn_live = lane == 0 ? xs0 + 64 < lg.W : ok_dn;            // lane 0: the column right of lane 63's
-        const double *px_dn = !dn_live ? e_mine : xd + plane + (long)(run0 + 1) * lg.P + (lane == 0 ? xs0 + 64 : xp);
-        const double *px_old = ok_dn ? xd + plane + (long)run0 * lg.P + xp : e_mine;
-        const long dn_stride = dn_live ? (long)lg.P : 0, old_stride = ok_dn ? (long)lg.P : 0;
-        double *ps = xd + plane + (long)(run0 - 4 * t) * lg.P + xl;
-        double *pe = e_mine + ((long)(run0 - d_begin + (lane >> 1)) * T + t) * 2 + (lane & 1);    // lanes 0..15: step lane/2, edge lane%2
-        const Stencil st_b = classify(g, lane_on ? xl : 0, 1, 1);
-        const bool gl_live = s > 0;
-#define CCP_LEX_WG_RUN(ROLE, BORDER) \
-    lex_wg_run<T, CHECK, ROLE, BORDER>(w, ring, brow, gring, t, lane, run0, run1, pb, pg, gl_live, px_dn, dn_stride, px_old, old_stride, ps, pe, lg.P, lane_on, st_b)
-        if (strip_interior) {
-            if (t == 0) CCP_LEX_WG_RUN(0, false);
-            else if (t == T - 1) CCP_LEX_WG_RUN(2, false);
-            else CCP_LEX_WG_RUN(1, false);
+        if (is_compute) {
+            const Stencil st_b = classify(g, lane_on ? xl : 0, 1, 1);
+            lex_lds_barrier();                                               // (the loader's priming barrier)
+            if (strip_interior) lex_wg_compute<T, CHECK, false>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
+            else lex_wg_compute<T, CHECK, true>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
+        } else if (is_loader) {
+            // lanes whose column lies outside the image load a clamped one: no load of the run is conditional,
+            // and what they fetch is never used
+            const double *pb = bd + plane + (long)(run0 + 1) * lg.P + min(max(cb + lane, 0), lg.W - 1);
+            const double *pb1 = bd + plane + (long)(run0 + 1) * lg.P + min(max(cb + kWave + min(lane, max(kCols - kWave - 1, 0)), 0), lg.W - 1);
+            const double *px = xd + plane + (long)run0 * lg.P + min(max(xs0 + 2 + min(lane, kWave - 2), 0), lg.W - 1);
+            const int gi = min(lane, 16 * T - 1);            // (second 64 lanes of the batch: + 64 doubles)
+            const double *pg = s > 0 ? e_left + ((long)(run0 - left_begin + ((gi & 15) >> 1)) * T + (gi >> 4)) * 2 + (gi & 1) : e_mine;
+            lex_wg_load<T>(st, ring, brow, lane, run0, run1, pb, pb1, px, pg, s > 0, lg.P);
         } else {
-            if (t == 0) CCP_LEX_WG_RUN(0, true);
-            else if (t == T - 1) CCP_LEX_WG_RUN(2, true);
-            else CCP_LEX_WG_RUN(1, true);
+            const Stencil st_b = classify(g, lane_on ? xl : 0, 1, 1);
+            double *ps = xd + plane + (long)(run0 - 4 * t) * lg.P + xl;
+            double *pe = e_mine + ((long)(run0 - d_begin) * T) * 2 + min(lane, 2 * T - 1);
+            const bool wrote = lane_on && st_b.diag != 0;
+            if (strip_interior) lex_wg_store<T, false>(st, ring, lane, run0, run1, ps, pe, lg.P, wrote);
+            else lex_wg_store<T, true>(st, ring, lane, run0, run1, ps, pe, lg.P, wrote);
         }
-#undef CCP_LEX_WG_RUN
         for (db = run1 + 8; db <= d_end; db += 8) general_block(db);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                   // compiler ordering only
-    __builtin_amdgcn_s_waitcnt(0);                                           // this wave's (write-through) stores acknowledged
-    if (lane == 0) __hip_atomic_store(w.mine, kLexDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (CHECK) {
-        const double total = wave_sum(w.acc);
+    __builtin_amdgcn_s_waitcnt(0);
+    lex_lds_barrier();
+    if (is_storer && lane == 0) __hip_atomic_store(st.mine, kLexDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (CHECK && is_compute) {
+        const double total = wave_sum(acc);
         if (lane == 0) partial[(((long)grp * T + t) * gridDim.y + ch) * partial_stride + s] = total;
     }
 }
