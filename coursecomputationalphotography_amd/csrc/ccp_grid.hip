@@ -1231,14 +1231,15 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     const size_t need = (size_t)C * groups * S * (wg ? kLexWordStride : 1), edges = (size_t)C * S * edge_steps * 2 * T;
     if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
     if (wg && (g->lex_order_groups != groups || g->lex_order_strips != S)) {
-        // Tickets in wavefront order: strip s of group k starts about (s + 3k) strip-lags after the first one, and
-        // a workgroup that is resident but waiting keeps a slot from one that could run.  Everything (k, s) waits
-        // for — (k, s-1), (k-1, s), (k-1, s+1) — sorts before it.
+        // Tickets in wavefront order: strip s of group k starts about (s + rho k) strip-lags after the first one,
+        // and a workgroup that is resident but waiting keeps a slot from one that could run.  Everything (k, s)
+        // waits for — (k, s-1), (k-1, s), (k-1, s+1) — sorts before it for any rho >= 1 (ties: lower group first).
+        static const long rho = std::max(1, getenv("CCP_GS_LEX_RHO") ? atoi(getenv("CCP_GS_LEX_RHO")) : 3);
         std::vector<unsigned> order((size_t)groups * S);
         size_t n = 0;
-        for (long key = 0; key <= (long)(S - 1) + 3L * (groups - 1); ++key)
-            for (long k = std::max(0L, (key - (S - 1) + 2) / 3); k <= std::min<long>(groups - 1, key / 3); ++k)
-                order[n++] = (unsigned)(k * S + (key - 3 * k));
+        for (long key = 0; key <= (long)(S - 1) + rho * (groups - 1); ++key)
+            for (long k = std::max(0L, (key - (S - 1) + rho - 1) / rho); k <= std::min<long>(groups - 1, key / rho); ++k)
+                order[n++] = (unsigned)(k * S + (key - rho * k));
         if (n != order.size()) return CCP_ERR_STATE;
         if (g->lex_order.n < order.size()) CCP_TRY(g->lex_order.alloc(order.size()));
         CCP_HIP(hipMemcpyAsync(g->lex_order.p, order.data(), order.size() * sizeof(unsigned), hipMemcpyHostToDevice, g->stream));

@@ -459,25 +459,31 @@ struct LexWgShape {
 
 // a / 3, correctly rounded, without the division sequence (body B does it at every step in the strip that
 // holds column 0, and every other strip waits on that one).  y = RN(1/3) = (1/3)(1 - 2^-54); q0 = RN(a y) is
-// within 1.5 ulp of a/3; r = a - 3 q0 is exact in an fma; a/3 = q0 + r/3 exactly, and q0 + r y differs from
-// it by |r/3| 2^-54 < 2^-106 |a|.  a/3 is never closer than ulp/6 to the midpoint of two doubles (a - 3m is a
-// non-zero multiple of ulp/2 for a midpoint m), so rounding q0 + r y — one rounding, in the fma — gives
-// RN(a/3).  r == 0 means q0 is the quotient itself.  Where the residual could underflow, and for zeros,
-// infinities and NaNs, the caller divides (`safe` false).  Checked on the host
-// against the machine's division: tests/cpp/div3_check.cpp.
-__device__ __forceinline__ double lex_div3(double a, bool &safe)
+// within 1.5 ulp of a/3; r = a - 3 q0 is a small multiple of ulp(q0), exact in an fma; a/3 = q0 + r/3 exactly,
+// and q0 + r y differs from it by |r/3| 2^-54.  a/3 is never closer than ulp/6 to the midpoint of two doubles
+// (a - 3m is a non-zero multiple of ulp/2 for a midpoint m), so rounding q0 + r y — one rounding, in the fma —
+// gives RN(a/3); r == 0 means q0 is the quotient itself (this keeps the sign of a zero).  Holds for every
+// finite a, subnormals included (fp64 subnormals are not flushed); infinities and NaNs the caller divides.
+// Checked on the host against the machine's division over every binade: tests/cpp/div3_check.cpp.
+__device__ __forceinline__ double lex_div3(double a, bool &finite)
 {
     const double y = 0x1.5555555555555p-2;
-    safe = __builtin_amdgcn_class(a, 0x108) /* +-normal */ && fabs(a) >= 0x1p-900;      // (3 q0 ~ a: no overflow)
+    finite = !__builtin_amdgcn_class(a, 0x207);               // not (NaN | +-inf)
     const double q0 = a * y;
     const double r = __builtin_fma(-3.0, q0, a);
     const double q1 = __builtin_fma(r, y, q0);
     return r == 0.0 ? q0 : q1;
 }
 
-// Blocks [db0, db1] (steps db0 .. db1+7) of compute wave t, every step in body A (BORDER = false) or B (true).
+// Blocks [db0, db1] (steps db0 .. db1+7) of compute wave t, every step in body A (KIND 0) or B (1: the wave holds
+// column 0 — only in strip 0, whose ghost lanes lie off the image; 2: it holds column W-1; 3: both, an image
+// narrower than a strip).  1 <= y <= H-2 for every lane, so the row of a pixel depends on its column alone:
+// column 0 has no left neighbour (diagonal 3), column W-1 only its left one (diagonal 1), a 1-pixel-wide image
+// and the lanes off the image have no row at all — those keep whatever the full-row formula gives, no row of the
+// matrix reads them.  A group moves at the pace of its first strip (every strip waits on its left neighbour),
+// and three of that strip's waves share a SIMD: body B is kept as short as body A allows.
 // ring[t] holds sweep t's INPUT rows (ring[0]: x, filled by the loader), ring[t+1] its results.
-template <int T, bool CHECK, bool BORDER>
+template <int T, bool CHECK, int KIND>
 __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (*ring)[kLexRing][kWave],
                                                const double (*brow)[LexWgShape<T>::kRowW], int t, int lane, int db0, int db1,
                                                bool lane_on, Stencil st_b)
@@ -485,10 +491,9 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
     const bool ghost = lane < 2;
     const int lds1 = max(lane - 1, 0), lds2 = max(lane - 2, 0);
     const int col = ghost ? LexWgShape<T>::kGhost + 2 * t + lane : lane - 2 - 2 * t + 2 * (T - 1);   // of a b row in LDS
-    // body B: this lane's kind of row (st_b: classify() of its column at an interior y)
-    const bool c_off = !lane_on || st_b.diag == 0;
+    const bool c_off = !lane_on || st_b.diag == 0;           // (st_b: classify() of this lane's column at an interior y)
     const bool c_x0 = !c_off && !st_b.left, c_xl = !c_off && !st_b.right;
-    const bool any_x0 = BORDER && __any(c_x0), any_xl = BORDER && __any(c_xl);
+    const bool wrote = KIND == 0 ? !ghost : !c_off;
     for (int db = db0; db <= db1; db += 8) {
         const int sb = (db - 4 * t) & (kLexBRows - 1);
 #pragma unroll
@@ -499,26 +504,18 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
             const double up = h1;
             const double left = lane_prev(h1);
             double nv = (vv + (((up + left) + right) + down)) * 0.25;        // (sparse-matrix.h:361-376 on a full row)
-            bool wrote = !ghost;
-            if (BORDER) {
-                // 1 <= y <= H-2 for every lane: the row of a pixel depends on its column alone — column 0 has no
-                // left neighbour (diagonal 3), column W-1 only its left one (diagonal 1), a 1-pixel-wide image
-                // and the lanes off the image have no row at all
-                if (any_x0) {
-                    const double a = vv + ((up + right) + down);
-                    bool safe;
-                    double q = lex_div3(a, safe);
-                    if (__any(c_x0 && !safe)) {
-                        asm volatile("" ::: "memory");                       // (keeps the division out of the common path)
-                        q = a / 3.0;
-                    }
-                    nv = c_x0 ? q : nv;
+            if (KIND & 1) {
+                const double a = vv + ((up + right) + down);
+                bool finite;
+                double q = lex_div3(a, finite);
+                if (__any(c_x0 && !finite)) {
+                    asm volatile("" ::: "memory");                           // (keeps the division out of the common path)
+                    q = a / 3.0;
                 }
-                if (any_xl) nv = c_xl ? vv + left : nv;
-                // (lanes off the image keep whatever the full-row formula gave: no row of the matrix reads them)
-                wrote = !ghost && !c_off;
+                nv = c_x0 ? q : nv;
             }
-            nv = ghost ? vv : nv;
+            if (KIND & 2) nv = c_xl ? vv + left : nv;
+            if (KIND != 1) nv = ghost ? vv : nv;
             if (CHECK) {
                 const double old = ring[t][(j + 4) & 7][lds2];
                 acc += wrote ? fabs(nv - old) : 0.0;
@@ -790,8 +787,13 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
         if (is_compute) {
             const Stencil st_b = classify(g, lane_on ? xl : 0, 1, 1);
             lex_lds_barrier();                                               // (the loader's priming barrier)
-            if (strip_interior) lex_wg_compute<T, CHECK, false>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
-            else lex_wg_compute<T, CHECK, true>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
+            // which borders this wave's columns xs0+2-2t .. xs0+63-2t hold
+            const bool has_x0 = s == 0 && xs0 + 2 - 2 * t <= 0 && xs0 + 63 - 2 * t >= 0;
+            const bool has_xl = xs0 + 63 - 2 * t >= lg.W - 1;            // (column W-1, or nothing on the image at all)
+            if (strip_interior) lex_wg_compute<T, CHECK, 0>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
+            else if (has_x0 && !has_xl) lex_wg_compute<T, CHECK, 1>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
+            else if (!has_x0) lex_wg_compute<T, CHECK, 2>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
+            else lex_wg_compute<T, CHECK, 3>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
         } else if (is_loader) {
             // lanes whose column lies outside the image load a clamped one: no load of the run is conditional,
             // and what they fetch is never used

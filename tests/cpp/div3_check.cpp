@@ -1,7 +1,8 @@
 // Host check of the division-free a/3 that k_lex_wg's border body uses (ccp_grid_lex.hpp, lex_div3): the same
 // three IEEE operations — multiply by RN(1/3), exact residual in an fma, correction in an fma — against the
-// machine's correctly rounded division, on random significands over many binades, on the neighbours of
-// every multiple of 3 near binade edges, on results that are exactly representable and on signed zeros.
+// machine's correctly rounded division, on random significands over EVERY binade (subnormals and the largest
+// finite numbers included), on the neighbours of every multiple of 3 near binade edges, on results that are
+// exactly representable and on signed zeros.  (Infinities and NaNs are the only inputs the kernel divides.)
 // Prints "ok <cases>" or the first mismatch.  Built with -ffp-contract=off.
 #include <cmath>
 #include <cstdint>
@@ -51,7 +52,7 @@ int main(int argc, char **argv)
     };
     for (long i = 0; i < n; ++i) {
         const uint64_t m = next() & ((1ull << 52) - 1);
-        const int e = (int)(next() % 1800) - 900 + 1023;               // exponents -900 .. 899
+        const int e = (int)(next() % 2047);                            // every exponent field: subnormals .. 2^1023
         uint64_t bits = ((uint64_t)(next() & 1) << 63) | ((uint64_t)e << 52) | m;
         double a;
         std::memcpy(&a, &bits, 8);
@@ -69,6 +70,13 @@ int main(int argc, char **argv)
         }
     for (long k = 0; k < 3000000; ++k)                                           // small integers and thirds of them
         if (!check((double)k) || !check((double)k * 0.25) || !check(-(double)k / 7.0)) return 1;
+    for (int e = 0; e < 2047; ++e)                                               // both ends of every binade
+        for (uint64_t m : {0ull, 1ull, 2ull, 3ull, (1ull << 52) - 1, (1ull << 52) - 2, (1ull << 51), (1ull << 51) + 1, 0x5555555555555ull, 0xAAAAAAAAAAAAAull}) {
+            const uint64_t bits = ((uint64_t)e << 52) | m;
+            double a;
+            std::memcpy(&a, &bits, 8);
+            if (!check(a) || !check(-a)) return 1;
+        }
     if (!check(0.0) || !check(-0.0)) return 1;
     std::printf("ok %ld\n", checked);
     return 0;
