@@ -1228,7 +1228,7 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     if (chunk <= 0) chunk = std::min(lg.W, lg.H) <= 1024 ? 8 : 16;
     chunk = std::max(kLexSkewAhead, std::min(chunk, kWave)) / kLexSkewAhead * kLexSkewAhead;   // whole ring turns per chunk
     const bool wg = g->lex_mode == 3 && T >= 2;
-    const size_t need = (size_t)C * groups * S * (wg ? kLexWordStride : 1), edges = (size_t)C * S * edge_steps * 2 * T;
+    const size_t need = (size_t)C * groups * S * (wg ? kLexWordStride : 1), edges = (size_t)C * S * edge_steps * 2 * T + (wg ? (size_t)C * groups * S * kLexScratch : 0);   // (+ the storers' scratch slots)
     if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
     if (wg && (g->lex_order_groups != groups || g->lex_order_strips != S)) {
         // Tickets in wavefront order: strip s of group k starts about (s + rho k) strip-lags after the first one,
@@ -1255,6 +1255,11 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     if constexpr (T >= 2) {
     if (g->lex_mode == 3) {                                  // the T sweeps of a group on the T waves of a workgroup
         static const int pad = getenv("CCP_GS_LEX_PAD_LDS") ? atoi(getenv("CCP_GS_LEX_PAD_LDS")) : 0;   // (occupancy experiments: extra LDS per workgroup)
+        if (getenv("CCP_GS_DEBUG")) {
+            int nb = 0;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lex_wg<T, false>, (T + 2) * kWave, pad);
+            fprintf(stderr, "[ccp_gs] k_lex_wg<%d>: %d workgroups per CU, %d groups x %d strips\n", T, nb, groups, S);
+        }
         if (partial)
             hipLaunchKernelGGL((k_lex_wg<T, true>), grid, dim3((T + 2) * kWave), pad, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,
                                g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, partial, lex_partials_per_sweep(g));
@@ -1338,7 +1343,7 @@ try {
     lg.plane = (long)lg.n_diag * lg.P;
     lg.nbx = (std::min(W, H) + kLexTile - 1) / kLexTile;
     const size_t elems = (size_t)lg.plane * C;
-    const size_t slack = (size_t)64 * lg.P;                  // k_lex_wg prefetches a few diagonals past the last one (never used)
+    const size_t slack = (size_t)kLexSlackRows * lg.P;       // k_lex_wg prefetches some diagonals past the last one (never used)
     if (g->lex_x.n != elems + slack) {
         CCP_TRY(g->lex_x.alloc(elems + slack));
         CCP_TRY(g->lex_b.alloc(elems + slack));

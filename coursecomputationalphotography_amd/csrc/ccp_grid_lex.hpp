@@ -440,6 +440,8 @@ k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGe
 // grid = (G * S, channels), block = (T + 2) * 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
 constexpr int kLexRing = 8;
 constexpr int kLexBRows = 32;
+constexpr int kLexSlackRows = 128;                 // diagonal rows allocated beyond the last one (k_lex_wg prefetches past the image)
+constexpr int kLexScratch = 32;                    // doubles per workgroup the storer of k_lex_wg may write to and nobody reads
 constexpr int kLexWordStride = 32;                 // progress words of k_lex_wg: one per 128-byte line (the word a strip's
                                                    // storer writes is polled by its neighbours' loaders)
 
@@ -475,31 +477,75 @@ __device__ __forceinline__ double lex_div3(double a, bool &finite)
     return r == 0.0 ? q0 : q1;
 }
 
-// Blocks [db0, db1] (steps db0 .. db1+7) of compute wave t, every step in body A (KIND 0) or B (1: the wave holds
-// column 0 — only in strip 0, whose ghost lanes lie off the image; 2: it holds column W-1; 3: both, an image
-// narrower than a strip).  1 <= y <= H-2 for every lane, so the row of a pixel depends on its column alone:
-// column 0 has no left neighbour (diagonal 3), column W-1 only its left one (diagonal 1), a 1-pixel-wide image
-// and the lanes off the image have no row at all — those keep whatever the full-row formula gives, no row of the
-// matrix reads them.  A group moves at the pace of its first strip (every strip waits on its left neighbour),
-// and three of that strip's waves share a SIMD: body B is kept as short as body A allows.
-// ring[t] holds sweep t's INPUT rows (ring[0]: x, filled by the loader), ring[t+1] its results.
-template <int T, bool CHECK, int KIND>
-__device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (*ring)[kLexRing][kWave],
-                                               const double (*brow)[LexWgShape<T>::kRowW], int t, int lane, int db0, int db1,
-                                               bool lane_on, Stencil st_b)
+// One block (8 steps from db) of compute wave t with the general body C: a lane's pixel and row are worked out
+// at every step (classify / gs_update).  Inputs come from the rings like everywhere else.  A rolled loop: it runs
+// for the ~20 blocks at the two ends of a strip only.
+template <int T, bool CHECK>
+__device__ __forceinline__ void lex_wg_general_block(double &h1, double &acc, double &old, double (*ring)[kLexRing][kWave],
+                                                               const double (*brow)[LexWgShape<T>::kRowW], Geom g, int W, int H, int t,
+                                                               int lane, int db, int xp)
 {
     const bool ghost = lane < 2;
-    const int lds1 = max(lane - 1, 0), lds2 = max(lane - 2, 0);
+    const int lds2 = max(lane - 2, 0);
+    const int col = ghost ? LexWgShape<T>::kGhost + 2 * t + lane : lane - 2 - 2 * t + 2 * (T - 1);
+    const int xl = xp - 2 * t;
+    const bool lane_on = !ghost && xl >= 0 && xl < W;
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j) {
+        const int d = db + j, y = d - xp - 2 * t;
+        const double *in = &ring[t][(j + 5) & 7][lds2];
+        const double down = in[0];
+        const double right = in[1];
+        const double vv = brow[(d - 4 * t) & (kLexBRows - 1)][col];
+        const double up = h1;
+        const double left = lane_prev(h1);
+        double nv = ghost ? vv : 0.0;
+        if (lane_on && y >= 0 && y < H) {
+            const Stencil sc = classify(g, xl, y, y);
+            if (sc.diag != 0) {
+                (void)gs_update(sc, vv, up, left, right, down, nv);
+                if (CHECK) acc += fabs(nv - old);
+            }
+        }
+        old = down;
+        ring[t + 1][j][lane] = nv;
+        h1 = nv;
+        lex_lds_barrier();
+    }
+}
+
+// Blocks db0 .. db1 of compute wave t.  A block whose 8 steps have 1 <= y <= H-2 for every real lane of the wave
+// (steps xs0+64+2t .. xs0+2t+H) takes body A (KIND 0) or B (1: the wave holds column 0 — only in strip 0, whose
+// ghost lanes lie off the image; 2: it holds column W-1; 3: both, an image narrower than a strip): the row of a
+// pixel then depends on its column alone — column 0 has no left neighbour (diagonal 3), column W-1 only its
+// left one (diagonal 1), a 1-pixel-wide image and the lanes off the image have no row at all; those keep
+// whatever the full-row formula gives, no row of the matrix reads them.  A group moves at the pace of its first
+// strip (every strip waits on its left neighbour): body B is kept as short as body A allows.  The other blocks
+// take body C.  ring[t] holds sweep t's INPUT rows (ring[0]: x, filled by the loader), ring[t+1] its results.
+template <int T, bool CHECK, int KIND>
+__device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (*ring)[kLexRing][kWave],
+                                               const double (*brow)[LexWgShape<T>::kRowW], Geom g, int W, int H, int t, int lane,
+                                               int db0, int db1, int xs0, bool lane_on, Stencil st_b)
+{
+    const bool ghost = lane < 2;
+    const int lds2 = max(lane - 2, 0);
     const int col = ghost ? LexWgShape<T>::kGhost + 2 * t + lane : lane - 2 - 2 * t + 2 * (T - 1);   // of a b row in LDS
     const bool c_off = !lane_on || st_b.diag == 0;           // (st_b: classify() of this lane's column at an interior y)
     const bool c_x0 = !c_off && !st_b.left, c_xl = !c_off && !st_b.right;
     const bool wrote = KIND == 0 ? !ghost : !c_off;
+    const int in_lo = xs0 + 64 + 2 * t, in_hi = xs0 + 2 * t + H;
+    double old = 0.0;
     for (int db = db0; db <= db1; db += 8) {
+        if (db < in_lo || db + 7 > in_hi) {
+            lex_wg_general_block<T, CHECK>(h1, acc, old, ring, brow, g, W, H, t, lane, db, xs0 + lane);
+            continue;
+        }
         const int sb = (db - 4 * t) & (kLexBRows - 1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const double right = ring[t][(j + 5) & 7][lds1];
-            const double down = ring[t][(j + 5) & 7][lds2];
+            const double *in = &ring[t][(j + 5) & 7][lds2];                  // two adjacent doubles: one ds_read2_b64
+            const double down = in[0];
+            const double right = in[1];
             const double vv = brow[(sb + j) & (kLexBRows - 1)][col];
             const double up = h1;
             const double left = lane_prev(h1);
@@ -516,10 +562,8 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
             }
             if (KIND & 2) nv = c_xl ? vv + left : nv;
             if (KIND != 1) nv = ghost ? vv : nv;
-            if (CHECK) {
-                const double old = ring[t][(j + 4) & 7][lds2];
-                acc += wrote ? fabs(nv - old) : 0.0;
-            }
+            if (CHECK) acc += wrote ? fabs(nv - old) : 0.0;                  // old: this pixel in the previous sweep
+            old = down;                                                      // ... is what was `down` one step (one row) earlier
             ring[t + 1][j][lane] = nv;
             h1 = nv;
             lex_lds_barrier();
@@ -548,53 +592,62 @@ __device__ __forceinline__ void lex_wg_gate(LexWgStrip &st, int db)
     }
 }
 
-// The loader's side of blocks [db0, db1].  pb: this lane's column of b row db0+1 (pb1: the columns past 64),
-// px: this lane's column of x row db0 (columns xs0+2 ..., as sweep 0's lanes 2.. read them one and two places to
-// their left), pg: lanes 0 .. 16T-1: the left strip's edge value of sweep lane/16, step db0 + (lane%16)/2, edge
-// lane%2 (a second load covers sweeps 4..7: 8 doubles further on).  Every slot of the register rings is refilled only after its old contents have been used (a load
-// issued while the old value is live lands in another register and costs a copy and a full drain at the
-// loop's back edge).
+// The loader's side of blocks db0 .. db1 (the whole strip).  Rows and columns outside the arrays are clamped:
+// what such a load fetches is never used, and no load is conditional.  Every slot of the register rings is
+// refilled only after its old contents have been used (a load issued while the old value is live lands in
+// another register and costs a copy and a full drain at the loop's back edge).
+//   bp, xq     b and x of this channel (diagonal-major: element (row r, column c) at r*P + c)
+//   cb         the leftmost image column any sweep of the strip touches (b row in LDS: column c - cb)
 template <int T>
 __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexRing][kWave], double (*brow)[LexWgShape<T>::kRowW], int lane,
-                                            int db0, int db1, const double *pb, const double *pb1, const double *px, const double *pg,
-                                            bool ghost_live, long P)
+                                            int db0, int db1, const double *bp, const double *xq, long P, int n_diag, int W, int cb, int xs0,
+                                            const double *e_left, int left_begin, int left_end)
 {
     constexpr int kCols = LexWgShape<T>::kCols, kGhost = LexWgShape<T>::kGhost;
     constexpr int kGhostOps = (16 * T + kWave - 1) / kWave;                  // 64-lane loads per ghost batch
-    // where lane's ghost value(s) of a block go: sweep gt, step gk/2, edge gk%2 -> row (d - 4 gt), column kGhost + 2 gt + e
-    int g_t[kGhostOps], g_step[kGhostOps], g_col[kGhostOps];
+    const int c_b0 = min(max(cb + lane, 0), W - 1);
+    const int c_b1 = min(max(cb + kWave + min(lane, max(kCols - kWave - 1, 0)), 0), W - 1);
+    const int c_x = min(max(xs0 + 2 + min(lane, kWave - 2), 0), W - 1);   // as sweep 0's lanes 2.. read x: one and two places to their left
+    auto b_row = [&](int r) { return bp + (long)min(max(r, 0), n_diag - 1) * P; };
+    auto x_row = [&](int r) { return xq + (long)min(max(r, 0), n_diag - 1) * P; };
+    // lane's ghost value(s) of a block: sweep g_t, step g_k, edge g_e -> b row (d - 4 g_t), column kGhost + 2 g_t + g_e
+    int g_t[kGhostOps], g_k[kGhostOps], g_col[kGhostOps];
     bool g_on[kGhostOps];
 #pragma unroll
     for (int q = 0; q < kGhostOps; ++q) {
         const int idx = q * kWave + lane;
         g_on[q] = idx < 16 * T;
         g_t[q] = min(idx >> 4, T - 1);
-        g_step[q] = (idx & 15) >> 1;
+        g_k[q] = (idx & 15) >> 1;
         g_col[q] = kGhost + 2 * g_t[q] + (idx & 1);
     }
+    // the left strip's edge value for step blk + g_k (raw: whether that step exists is ghost_valid, applied where
+    // the value is used — a select right behind the load would wait for it, and for every prefetch before it)
+    auto ghost_load = [&](int blk, int q) -> double {
+        if (e_left == nullptr) return 0.0;
+        const int d = blk + g_k[q];
+        return lex_ld(e_left + ((long)(min(max(d, left_begin), left_end) - left_begin) * T + g_t[q]) * 2 + (g_col[q] & 1));
+    };
+    auto ghost_valid = [&](int blk, int q) { const int d = blk + g_k[q]; return e_left != nullptr && d >= left_begin && d <= left_end; };
     lex_wg_gate(st, db0);
-    {   // what the first steps of the run read before the rings are rolling: x rows db0, db0+1, db0+2 and the
-        // ghost values of block db0
+    {   // what the first steps read before the rings are rolling: x rows db0, db0+1, db0+2 and the ghost values of
+        // block db0 (the b rows up to db0: by all waves, in the kernel)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) ring[0][(db0 + q - 4) & 7][lane] = lex_ld(px + (long)q * P);
+        for (int q = 0; q < 3; ++q) ring[0][(db0 + q - 4) & 7][lane] = lex_ld(x_row(db0 + q) + c_x);
 #pragma unroll
         for (int q = 0; q < kGhostOps; ++q) {
-            const double v = ghost_live ? lex_ld(pg + 8 * q) : 0.0;
-            if (g_on[q]) brow[(db0 + g_step[q] - 4 * g_t[q]) & (kLexBRows - 1)][g_col[q]] = v;
+            const double v = ghost_load(db0, q);
+            if (g_on[q]) brow[(db0 + g_k[q] - 4 * g_t[q]) & (kLexBRows - 1)][g_col[q]] = ghost_valid(db0, q) ? v : 0.0;
         }
     }
-    px += 3 * P;
-    pg += 16 * T;
     double qb[8], qb1[8], qx[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        qb[j] = lex_ld(pb);                                                  // b row db0 + 1 + j
-        qb1[j] = kCols > kWave ? lex_ld(pb1) : 0.0;
-        qx[j] = lex_ld(px);                                                  // x row db0 + 3 + j
-        pb += P;
-        pb1 += P;
-        px += P;
+        qb[j] = b_row(db0 + 1 + j)[c_b0];
+        qb1[j] = kCols > kWave ? b_row(db0 + 1 + j)[c_b1] : 0.0;
+        qx[j] = lex_ld(x_row(db0 + 3 + j) + c_x);
     }
+    const double *pb = bp + (long)(db0 + 9) * P + c_b0, *pb1 = bp + (long)(db0 + 9) * P + c_b1, *px = xq + (long)(db0 + 11) * P + c_x;
     lex_lds_barrier();                                                       // (every wave of the workgroup comes here)
     for (int db = db0; db <= db1; db += 8) {
         if (db > db0) lex_wg_gate(st, db);
@@ -603,8 +656,10 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
         const unsigned polled = __hip_atomic_load(st.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double qg[kGhostOps];
 #pragma unroll
-        for (int q = 0; q < kGhostOps; ++q) qg[q] = ghost_live ? lex_ld(pg + 8 * q) : 0.0;       // block db + 8
-        pg += 16 * T;
+        for (int q = 0; q < kGhostOps; ++q) qg[q] = ghost_load(db + 8, q);
+        // The rows fetched from here on exist: b row d+9 >= 1 (the strip's first block starts at -8 or later), and
+        // the arrays carry kLexSlackRows rows beyond the last diagonal for the prefetches that run past the image
+        // at the end of the rightmost strips (never used).  Running pointers, nothing to clamp.
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = (db + j + 1) & (kLexBRows - 1);
@@ -614,11 +669,11 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
             if (j == 7) {
 #pragma unroll
                 for (int q = 0; q < kGhostOps; ++q)
-                    if (g_on[q]) brow[(db + 8 + g_step[q] - 4 * g_t[q]) & (kLexBRows - 1)][g_col[q]] = qg[q];
+                    if (g_on[q]) brow[(db + 8 + g_k[q] - 4 * g_t[q]) & (kLexBRows - 1)][g_col[q]] = ghost_valid(db + 8, q) ? qg[q] : 0.0;
             }
             asm volatile("" ::: "memory");
-            qb[j] = lex_ld(pb);                                              // b row d + 9
-            if (kCols > kWave) qb1[j] = lex_ld(pb1);
+            qb[j] = lex_ld(pb);                                              // b row d + 9 (sc1 as well: streamed once, and a
+            if (kCols > kWave) qb1[j] = lex_ld(pb1);                         // plain load was measured slower here)
             qx[j] = lex_ld(px);                                              // x row d + 11
             pb += P;
             pb1 += P;
@@ -629,33 +684,58 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
     }
 }
 
-// The storer's side of blocks [db0, db1]: after the barrier of step d, sweep T-1's row of that step goes to x
-// and the 2T edge values of the step to the edge buffer.  ps: this lane's pixel of sweep T-1 at step db0,
-// pe: lanes 0..2T-1: this strip's edge slot (step db0, sweep lane/2, edge lane%2).
-template <int T, bool BORDER>
-__device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLexRing][kWave], int lane, int db0, int db1, double *ps,
-                                             double *pe, long P, bool wrote)
+// The storer's side of blocks db0 .. db1: after the barrier of step d, sweep T-1's row of that step goes to x
+// (the pixels that have a row) and the 2T edge values of the step to the edge buffer.
+template <int T>
+__device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLexRing][kWave], Geom g, int W, int H, int lane, int db0, int db1,
+                                             double *xq, long P, int xs0, int d_begin, int d_end, double *e_mine, double *scratch,
+                                             bool strip_interior, Stencil st_b)
 {
+    constexpr int t = T - 1;
+    const int xp = xs0 + lane, xl = xp - 2 * t;
+    const bool ghost = lane < 2;
+    const bool lane_on = !ghost && xl >= 0 && xl < W;
+    const int in_lo = xs0 + 64 + 2 * t, in_hi = xs0 + 2 * t + H;
     const int e_t = min(lane >> 1, T - 1) + 1, e_lane = kWave - 2 + (lane & 1);
     lex_lds_barrier();                                                       // (the loader's priming barrier)
     for (int db = db0; db <= db1; db += 8) {
+        // Exactly two stores per step, whatever the masks say (lane 0 and the edge lanes fall back to scratch slots
+        // of this workgroup's own): the publication below counts on it.
+        if (db >= in_lo && db + 7 <= in_hi) {
+            // every real lane has 1 <= y <= H-2: which pixels have a row does not change from step to step.  In an
+            // interior strip the ghost lanes store too: they carry the left strip's results of the same sweep for
+            // exactly these pixels, so it is the value already there.
+            const bool wrote = strip_interior || (lane_on && st_b.diag != 0);
+            double *px = xq + (long)(db - 4 * t) * P + xl;
+            double *pe = e_mine + ((long)(db - d_begin) * T) * 2 + lane;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            lex_lds_barrier();                                               // step d is in the rings
-            const double v = ring[T][j][lane];
-            const double ev = ring[e_t][j][e_lane];
-            // body A stores from the ghost lanes too: they carry the left strip's results of the same sweep for
-            // exactly these pixels, so it is the value already there
-            if (!BORDER || wrote) lex_st(ps, v);
-            if (lane < 2 * T) lex_st(pe, ev);
-            ps += P;
-            pe += 2 * T;
+            for (int j = 0; j < 8; ++j) {
+                lex_lds_barrier();                                           // step d is in the rings
+                const double v = ring[T][j][lane];
+                const double ev = ring[e_t][j][e_lane];
+                if (strip_interior) lex_st(px, v);
+                else if (wrote || lane == 0) lex_st(wrote ? px : scratch + j, v);
+                if (lane < 2 * T) lex_st(pe, ev);
+                px += P;
+                pe += 2 * T;
+            }
+        } else {
+#pragma unroll 1
+            for (int j = 0; j < 8; ++j) {
+                const int d = db + j, y = d - xp - 2 * t;
+                lex_lds_barrier();
+                const double v = ring[T][j][lane];
+                const double ev = ring[e_t][j][e_lane];
+                const bool wrote = lane_on && y >= 0 && y < H && classify(g, xl, y, y).diag != 0;
+                if (wrote || lane == 0) lex_st(wrote ? xq + (long)(d - 4 * t) * P + xl : scratch + j, v);
+                if (lane < 2 * T) lex_st((d >= d_begin && d <= d_end) ? e_mine + ((long)(d - d_begin) * T) * 2 + lane : scratch + 8 + lane, ev);
+            }
         }
-        // Stores complete in issue order: once at most the 48 youngest are outstanding (16 per block and a
-        // publication: this block, the one before, most of a third), every store of the blocks before those
-        // has been acknowledged — publish their steps, without draining.
+        // Stores complete in issue order, and a block issues 17 of them (16 + this publication): once at most the 48
+        // youngest are outstanding — this block's, the one before and most of a third — every store of the blocks
+        // before those has been acknowledged.  Publish their steps, without draining.
         asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-        if (lane == 0 && db - 16 > db0) __hip_atomic_store(st.mine, (unsigned)(db - 16), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_store(st.mine, (unsigned)max(db - 16, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -667,7 +747,7 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
 {
     static_assert(kLexRing == 8 && T >= 2, "the unrolled step index is the ring slot");
     static_assert(4 * (T - 1) + 4 <= kLexBRows, "a b row stays in LDS from step r-1 to step r+4(T-1)");
-    constexpr int kCols = LexWgShape<T>::kCols, kRowW = LexWgShape<T>::kRowW;
+    constexpr int kRowW = LexWgShape<T>::kRowW;
     __shared__ double ring[T + 1][kLexRing][kWave];
     __shared__ double brow[kLexBRows][kRowW];
     __shared__ unsigned s_ticket;
@@ -675,31 +755,26 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
     if (!((active_mask >> ch) & 1u)) return;
     const int lane = threadIdx.x & (kWave - 1);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));     // 0..T-1: sweeps, T: loader, T+1: storer
-    const bool is_compute = wv < T, is_loader = wv == T, is_storer = wv == T + 1;
-    const int t = min(wv, T - 1);                            // (the storer works on sweep T-1's geometry)
+    const int t = min(wv, T - 1);
     if (threadIdx.x == 0) s_ticket = atomicAdd(&ticket[ch], 1u);
     if (wv <= T) {
 #pragma unroll
         for (int q = 0; q < kLexRing; ++q) ring[wv][q][lane] = 0.0;
     }
+    for (int i = threadIdx.x; i < kLexBRows * kRowW; i += (T + 2) * kWave) (&brow[0][0])[i] = 0.0;
     __syncthreads();
     const unsigned tk = order[s_ticket];                     // (group, strip) in wavefront order
     const int grp = (int)(tk / (unsigned)S), s = (int)(tk % (unsigned)S);
     const int HS = lg.H + 2 * (T - 1);
     const int xs0 = kLexSkewCols * s - 2;
-    const int xp = xs0 + lane;
-    const int xl = xp - 2 * t;                               // this lane's image column
-    const bool ghost = lane < 2;
+    const int xl = xs0 + lane - 2 * t;                       // this lane's image column
+    const bool lane_on = lane >= 2 && xl >= 0 && xl < lg.W;
     const int d_begin = xs0, d_end = xs0 + (kWave - 1) + HS - 1;
-    const int d_base = d_begin & ~7;                         // (floor to a multiple of 8, also when negative)
+    const int db0 = d_begin & ~7, db1 = d_end & ~7;          // first and last block (floor to a multiple of 8, also when negative)
     const long plane = (long)ch * lg.plane;
     double *e_mine = edges + ((long)ch * S + s) * edge_steps * (2 * T);
     const double *e_left = s > 0 ? edges + ((long)ch * S + s - 1) * edge_steps * (2 * T) : nullptr;
     const int left_begin = xs0 - kLexSkewCols, left_end = left_begin + (kWave - 1) + HS - 1;
-    const bool lane_on = !ghost && xl >= 0 && xl < lg.W;
-    const bool ok_dn = xp >= 0 && xp < lg.W, ok_rt = xp + 1 >= 0 && xp + 1 < lg.W;
-    const bool ghost_live = ghost && e_left != nullptr;
-    const int lds1 = max(lane - 1, 0), lds2 = max(lane - 2, 0);
     const int cb = xs0 + 2 - 2 * (T - 1);                    // the leftmost image column any sweep of the strip touches
 
     // One progress word per strip, written by the storer.  The loader watches: lane 0 the left strip (edge
@@ -718,109 +793,47 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
         st.need_off = 19 + 4 * (T - 1);                      // x row db+18, written by sweep T-1 at step db+18+4(T-1)
     }
 
-    // blocks in which every real lane of every sweep has 1 <= y <= H-2 at every step (sweep t: steps
-    // xs0+64+2t .. xs0+2t+H), the same blocks for all waves
-    const int run0 = (max(xs0 + 64 + 2 * (T - 1), d_begin) + 7) & ~7;
-    const int run1 = (min(xs0 + lg.H, d_end) - 7) & ~7;                      // last block of the run (< run0: none)
+    {   // b rows db0 - 4(T-1) .. db0 into the ring, a few per wave: sweep t reads row d - 4t at step d (the loader
+        // brings row d + 1 at step d)
+        constexpr int kCols = LexWgShape<T>::kCols, kPrime = 4 * (T - 1) + 1, kPer = (kPrime + T + 1) / (T + 2);
+        const int c0 = min(max(cb + lane, 0), lg.W - 1), c1 = min(max(cb + kWave + min(lane, max(kCols - kWave - 1, 0)), 0), lg.W - 1);
+#pragma unroll
+        for (int q = 0; q < kPer; ++q) {
+            const int r = db0 - (kPrime - 1) + wv * kPer + q;
+            if (r <= db0) {                                              // (uniform)
+                const double *row = bd + plane + (long)min(max(r, 0), lg.n_diag - 1) * lg.P;
+                brow[r & (kLexBRows - 1)][lane] = row[c0];
+                if (kCols > kWave && lane < kCols - kWave) brow[r & (kLexBRows - 1)][kWave + lane] = row[c1];
+            }
+        }
+    }
     const bool strip_interior = s > 0 && xs0 + 2 - 2 * t >= 1 && xs0 + 63 - 2 * t <= lg.W - 2;
-    double h1 = 0.0, acc = 0.0;
-
-    auto general_block = [&](int db) {                                       // C: one step at a time, nothing in flight
-        if (is_loader) lex_wg_gate(st, db);
-        lex_lds_barrier();
-#pragma unroll 1
-        for (int d = db; d < db + 8; ++d) {
-            if (d < d_begin || d > d_end) continue;                          // (uniform over the workgroup)
-            if (is_loader) {                                                 // b row d + 1 into the ring
-                const int r = d + 1;
-                const bool r_ok = r >= 0 && r < lg.n_diag;
-                const int c0 = cb + lane, c1 = cb + kWave + lane;
-                brow[r & (kLexBRows - 1)][lane] = (r_ok && c0 >= 0 && c0 < lg.W) ? bd[plane + (long)r * lg.P + c0] : 0.0;
-                if (kCols > kWave && lane < kCols - kWave)
-                    brow[r & (kLexBRows - 1)][kWave + lane] = (r_ok && c1 >= 0 && c1 < lg.W) ? bd[plane + (long)r * lg.P + c1] : 0.0;
-            }
-            if (is_compute) {
-                const int yp = d - xp, y = yp - 2 * t;
-                double right = 0.0, down = 0.0, old = 0.0, vv = 0.0;
-                if (t == 0) {                                 // sweep 0's inputs from x (the previous group's result)
-                    if (ok_dn && yp + 1 >= 0 && yp + 1 < lg.H) down = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp]);
-                    if (ok_rt && yp >= 0 && yp < lg.H) right = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp + 1]);
-                    if (CHECK && ok_dn && yp >= 0 && yp < lg.H) old = lex_ld(&xd[plane + (long)d * lg.P + xp]);
-                } else {
-                    right = ring[t][(d - 3) & 7][lds1];
-                    down = ring[t][(d - 3) & 7][lds2];
-                    if (CHECK) old = ring[t][(d - 4) & 7][lds2];
-                }
-                const bool on = lane_on && y >= 0 && y < lg.H;
-                if (ghost) {
-                    if (ghost_live && d >= left_begin && d <= left_end) vv = lex_ld(&e_left[((long)(d - left_begin) * T + t) * 2 + lane]);
-                } else if (on) {
-                    vv = bd[plane + (long)(xl + y) * lg.P + xl];
-                }
-                const double up = h1;
-                const double left = lane_prev(h1);
-                double nv = ghost ? vv : 0.0;
-                if (on) {
-                    const Stencil sc = classify(g, xl, y, y);
-                    if (sc.diag != 0) {
-                        (void)gs_update(sc, vv, up, left, right, down, nv);
-                        if (CHECK) acc += fabs(nv - old);
-                        if (t == T - 1) lex_st(&xd[plane + (long)(xl + y) * lg.P + xl], nv);
-                    }
-                }
-                ring[t + 1][d & 7][lane] = nv;
-                if (lane >= kWave - 2) lex_st(&e_mine[((long)(d - d_begin) * T + t) * 2 + (lane - (kWave - 2))], nv);
-                h1 = nv;
-            }
-            lex_lds_barrier();
+    const Stencil st_b = classify(g, lane_on ? xl : 0, 1, 1);                // (meaningful where H >= 3: inner blocks only)
+    if (wv < T) {
+        double h1 = 0.0, acc = 0.0;
+        // which borders this wave's columns xs0+2-2t .. xs0+63-2t hold
+        const bool has_x0 = s == 0 && xs0 + 2 - 2 * t <= 0 && xs0 + 63 - 2 * t >= 0;
+        const bool has_xl = xs0 + 63 - 2 * t >= lg.W - 1;                // (column W-1, or nothing on the image at all)
+        lex_lds_barrier();                                                   // (the loader's priming barrier)
+        if (strip_interior) lex_wg_compute<T, CHECK, 0>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
+        else if (has_x0 && !has_xl) lex_wg_compute<T, CHECK, 1>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
+        else if (!has_x0) lex_wg_compute<T, CHECK, 2>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
+        else lex_wg_compute<T, CHECK, 3>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
+        if (CHECK) {
+            const double total = wave_sum(acc);
+            if (lane == 0) partial[(((long)grp * T + t) * gridDim.y + ch) * partial_stride + s] = total;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // compiler ordering only
-        __builtin_amdgcn_s_waitcnt(0);                                       // this wave's (write-through) stores acknowledged
-        lex_lds_barrier();                                                   // ... and every other wave's
-        if (is_storer && lane == 0 && db + 7 < d_end)
-            __hip_atomic_store(st.mine, (unsigned)max(db + 8, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    };
-
-    int db = d_base;
-    for (; db <= d_end && (db < run0 || run1 < run0); db += 8) general_block(db);
-    if (run1 >= run0) {
-        if (is_compute) {
-            const Stencil st_b = classify(g, lane_on ? xl : 0, 1, 1);
-            lex_lds_barrier();                                               // (the loader's priming barrier)
-            // which borders this wave's columns xs0+2-2t .. xs0+63-2t hold
-            const bool has_x0 = s == 0 && xs0 + 2 - 2 * t <= 0 && xs0 + 63 - 2 * t >= 0;
-            const bool has_xl = xs0 + 63 - 2 * t >= lg.W - 1;            // (column W-1, or nothing on the image at all)
-            if (strip_interior) lex_wg_compute<T, CHECK, 0>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
-            else if (has_x0 && !has_xl) lex_wg_compute<T, CHECK, 1>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
-            else if (!has_x0) lex_wg_compute<T, CHECK, 2>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
-            else lex_wg_compute<T, CHECK, 3>(h1, acc, ring, brow, t, lane, run0, run1, lane_on, st_b);
-        } else if (is_loader) {
-            // lanes whose column lies outside the image load a clamped one: no load of the run is conditional,
-            // and what they fetch is never used
-            const double *pb = bd + plane + (long)(run0 + 1) * lg.P + min(max(cb + lane, 0), lg.W - 1);
-            const double *pb1 = bd + plane + (long)(run0 + 1) * lg.P + min(max(cb + kWave + min(lane, max(kCols - kWave - 1, 0)), 0), lg.W - 1);
-            const double *px = xd + plane + (long)run0 * lg.P + min(max(xs0 + 2 + min(lane, kWave - 2), 0), lg.W - 1);
-            const int gi = min(lane, 16 * T - 1);            // (second 64 lanes of the batch: + 64 doubles)
-            const double *pg = s > 0 ? e_left + ((long)(run0 - left_begin + ((gi & 15) >> 1)) * T + (gi >> 4)) * 2 + (gi & 1) : e_mine;
-            lex_wg_load<T>(st, ring, brow, lane, run0, run1, pb, pb1, px, pg, s > 0, lg.P);
-        } else {
-            const Stencil st_b = classify(g, lane_on ? xl : 0, 1, 1);
-            double *ps = xd + plane + (long)(run0 - 4 * t) * lg.P + xl;
-            double *pe = e_mine + ((long)(run0 - d_begin) * T) * 2 + min(lane, 2 * T - 1);
-            const bool wrote = lane_on && st_b.diag != 0;
-            if (strip_interior) lex_wg_store<T, false>(st, ring, lane, run0, run1, ps, pe, lg.P, wrote);
-            else lex_wg_store<T, true>(st, ring, lane, run0, run1, ps, pe, lg.P, wrote);
-        }
-        for (db = run1 + 8; db <= d_end; db += 8) general_block(db);
+    } else if (wv == T) {
+        lex_wg_load<T>(st, ring, brow, lane, db0, db1, bd + plane, xd + plane, lg.P, lg.n_diag, lg.W, cb, xs0, e_left, left_begin, left_end);
+    } else {
+        // (scratch: kLexScratch doubles per workgroup behind the edge values of all strips)
+        double *scratch = edges + (long)gridDim.y * S * edge_steps * (2 * T) + (((long)ch * G + grp) * S + s) * kLexScratch;
+        lex_wg_store<T>(st, ring, g, lg.W, lg.H, lane, db0, db1, xd + plane, lg.P, xs0, d_begin, d_end, e_mine, scratch, strip_interior, st_b);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                   // compiler ordering only
-    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_s_waitcnt(0);                                           // this wave's (write-through) stores acknowledged
     lex_lds_barrier();
-    if (is_storer && lane == 0) __hip_atomic_store(st.mine, kLexDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (CHECK && is_compute) {
-        const double total = wave_sum(acc);
-        if (lane == 0) partial[(((long)grp * T + t) * gridDim.y + ch) * partial_stride + s] = total;
-    }
+    if (wv == T + 1 && lane == 0) __hip_atomic_store(st.mine, kLexDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // eps[k*channels + ch] = sum of the partials of iteration k in a fixed order.  grid = (iterations, channels)
