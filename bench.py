@@ -199,6 +199,10 @@ def parity_against_in_place(g, W, H, iters):
             "rel_residual": float(np.sqrt(rr1 / bb1).max())}
 
 
+# k_lex_wg at 8 sweeps per pass: b row of 76 columns per 62 pixels, x row of 63, x write, edge values both ways
+LEX_WG_BYTES_PER_UPDATE = (76.0 / 62.0 * 8.0 + 63.0 / 62.0 * 8.0 + 8.0) / 8.0 + 2.0 * 16.0 / 62.0
+
+
 def config0(capi):
     """BASELINE configs[0]: 512x512 single channel, the reference's lexicographic order (plumbing case)."""
     import numpy as np
@@ -220,11 +224,14 @@ def config0(capi):
     want, _, _ = oracle.Oracle().from_csr(v, c, r).gauss_seidel(b, 0.0, iters)
     ups = W * H * iters / rep.seconds
     return {"workload": "512x512 single-channel Poisson, lexicographic Gauss-Seidel (reference order), 100 iterations",
-            "kernel": "k_lex_strips (strip waves marching down the hyperplanes x + y + 2k, all sweeps in one launch)", "ms": rep.seconds * 1e3,
+            "kernel": "k_lex_wg (time-skewed strips: 8 sweeps per pass on the 8 compute waves of a workgroup, a loader and a "
+                      "storer wave, all passes in one launch per pass depth)", "ms": rep.seconds * 1e3,
             "pixel_updates_per_s": ups,
-            "bytes_model": "32 B per update (two neighbour diagonals 16 + b 8 + x write 8)",
-            "frac": ups * 32.0 / 1e9 / HBM_PEAK_GBS,
-            "bound_note": "latency bound at this size: 8 strips x 100 sweeps = 800 waves on a critical path of W+H+(chunk+2)K dependent steps",
+            "bytes_model": f"{LEX_WG_BYTES_PER_UPDATE:.2f} B per update at 8 sweeps per pass (b 76/62 x 8/8, x read 63/62 x 8/8, x write "
+                           "8/8, edge values 2 x 16/62); PMC on 16384^2: 4.33 B (profiles/r02_pmc_*_lex_wg_16384.csv)",
+            "frac": ups * LEX_WG_BYTES_PER_UPDATE / 1e9 / HBM_PEAK_GBS,
+            "bound_note": "not a bandwidth-bound kernel: lock-step steps of ~0.2 us (LDS round trip + barrier, tools/step_bench.hip); at "
+                          "this size 10 strips x 12 passes on a critical path of ~(H + 64 + 60 strips) steps per pass",
             "bit_identical_to_oracle": bool(np.array_equal(x, want)),
             "cpu_baseline": {"value": W * H * iters / secs, "unit": "pixel-updates/s", "cores": 1, "kind": kind,
                              "sample": f"the same system and iteration count, {secs:.3f} s"}}
@@ -447,7 +454,7 @@ def main():
         rep = g.gauss_seidel_lexicographic(0.0, args.reference_order_iters, 0)[0]
         extra["reference_order"] = {
             "what": "lexicographic Gauss-Seidel (the reference's index-order sweep, sparse-matrix.h:357-370), "
-                    "strip waves over the hyperplanes x + y + 2k, one launch; iterates bit-identical to the reference's",
+                    "time-skewed strips, 8 sweeps per pass (k_lex_wg); iterates bit-identical to the reference's",
             "iterations": rep.iterations, "seconds": rep.seconds,
             "pixel_updates_per_s": float(W) * H * C * rep.iterations / rep.seconds,
             "rel_residual_after": float(solver.rel_residual().max())}

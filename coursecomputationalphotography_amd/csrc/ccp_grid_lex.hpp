@@ -6,9 +6,12 @@
 // hyperplane tau - 1:  (x,y-1,k) and (x-1,y,k) trivially, (x+1,y,k-1) and (x,y+1,k-1) because
 // x+y+1 + 2(k-1) = tau - 1.  All points of one hyperplane are therefore independent, any order that
 // walks tau upwards reproduces the sequential sweep exactly, and one hyperplane holds pixels of many
-// iterations at once — the pipeline never drains between sweeps.  One launch per tau updates, in
-// place, anti-diagonal d = tau - 2k of every iteration k in flight (the launch writes diagonals of
-// one parity and reads the other, so there is no hazard inside a launch).
+// iterations at once — the pipeline never drains between sweeps.  Four engines walk it (ccp_grid.hip,
+// CCP_GS_LEX_MODE):  k_lex_plane, one launch per tau, anti-diagonal d = tau - 2k of every iteration k in
+// flight (a launch writes diagonals of one parity and reads the other: no hazard inside a launch);
+// k_lex_strips, one launch, a wave per (sweep, strip of 64 columns) with neighbour-only progress words;
+// k_lex_skew, T sweeps per pass in one wave after the skew x' = x + 2t, y' = y + 2t; and k_lex_wg, the
+// default: the same skew with the T sweeps on the T waves of a workgroup, rows exchanged through LDS.
 //
 // Layout: "diagonal-major" — diagonal d = x + y is row d of a (W+H-1) x P array, pixel at column x:
 //   (x,y-1) -> [d-1][x]   (x-1,y) -> [d-1][x-1]   (x+1,y) -> [d+1][x+1]   (x,y+1) -> [d+1][x]
@@ -435,8 +438,8 @@ k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGe
 //   B  every real lane has 1 <= y <= H-2 but the strip touches the left / right image border: the row of a
 //      lane depends on its column alone and is classified once (the first and last strips must keep pace with
 //      the rest — every strip waits on its left neighbour);
-//   C  anything else (the first and last ~80 steps of a strip): the general body of k_lex_skew, one step at a
-//      time, every compute wave doing its own loads and stores.
+//   C  anything else (the first and last ~10 blocks of a strip): classify / gs_update at every step.
+// All three read their inputs from the rings: no wave but the loader loads, no wave but the storer stores.
 // grid = (G * S, channels), block = (T + 2) * 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
 constexpr int kLexRing = 8;
 constexpr int kLexBRows = 32;
