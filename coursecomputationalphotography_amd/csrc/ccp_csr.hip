@@ -111,7 +111,9 @@ struct ccp_csr {
     // Dirichlet values around it (diagonal 4, -1 to every 4-neighbour inside) — BASELINE configs[4].  Then a
     // Dirichlet-mask grid on a canvas the region is embedded in sweeps it matrix-free; `where` maps unknown i
     // to its element of the canvas planes.
-    int region_state = -1;                 // -1 unknown, 0 no, 1 yes
+    int region_state = -1;                 // -1 unknown, 0 no, 1 yes, 2 yes for the reference's order only (the canvas' parity
+                                           //    is a 2-colouring of the region, but not the colouring the colour-ordered sweep uses)
+    bool region_wants_two_colouring = false;   // state 0 only because the resolved colouring has more than two colours
     ccp_grid *region_grid = nullptr;
     DevBuf<long> region_where;
     std::vector<int> region_colour;        // (x + y) & 1 of the embedding: the colouring the grid sweep realises
@@ -706,10 +708,14 @@ bool embed_region(const ccp_csr *m, const std::vector<int> &colour, RegionEmbedd
 int resolve_colouring(ccp_csr *m, std::vector<int> &colour, int &nc);
 
 // Recognise (once per upload) and set up the Dirichlet-mask twin.
-int detect_region(ccp_csr *m)
+bool bipartite_colouring(ccp_csr *m, std::vector<int> &colour);
+
+int detect_region(ccp_csr *m, bool for_reference_order = false)
 {
-    if (m->region_state >= 0) return CCP_OK;
+    if (m->region_state >= 1) return CCP_OK;
+    if (m->region_state == 0 && !(for_reference_order && m->region_wants_two_colouring)) return CCP_OK;
     m->region_state = 0;
+    m->region_wants_two_colouring = false;
     if (!m->allow_region || m->n_rows < 4 || m->n_rows != m->n_cols || !m->overlay.empty()) return CCP_OK;
     const double t0 = now_s();
     // cheap screen before anything O(nnz): row 0 must look like a region row
@@ -721,7 +727,16 @@ int detect_region(ccp_csr *m)
     std::vector<int> colour;
     int nc = 0;
     CCP_TRY(resolve_colouring(m, colour, nc));
-    if (nc != 2) return CCP_OK;
+    bool order_only = false;
+    if (nc != 2) {
+        // No colouring was given and the greedy one needs a third colour somewhere.  The colour-ordered sweep then
+        // runs with that colouring, on the stored matrix.  The index-order sweep does not care about colours: any
+        // 2-colouring of the (bipartite) pixel graph gives the canvas its parity.
+        m->region_wants_two_colouring = true;
+        if (!for_reference_order || !bipartite_colouring(m, colour)) return CCP_OK;
+        m->region_wants_two_colouring = false;
+        order_only = true;
+    }
     RegionEmbedding E;
     if (!embed_region(m, colour, E)) {
         if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] not a raster-region Laplacian (%.3f s)\n", now_s() - t0);
@@ -750,7 +765,7 @@ int detect_region(ccp_csr *m)
     m->region_colour.swap(colour);
     m->region_w = E.W;
     m->region_h = E.H;
-    m->region_state = 1;
+    m->region_state = order_only ? 2 : 1;
     if (getenv("CCP_GS_DEBUG"))
         fprintf(stderr, "[ccp_gs] raster-region Laplacian: %ld unknowns on a %d x %d canvas (%.0f %% filled), recognised in %.3f s\n", n,
                 E.W, E.H, 100.0 * n / ((double)E.W * E.H), now_s() - t0);
@@ -807,6 +822,36 @@ int resolve_colouring(ccp_csr *m, std::vector<int> &colour, int &nc)
     }
     if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] colouring (%d colours) in %.3f s\n", nc, now_s() - t0);
     return CCP_OK;
+}
+
+// A proper 2-colouring of the rows by breadth-first search over the stored couplings (false: an odd cycle, or a
+// coupling stored in one direction only reaches a row the other way round with the wrong colour).
+bool bipartite_colouring(ccp_csr *m, std::vector<int> &colour)
+{
+    const int n = m->n_rows;
+    colour.assign((size_t)n, -1);
+    std::vector<int> queue;
+    queue.reserve((size_t)n);
+    for (int root = 0; root < n; ++root) {
+        if (colour[root] >= 0) continue;
+        colour[root] = 0;
+        queue.clear();
+        queue.push_back(root);
+        for (size_t head = 0; head < queue.size(); ++head) {
+            const int i = queue[head];
+            for (long k = m->row_ptr[i]; k < m->row_ptr[i + 1]; ++k) {
+                const int c = m->col[k];
+                if (c == i || c < 0 || c >= n) continue;
+                if (colour[c] < 0) {
+                    colour[c] = colour[i] ^ 1;
+                    queue.push_back(c);
+                } else if (colour[c] == colour[i]) {
+                    return false;
+                }
+            }
+        }
+    }
+    return true;
 }
 
 int ensure_multicolour(ccp_csr *m)
@@ -1244,13 +1289,16 @@ try {
             return ccp_grid_get_x_host(m->grid, 0, x_out, 0, m->poisson_h);
         }
     }
-    if (ordering == CCP_ORDER_MULTICOLOUR && m->allow_structured && m->allow_region) {
+    if (m->allow_structured && m->allow_region) {
         // The 5-point Laplacian of a raster region (a brush / label region of a blend; BASELINE configs[4]):
         // swept matrix-free by the Dirichlet-mask grid kernels on a canvas the region is embedded in —
         // 24 B per pixel per PASS of several iterations instead of 92 B per row per iteration.  Same colour
         // order, same arithmetic, same bits as the sliced-ELL sweep (the step sums to summation order).
-        CCP_TRY(detect_region(m));
-        if (m->region_state == 1) {
+        // In the reference's own order the canvas is swept in raster order (k_lex_wg, Dirichlet-mask variant):
+        // the unknowns are numbered in raster order and every piece of the region keeps its shape on the canvas,
+        // so two coupled unknowns are met in the order of their indices — the index-order sweep, bit for bit.
+        CCP_TRY(detect_region(m, ordering == CCP_ORDER_LEXICOGRAPHIC));
+        if (m->region_state == 1 || (m->region_state == 2 && ordering == CCP_ORDER_LEXICOGRAPHIC)) {
             const long n = m->n_rows;
             hipStream_t s = m->stream;
             ccp_grid *g = m->region_grid;
@@ -1269,12 +1317,17 @@ try {
                 hipLaunchKernelGGL((k_canvas_move<2>), dim3(blocks_for(n)), dim3(kBlock), 0, s, gx, m->tmp.p, m->region_where.p, n, 1.0);   // sparse-matrix.h:352
             }
             CCP_HIP(hipGetLastError());
-            CCP_TRY(ccp_grid_region_begin(g));
-            CCP_TRY(ccp_grid_gauss_seidel(g, epsilon, max_iteration, check_every, report));
-            float region_ms = 0.f;
-            int64_t launches = 0, pass_iters = 0;
-            CCP_TRY(ccp_grid_region_end(g, &region_ms, &launches, &pass_iters));
-            m->last_launches = launches;
+            if (ordering == CCP_ORDER_LEXICOGRAPHIC) {
+                CCP_TRY(ccp_grid_gauss_seidel_lexicographic(g, epsilon, max_iteration, check_every, report));
+                m->last_launches = 0;
+            } else {
+                CCP_TRY(ccp_grid_region_begin(g));
+                CCP_TRY(ccp_grid_gauss_seidel(g, epsilon, max_iteration, check_every, report));
+                float region_ms = 0.f;
+                int64_t launches = 0, pass_iters = 0;
+                CCP_TRY(ccp_grid_region_end(g, &region_ms, &launches, &pass_iters));
+                m->last_launches = launches;
+            }
             hipLaunchKernelGGL((k_canvas_move<1>), dim3(blocks_for(n)), dim3(kBlock), 0, s, gx, m->tmp.p, m->region_where.p, n, 0.0);
             CCP_HIP(hipGetLastError());
             CCP_HIP(hipMemcpyAsync(x_out, m->tmp.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));

@@ -1227,7 +1227,7 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     int chunk = g->lex_chunk;
     if (chunk <= 0) chunk = std::min(lg.W, lg.H) <= 1024 ? 8 : 16;
     chunk = std::max(kLexSkewAhead, std::min(chunk, kWave)) / kLexSkewAhead * kLexSkewAhead;   // whole ring turns per chunk
-    const bool wg = g->lex_mode == 3 && T >= 2;
+    const bool wg = g->lex_mode == 3;
     const size_t need = (size_t)C * groups * S * (wg ? kLexWordStride : 1), edges = (size_t)C * S * edge_steps * 2 * T + (wg ? (size_t)C * groups * S * kLexScratch : 0);   // (+ the storers' scratch slots)
     if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
     if (wg && (g->lex_order_groups != groups || g->lex_order_strips != S)) {
@@ -1252,24 +1252,30 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     CCP_HIP(hipMemsetAsync(g->lex_progress.p, 0, need * sizeof(unsigned), g->stream));
     CCP_HIP(hipMemsetAsync(g->lex_ticket.p, 0, kMaxChannels * sizeof(unsigned), g->stream));
     dim3 grid((unsigned)((long)groups * S), (unsigned)C);
-    if constexpr (T >= 2) {
-    if (g->lex_mode == 3) {                                  // the T sweeps of a group on the T waves of a workgroup
+    if (wg) {                                                // the T sweeps of a group on the T waves of a workgroup
         static const int pad = getenv("CCP_GS_LEX_PAD_LDS") ? atoi(getenv("CCP_GS_LEX_PAD_LDS")) : 0;   // (occupancy experiments: extra LDS per workgroup)
         if (getenv("CCP_GS_DEBUG")) {
             int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lex_wg<T, false>, (T + 2) * kWave, pad);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lex_wg<T, false, false>, (T + 2) * kWave, pad);
             fprintf(stderr, "[ccp_gs] k_lex_wg<%d>: %d workgroups per CU, %d groups x %d strips\n", T, nb, groups, S);
         }
-        if (partial)
-            hipLaunchKernelGGL((k_lex_wg<T, true>), grid, dim3((T + 2) * kWave), pad, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,
-                               g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, partial, lex_partials_per_sweep(g));
-        else
-            hipLaunchKernelGGL((k_lex_wg<T, false>), grid, dim3((T + 2) * kWave), pad, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,
-                               g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, static_cast<double *>(nullptr), 0L);
+        const dim3 block((T + 2) * kWave);
+        double *nop = nullptr;
+#define CCP_LEX_WG(CHECK, MASKED, P, STRIDE)                                                                                         \
+    hipLaunchKernelGGL((k_lex_wg<T, CHECK, MASKED>), grid, block, pad, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,    \
+                       g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, P, STRIDE)
+        if (g->masked) {
+            if (partial) CCP_LEX_WG(true, true, partial, lex_partials_per_sweep(g));
+            else CCP_LEX_WG(false, true, nop, 0L);
+        } else {
+            if (partial) CCP_LEX_WG(true, false, partial, lex_partials_per_sweep(g));
+            else CCP_LEX_WG(false, false, nop, 0L);
+        }
+#undef CCP_LEX_WG
         CCP_HIP(hipGetLastError());
         return CCP_OK;
     }
-    }
+    if (g->masked) return CCP_ERR_UNSUPPORTED;               // (only k_lex_wg knows Dirichlet masks)
     if (partial)
         hipLaunchKernelGGL((k_lex_skew<T, true>), grid, dim3(kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S, chunk,
                            g->lex_progress.p, g->lex_ticket.p, g->lex_edges.p, edge_steps, mask, partial, lex_partials_per_sweep(g));
@@ -1332,7 +1338,7 @@ int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max
 try {
     CCP_TRY(bind(g));
     if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;   // whole image only
-    if (g->masked) return CCP_ERR_UNSUPPORTED;            // the reference-order sweep of a masked region is the CSR path's
+    if (g->masked && g->lex_mode != 3) return CCP_ERR_UNSUPPORTED;   // Dirichlet masks: k_lex_wg only
     if (max_iteration < 0 || check_every < 0) return CCP_ERR_BAD_ARG;
     const int C = g->desc.channels, W = g->desc.width, H = g->desc.height;
     LexGeom &lg = g->lexg;
@@ -1353,7 +1359,8 @@ try {
     CCP_TRY(begin_timing(g));
     dim3 cgrid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, (unsigned)C);
     hipLaunchKernelGGL((k_lex_convert<true>), cgrid, dim3(kBlock), 0, g->stream, g->x.p, g->lex_x.p, g->geom, lg);
-    hipLaunchKernelGGL((k_lex_convert<true>), cgrid, dim3(kBlock), 0, g->stream, g->b.p, g->lex_b.p, g->geom, lg);
+    if (g->masked) hipLaunchKernelGGL(k_lex_convert_b_masked, cgrid, dim3(kBlock), 0, g->stream, g->b.p, g->maskp.p, g->lex_b.p, g->geom, lg);
+    else hipLaunchKernelGGL((k_lex_convert<true>), cgrid, dim3(kBlock), 0, g->stream, g->b.p, g->lex_b.p, g->geom, lg);
     CCP_HIP(hipGetLastError());
 
     const unsigned all = (C >= 32) ? 0xffffffffu : ((1u << C) - 1u);

@@ -51,6 +51,24 @@ k_lex_convert(double *__restrict__ split, double *__restrict__ diag, Geom g, Lex
     else split[s] = diag[d];
 }
 
+// Dirichlet-mask grids (k_lex_wg<.., MASKED>): b in diagonal-major layout with a marker — a signalling NaN no
+// arithmetic produces — wherever the pixel is not an unknown.  The sweep sees one array instead of two: a pixel
+// whose b is the marker stays 0, every other pixel has the full row (diagonal 4; a neighbour that is not an
+// unknown holds 0, and adding -1 * 0 to the row sum leaves its bits unchanged).
+constexpr unsigned kLexFixedHi = 0x7ff4c0deu;
+__device__ __forceinline__ double lex_fixed_marker() { return __hiloint2double((int)kLexFixedHi, 1); }
+__device__ __forceinline__ bool lex_is_fixed(double b) { return (unsigned)__double2hiint(b) == kLexFixedHi; }
+
+__global__ void __launch_bounds__(kBlock)
+k_lex_convert_b_masked(const double *__restrict__ split, const unsigned char *__restrict__ mask, double *__restrict__ diag, Geom g, LexGeom lg)
+{
+    const int x = blockIdx.x * kBlock + threadIdx.x;
+    const int y = blockIdx.y, ch = blockIdx.z;
+    if (x >= lg.W) return;
+    const long s1 = row_off(g, y, (x + y) & 1) + (x >> 1);
+    diag[(long)ch * lg.plane + (long)(x + y) * lg.P + x] = mask[s1] ? split[(long)ch * g.ch_stride + s1] : lex_fixed_marker();
+}
+
 // One hyperplane.  grid = (nbx, iterations in flight, channels); blockIdx.y -> k = k_lo + blockIdx.y,
 // diagonal d = tau - 2k (the host launches only k with 0 <= d < n_diag).
 // CHECK: partial[((k*channels + ch)*n_diag + d)*nbx + blockIdx.x] = sum |x_new - x_old| of the block
@@ -574,6 +592,38 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
     }
 }
 
+// Dirichlet-mask grid: one body for every block.  An unknown has the full row (diagonal 4); a pixel whose b is
+// the marker — not an unknown, or off the canvas (the loader puts the marker there) — stays 0.
+template <int T, bool CHECK>
+__device__ __forceinline__ void lex_wg_compute_masked(double &h1, double &acc, double (*ring)[kLexRing][kWave],
+                                                      const double (*brow)[LexWgShape<T>::kRowW], int t, int lane, int db0, int db1)
+{
+    const bool ghost = lane < 2;
+    const int lds2 = max(lane - 2, 0);
+    const int col = ghost ? LexWgShape<T>::kGhost + 2 * t + lane : lane - 2 - 2 * t + 2 * (T - 1);
+    double old = 0.0;
+    for (int db = db0; db <= db1; db += 8) {
+        const int sb = (db - 4 * t) & (kLexBRows - 1);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const double *in = &ring[t][(j + 5) & 7][lds2];
+            const double down = in[0];
+            const double right = in[1];
+            const double vv = brow[(sb + j) & (kLexBRows - 1)][col];
+            const double up = h1;
+            const double left = lane_prev(h1);
+            double nv = (vv + (((up + left) + right) + down)) * 0.25;
+            nv = lex_is_fixed(vv) ? 0.0 : nv;
+            nv = ghost ? vv : nv;
+            if (CHECK) acc += ghost ? 0.0 : fabs(nv - old);
+            old = down;
+            ring[t + 1][j][lane] = nv;
+            h1 = nv;
+            lex_lds_barrier();
+        }
+    }
+}
+
 // What the loader and the storer know about the strip.
 struct LexWgStrip {
     const unsigned *watch;               // lanes 0..2 of the loader: whose progress to watch (own word: nothing to wait for)
@@ -601,10 +651,12 @@ __device__ __forceinline__ void lex_wg_gate(LexWgStrip &st, int db)
 // another register and costs a copy and a full drain at the loop's back edge).
 //   bp, xq     b and x of this channel (diagonal-major: element (row r, column c) at r*P + c)
 //   cb         the leftmost image column any sweep of the strip touches (b row in LDS: column c - cb)
-template <int T>
+//   MASKED     Dirichlet-mask grid: what lies off the canvas is made "not an unknown" (b: the marker) holding 0 (x)
+//              as it goes into LDS — there, not behind the load, where a select would wait for the load.
+template <int T, bool MASKED>
 __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexRing][kWave], double (*brow)[LexWgShape<T>::kRowW], int lane,
-                                            int db0, int db1, const double *bp, const double *xq, long P, int n_diag, int W, int cb, int xs0,
-                                            const double *e_left, int left_begin, int left_end)
+                                            int db0, int db1, const double *bp, const double *xq, long P, int n_diag, int W, int H, int cb,
+                                            int xs0, const double *e_left, int left_begin, int left_end)
 {
     constexpr int kCols = LexWgShape<T>::kCols, kGhost = LexWgShape<T>::kGhost;
     constexpr int kGhostOps = (16 * T + kWave - 1) / kWave;                  // 64-lane loads per ghost batch
@@ -613,6 +665,11 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
     const int c_x = min(max(xs0 + 2 + min(lane, kWave - 2), 0), W - 1);   // as sweep 0's lanes 2.. read x: one and two places to their left
     auto b_row = [&](int r) { return bp + (long)min(max(r, 0), n_diag - 1) * P; };
     auto x_row = [&](int r) { return xq + (long)min(max(r, 0), n_diag - 1) * P; };
+    // MASKED: is (diagonal row r, this lane's column) a pixel of the canvas?
+    const int k_b0 = cb + lane, k_b1 = cb + kWave + lane, k_x = xs0 + 2 + lane;
+    auto on_canvas = [&](int r, int c) { return c >= 0 && c < W && (unsigned)(r - c) < (unsigned)H; };
+    auto b_in = [&](double v, int r, int c) { return (!MASKED || on_canvas(r, c)) ? v : lex_fixed_marker(); };
+    auto x_in = [&](double v, int r, int c) { return (!MASKED || (lane < kWave - 1 && on_canvas(r, c))) ? v : 0.0; };
     // lane's ghost value(s) of a block: sweep g_t, step g_k, edge g_e -> b row (d - 4 g_t), column kGhost + 2 g_t + g_e
     int g_t[kGhostOps], g_k[kGhostOps], g_col[kGhostOps];
     bool g_on[kGhostOps];
@@ -636,7 +693,7 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
     {   // what the first steps read before the rings are rolling: x rows db0, db0+1, db0+2 and the ghost values of
         // block db0 (the b rows up to db0: by all waves, in the kernel)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) ring[0][(db0 + q - 4) & 7][lane] = lex_ld(x_row(db0 + q) + c_x);
+        for (int q = 0; q < 3; ++q) ring[0][(db0 + q - 4) & 7][lane] = x_in(lex_ld(x_row(db0 + q) + c_x), db0 + q, k_x);
 #pragma unroll
         for (int q = 0; q < kGhostOps; ++q) {
             const double v = ghost_load(db0, q);
@@ -666,9 +723,9 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = (db + j + 1) & (kLexBRows - 1);
-            brow[r][lane] = qb[j];                                           // b row d + 1
-            if (kCols > kWave && lane < kCols - kWave) brow[r][kWave + lane] = qb1[j];
-            ring[0][(j + 7) & 7][lane] = qx[j];                              // x row d + 3: read by sweep 0 at steps d+2, d+3
+            if (kCols >= kWave || lane < kCols) brow[r][lane] = b_in(qb[j], db + j + 1, k_b0);   // b row d + 1 (T = 1: 62 columns)
+            if (kCols > kWave && lane < kCols - kWave) brow[r][kWave + lane] = b_in(qb1[j], db + j + 1, k_b1);
+            ring[0][(j + 7) & 7][lane] = x_in(qx[j], db + j + 3, k_x);       // x row d + 3: read by sweep 0 at steps d+2, d+3
             if (j == 7) {
 #pragma unroll
                 for (int q = 0; q < kGhostOps; ++q)
@@ -689,7 +746,7 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
 
 // The storer's side of blocks db0 .. db1: after the barrier of step d, sweep T-1's row of that step goes to x
 // (the pixels that have a row) and the 2T edge values of the step to the edge buffer.
-template <int T>
+template <int T, bool MASKED>
 __device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLexRing][kWave], Geom g, int W, int H, int lane, int db0, int db1,
                                              double *xq, long P, int xs0, int d_begin, int d_end, double *e_mine, double *scratch,
                                              bool strip_interior, Stencil st_b)
@@ -704,7 +761,19 @@ __device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLex
     for (int db = db0; db <= db1; db += 8) {
         // Exactly two stores per step, whatever the masks say (lane 0 and the edge lanes fall back to scratch slots
         // of this workgroup's own): the publication below counts on it.
-        if (db >= in_lo && db + 7 <= in_hi) {
+        if (MASKED) {
+            // Dirichlet-mask grid: every pixel of the canvas is stored (one that is not an unknown holds 0 and gets 0)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int d = db + j;
+                lex_lds_barrier();
+                const double v = ring[T][j][lane];
+                const double ev = ring[e_t][j][e_lane];
+                const bool wrote = lane_on && (unsigned)(d - xp - 2 * t) < (unsigned)H;
+                if (wrote || lane == 0) lex_st(wrote ? xq + (long)(d - 4 * t) * P + xl : scratch + j, v);
+                if (lane < 2 * T) lex_st((d >= d_begin && d <= d_end) ? e_mine + ((long)(d - d_begin) * T) * 2 + lane : scratch + 8 + lane, ev);
+            }
+        } else if (db >= in_lo && db + 7 <= in_hi) {
             // every real lane has 1 <= y <= H-2: which pixels have a row does not change from step to step.  In an
             // interior strip the ghost lanes store too: they carry the left strip's results of the same sweep for
             // exactly these pixels, so it is the value already there.
@@ -742,13 +811,13 @@ __device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLex
     }
 }
 
-template <int T, bool CHECK>
+template <int T, bool CHECK, bool MASKED>
 __global__ void __launch_bounds__((T + 2) * kWave)
 k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S,
          unsigned *__restrict__ progress, unsigned *__restrict__ ticket, const unsigned *__restrict__ order,
          double *__restrict__ edges, long edge_steps, unsigned active_mask, double *__restrict__ partial, long partial_stride)
 {
-    static_assert(kLexRing == 8 && T >= 2, "the unrolled step index is the ring slot");
+    static_assert(kLexRing == 8 && T >= 1, "the unrolled step index is the ring slot");
     static_assert(4 * (T - 1) + 4 <= kLexBRows, "a b row stays in LDS from step r-1 to step r+4(T-1)");
     constexpr int kRowW = LexWgShape<T>::kRowW;
     __shared__ double ring[T + 1][kLexRing][kWave];
@@ -805,8 +874,10 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
             const int r = db0 - (kPrime - 1) + wv * kPer + q;
             if (r <= db0) {                                              // (uniform)
                 const double *row = bd + plane + (long)min(max(r, 0), lg.n_diag - 1) * lg.P;
-                brow[r & (kLexBRows - 1)][lane] = row[c0];
-                if (kCols > kWave && lane < kCols - kWave) brow[r & (kLexBRows - 1)][kWave + lane] = row[c1];
+                const bool in0 = !MASKED || (cb + lane >= 0 && cb + lane < lg.W && (unsigned)(r - cb - lane) < (unsigned)lg.H);
+                const bool in1 = !MASKED || (cb + kWave + lane < lg.W && (unsigned)(r - cb - kWave - lane) < (unsigned)lg.H);
+                if (kCols >= kWave || lane < kCols) brow[r & (kLexBRows - 1)][lane] = in0 ? row[c0] : lex_fixed_marker();
+                if (kCols > kWave && lane < kCols - kWave) brow[r & (kLexBRows - 1)][kWave + lane] = in1 ? row[c1] : lex_fixed_marker();
             }
         }
     }
@@ -818,7 +889,8 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
         const bool has_x0 = s == 0 && xs0 + 2 - 2 * t <= 0 && xs0 + 63 - 2 * t >= 0;
         const bool has_xl = xs0 + 63 - 2 * t >= lg.W - 1;                // (column W-1, or nothing on the image at all)
         lex_lds_barrier();                                                   // (the loader's priming barrier)
-        if (strip_interior) lex_wg_compute<T, CHECK, 0>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
+        if (MASKED) lex_wg_compute_masked<T, CHECK>(h1, acc, ring, brow, t, lane, db0, db1);
+        else if (strip_interior) lex_wg_compute<T, CHECK, 0>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
         else if (has_x0 && !has_xl) lex_wg_compute<T, CHECK, 1>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
         else if (!has_x0) lex_wg_compute<T, CHECK, 2>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
         else lex_wg_compute<T, CHECK, 3>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
@@ -827,11 +899,11 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
             if (lane == 0) partial[(((long)grp * T + t) * gridDim.y + ch) * partial_stride + s] = total;
         }
     } else if (wv == T) {
-        lex_wg_load<T>(st, ring, brow, lane, db0, db1, bd + plane, xd + plane, lg.P, lg.n_diag, lg.W, cb, xs0, e_left, left_begin, left_end);
+        lex_wg_load<T, MASKED>(st, ring, brow, lane, db0, db1, bd + plane, xd + plane, lg.P, lg.n_diag, lg.W, lg.H, cb, xs0, e_left, left_begin, left_end);
     } else {
         // (scratch: kLexScratch doubles per workgroup behind the edge values of all strips)
         double *scratch = edges + (long)gridDim.y * S * edge_steps * (2 * T) + (((long)ch * G + grp) * S + s) * kLexScratch;
-        lex_wg_store<T>(st, ring, g, lg.W, lg.H, lane, db0, db1, xd + plane, lg.P, xs0, d_begin, d_end, e_mine, scratch, strip_interior, st_b);
+        lex_wg_store<T, MASKED>(st, ring, g, lg.W, lg.H, lane, db0, db1, xd + plane, lg.P, xs0, d_begin, d_end, e_mine, scratch, strip_interior, st_b);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                   // compiler ordering only
     __builtin_amdgcn_s_waitcnt(0);                                           // this wave's (write-through) stores acknowledged

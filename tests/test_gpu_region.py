@@ -117,9 +117,9 @@ def test_csr_upload_reaches_the_region_grid(capi, orc, monkeypatch, name):
     else:                                   # the reference loop never starts: eps = 10 <= epsilon
         x, rep = m.gauss_seidel(b, threshold, 2000, x0=near, check_every=1)
         assert it == 0 and rep.iterations == 0 and np.array_equal(x, near)
-    # the reference's own order is not the region grid's business: general path, still exact
+    # the reference's own order: the canvas swept in raster order (k_lex_wg, Dirichlet-mask variant)
     x, _ = m.gauss_seidel(b, 0.0, 3, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
-    assert m.last_path() == "sliced ELL"
+    assert m.last_path().startswith("region grid"), m.last_path()
     assert np.array_equal(x, orc.from_csr(v, c, r).gauss_seidel(b, 0.0, 3)[0])
     m.close()
     # the same matrix kept on the general path
@@ -129,6 +129,42 @@ def test_csr_upload_reaches_the_region_grid(capi, orc, monkeypatch, name):
     x2, _ = m.gauss_seidel(b, 0.0, 17, check_every=0)
     assert m.last_path() == "sliced ELL"
     assert np.array_equal(x2, orc.multicolour_gauss_seidel(v, c, r, colour, b, 0.0, 17)[0])
+    m.close()
+
+
+@pytest.mark.parametrize("name", list(MASKS))
+def test_region_in_the_references_own_order(capi, orc, monkeypatch, name):
+    """gaussSeidel in index order (sparse-matrix.h:350-380, the matrix as it is) on a raster-region Laplacian: the
+    region grid swept in raster order gives the oracle's bits for sweep counts that leave passes of 8, 4, 2 and 1,
+    with a start vector, and stops where the oracle stops; so does the stored-matrix path (CCP_GS_MASKED=0)."""
+    mask = MASKS[name]()
+    v, c, r, colour, ys, xs, b, x0 = region_system(mask, 21)
+    om = orc.from_csr(v, c, r)
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    for k in (1, 8, 15, 26):
+        x, rep = m.gauss_seidel(b, 0.0, k, x0=x0, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+        assert m.last_path().startswith("region grid"), m.last_path()
+        want = om.gauss_seidel(b, 0.0, k, x0=x0)[0]
+        assert rep.iterations == k and np.array_equal(x, want), (name, k, np.abs(x - want).max())
+    x, _ = m.gauss_seidel(b, 0.0, 5, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)          # default start: all ones
+    assert np.array_equal(x, om.gauss_seidel(b, 0.0, 5)[0])
+    near = om.gauss_seidel(b, 0.0, 80)[0]
+    threshold = om.gauss_seidel(b, 0.0, 21, x0=near)[2] * (1.0 + 1e-9)
+    want, it, eps = om.gauss_seidel(b, threshold, 2000, x0=near)
+    x, rep = m.gauss_seidel(b, threshold, 2000, x0=near, check_every=1, ordering=capi.ORDER_LEXICOGRAPHIC)
+    assert rep.iterations == it and np.array_equal(x, want), (name, it, rep.iterations)
+    if it > 0:
+        assert rep.converged == 1 and abs(rep.last_l1_step - eps) <= 1e-12 * eps
+    # no colouring was given: the colour-ordered sweep of the same handle uses the library's own colouring (which
+    # may need a third colour, and then stays on the stored matrix) — whatever it reports is what it sweeps with
+    col, nc = m.get_colouring()
+    x, _ = m.gauss_seidel(b, 0.0, 4, x0=x0, check_every=0)
+    assert np.array_equal(x, orc.multicolour_gauss_seidel(v, c, r, col, b, 0.0, 4, x0=x0)[0]), (name, nc, m.last_path())
+    m.close()
+    monkeypatch.setenv("CCP_GS_MASKED", "0")
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    x, _ = m.gauss_seidel(b, 0.0, 8, x0=x0, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+    assert m.last_path() == "sliced ELL" and np.array_equal(x, om.gauss_seidel(b, 0.0, 8, x0=x0)[0])
     m.close()
 
 
