@@ -359,6 +359,22 @@ def run_round2(n, rng, orc):
             if label in outs and not np.array_equal(outs[label], want):
                 bad += 1
                 print("MISMATCH region", label, outs.get(label + "_path"), W, H, iters, float(np.abs(outs[label] - want).max()), flush=True)
+        # the same region in the reference's own order, with and without a colouring (mask variant of k_lex_wg)
+        want_lex = orc.from_csr(v, c, r).gauss_seidel(b, 0.0, iters, x0=x0)[0]
+        for with_colouring in (True, False):
+            try:
+                m = capi.CsrMatrix().upload_compressed(v, c, r)
+                if with_colouring:
+                    m.set_colouring(colour, 2)
+                got, _ = m.gauss_seidel(b, 0.0, iters, x0=x0, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+                path = m.last_path()
+                m.close()
+                if not np.array_equal(got, want_lex):
+                    bad += 1
+                    print("MISMATCH region reference order", with_colouring, path, W, H, iters, float(np.abs(got - want_lex).max()), flush=True)
+            except Exception as e:
+                bad += 1
+                print("ERROR region reference order", with_colouring, W, H, iters, repr(e), flush=True)
         if colour[0] == ((xs[0] + ys[0]) & 1):                            # the mask grid directly (its colour 0 is (x+y) even)
             os.environ["CCP_GS_TMAX"] = str(int(rng.integers(1, 8)))
             os.environ["CCP_GS_CHUNK"] = str(int(rng.integers(8, 200)))
