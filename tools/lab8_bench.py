@@ -67,6 +67,13 @@ for label, env in (("region_grid", "1"), ("sliced_ell", "0")):
     out["union_region_" + label] = {"unknowns": n, "path": m.last_path(), "iterations": K, "ms_per_iteration": rep.seconds * 1e3 / K,
                                     "row_updates_per_s": n * K / rep.seconds, "first_solve_incl_setup_s": t_first,
                                     "rel_residual": float(np.sqrt(r2 / b2)), "checksum": float(np.abs(x).sum())}
+    # the same region through the reference's unchanged call: gaussSeidel in index order (the facade's default)
+    m.gauss_seidel(b, 0.0, 2, x0=x0, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+    x, rep = m.gauss_seidel(b, 0.0, K, x0=x0, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+    out["union_region_" + label]["reference_order"] = {"path": m.last_path(), "iterations": K, "row_updates_per_s": n * K / rep.seconds,
+                                                       "checksum": float(np.abs(x).sum())}
     m.close()
-out["union_region_paths_agree"] = out["union_region_region_grid"]["checksum"] == out["union_region_sliced_ell"]["checksum"]
+out["union_region_paths_agree"] = (out["union_region_region_grid"]["checksum"] == out["union_region_sliced_ell"]["checksum"]
+                                   and out["union_region_region_grid"]["reference_order"]["checksum"]
+                                   == out["union_region_sliced_ell"]["reference_order"]["checksum"])
 print(json.dumps(out))
