@@ -281,8 +281,10 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration,
 
 /* The same loop in the reference's OWN sweep order (index order, sparse-matrix.h:357-370): iterates,
  * stop sweep and result are those of SparseMatrix::gaussSeidel on the unpermuted matrix, bit for bit
- * (eps to summation order).  The sweep is pipelined over the hyperplanes x + y + 2k (pixel, iteration),
- * one launch per hyperplane, on a diagonal-major copy of x and b (2x the image's memory while it runs).
+ * (eps to summation order).  The sweeps are pipelined over the hyperplanes x + y + 2k (pixel, iteration):
+ * time-skewed strips, 8 sweeps per pass through memory, one launch per pass depth, on a diagonal-major copy
+ * of x and b (2x the image's memory while it runs).  Dirichlet-mask handles too: the unknowns are swept in
+ * raster order (what SparseMatrix::gaussSeidel does with a region matrix numbered in raster order).
  * Whole-image handles only (no ghost rows: CCP_ERR_STATE).  check_every as above. */
 int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max_iteration,
                                         int32_t check_every, ccp_gs_report *report);
