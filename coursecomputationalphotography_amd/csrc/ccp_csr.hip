@@ -1317,8 +1317,11 @@ try {
                 hipLaunchKernelGGL((k_canvas_move<2>), dim3(blocks_for(n)), dim3(kBlock), 0, s, gx, m->tmp.p, m->region_where.p, n, 1.0);   // sparse-matrix.h:352
             }
             CCP_HIP(hipGetLastError());
+            bool swept = true;
             if (ordering == CCP_ORDER_LEXICOGRAPHIC) {
-                CCP_TRY(ccp_grid_gauss_seidel_lexicographic(g, epsilon, max_iteration, check_every, report));
+                const int st = ccp_grid_gauss_seidel_lexicographic(g, epsilon, max_iteration, check_every, report);
+                if (st == CCP_ERR_UNSUPPORTED) swept = false;     // (an engine chosen by CCP_GS_LEX_MODE that knows no masks)
+                else CCP_TRY(st);
                 m->last_launches = 0;
             } else {
                 CCP_TRY(ccp_grid_region_begin(g));
@@ -1328,12 +1331,14 @@ try {
                 CCP_TRY(ccp_grid_region_end(g, &region_ms, &launches, &pass_iters));
                 m->last_launches = launches;
             }
-            hipLaunchKernelGGL((k_canvas_move<1>), dim3(blocks_for(n)), dim3(kBlock), 0, s, gx, m->tmp.p, m->region_where.p, n, 0.0);
-            CCP_HIP(hipGetLastError());
-            CCP_HIP(hipMemcpyAsync(x_out, m->tmp.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
-            CCP_HIP(hipStreamSynchronize(s));
-            m->last_path = CCP_PATH_REGION_GRID;
-            return CCP_OK;
+            if (swept) {
+                hipLaunchKernelGGL((k_canvas_move<1>), dim3(blocks_for(n)), dim3(kBlock), 0, s, gx, m->tmp.p, m->region_where.p, n, 0.0);
+                CCP_HIP(hipGetLastError());
+                CCP_HIP(hipMemcpyAsync(x_out, m->tmp.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+                CCP_HIP(hipStreamSynchronize(s));
+                m->last_path = CCP_PATH_REGION_GRID;
+                return CCP_OK;
+            }
         }
     }
     if (ordering == CCP_ORDER_LEXICOGRAPHIC && m->allow_structured) {
