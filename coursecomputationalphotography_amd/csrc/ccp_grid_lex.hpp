@@ -439,7 +439,7 @@ k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGe
 // lanes, edge buffer, progress words and tickets as k_lex_skew, but a workgroup of T + 2 waves per strip:
 //
 //   waves 0 .. T-1   one sweep each.  Wave t reads its inputs from LDS only — the results of sweep t-1 three and
-//                    four steps back (one and two lanes to the left) from a ring of the last 8 result rows per
+//                    steps back (one and two lanes to the left) from a ring of the last 4 result rows per
 //                    sweep, b from a ring of 32 diagonal rows — and writes its result row into the ring.  No
 //                    global memory operation, ~20 instructions per step.
 //   wave T           the loader: everything the pass reads from memory, eight steps ahead in registers — the
@@ -459,7 +459,7 @@ k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGe
 //   C  anything else (the first and last ~10 blocks of a strip): classify / gs_update at every step.
 // All three read their inputs from the rings: no wave but the loader loads, no wave but the storer stores.
 // grid = (G * S, channels), block = (T + 2) * 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
-constexpr int kLexRing = 8;
+constexpr int kLexRing = 4;                        // result rows kept per sweep: written at step d, read at step d+3, free at d+4
 constexpr int kLexBRows = 32;
 constexpr int kLexSlackRows = 128;                 // diagonal rows allocated beyond the last one (k_lex_wg prefetches past the image)
 constexpr int kLexScratch = 32;                    // doubles per workgroup the storer of k_lex_wg may write to and nobody reads
@@ -514,7 +514,7 @@ __device__ __forceinline__ void lex_wg_general_block(double &h1, double &acc, do
 #pragma unroll 1
     for (int j = 0; j < 8; ++j) {
         const int d = db + j, y = d - xp - 2 * t;
-        const double *in = &ring[t][(j + 5) & 7][lds2];
+        const double *in = &ring[t][(j + 1) & (kLexRing - 1)][lds2];
         const double down = in[0];
         const double right = in[1];
         const double vv = brow[(d - 4 * t) & (kLexBRows - 1)][col];
@@ -529,7 +529,7 @@ __device__ __forceinline__ void lex_wg_general_block(double &h1, double &acc, do
             }
         }
         old = down;
-        ring[t + 1][j][lane] = nv;
+        ring[t + 1][j & (kLexRing - 1)][lane] = nv;
         h1 = nv;
         lex_lds_barrier();
     }
@@ -564,7 +564,7 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
         const int sb = (db - 4 * t) & (kLexBRows - 1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const double *in = &ring[t][(j + 5) & 7][lds2];                  // two adjacent doubles: one ds_read2_b64
+            const double *in = &ring[t][(j + 1) & (kLexRing - 1)][lds2];                  // two adjacent doubles: one ds_read2_b64
             const double down = in[0];
             const double right = in[1];
             const double vv = brow[(sb + j) & (kLexBRows - 1)][col];
@@ -585,7 +585,7 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
             if (KIND != 1) nv = ghost ? vv : nv;
             if (CHECK) acc += wrote ? fabs(nv - old) : 0.0;                  // old: this pixel in the previous sweep
             old = down;                                                      // ... is what was `down` one step (one row) earlier
-            ring[t + 1][j][lane] = nv;
+            ring[t + 1][j & (kLexRing - 1)][lane] = nv;
             h1 = nv;
             lex_lds_barrier();
         }
@@ -606,7 +606,7 @@ __device__ __forceinline__ void lex_wg_compute_masked(double &h1, double &acc, d
         const int sb = (db - 4 * t) & (kLexBRows - 1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const double *in = &ring[t][(j + 5) & 7][lds2];
+            const double *in = &ring[t][(j + 1) & (kLexRing - 1)][lds2];
             const double down = in[0];
             const double right = in[1];
             const double vv = brow[(sb + j) & (kLexBRows - 1)][col];
@@ -617,7 +617,7 @@ __device__ __forceinline__ void lex_wg_compute_masked(double &h1, double &acc, d
             nv = ghost ? vv : nv;
             if (CHECK) acc += ghost ? 0.0 : fabs(nv - old);
             old = down;
-            ring[t + 1][j][lane] = nv;
+            ring[t + 1][j & (kLexRing - 1)][lane] = nv;
             h1 = nv;
             lex_lds_barrier();
         }
@@ -693,7 +693,7 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
     {   // what the first steps read before the rings are rolling: x rows db0, db0+1, db0+2 and the ghost values of
         // block db0 (the b rows up to db0: by all waves, in the kernel)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) ring[0][(db0 + q - 4) & 7][lane] = x_in(lex_ld(x_row(db0 + q) + c_x), db0 + q, k_x);
+        for (int q = 0; q < 3; ++q) ring[0][(db0 + q) & (kLexRing - 1)][lane] = x_in(lex_ld(x_row(db0 + q) + c_x), db0 + q, k_x);
 #pragma unroll
         for (int q = 0; q < kGhostOps; ++q) {
             const double v = ghost_load(db0, q);
@@ -725,7 +725,7 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
             const int r = (db + j + 1) & (kLexBRows - 1);
             if (kCols >= kWave || lane < kCols) brow[r][lane] = b_in(qb[j], db + j + 1, k_b0);   // b row d + 1 (T = 1: 62 columns)
             if (kCols > kWave && lane < kCols - kWave) brow[r][kWave + lane] = b_in(qb1[j], db + j + 1, k_b1);
-            ring[0][(j + 7) & 7][lane] = x_in(qx[j], db + j + 3, k_x);       // x row d + 3: read by sweep 0 at steps d+2, d+3
+            ring[0][(j + 3) & (kLexRing - 1)][lane] = x_in(qx[j], db + j + 3, k_x);       // x row d + 3: read by sweep 0 at steps d+2, d+3
             if (j == 7) {
 #pragma unroll
                 for (int q = 0; q < kGhostOps; ++q)
@@ -767,8 +767,8 @@ __device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLex
             for (int j = 0; j < 8; ++j) {
                 const int d = db + j;
                 lex_lds_barrier();
-                const double v = ring[T][j][lane];
-                const double ev = ring[e_t][j][e_lane];
+                const double v = ring[T][j & (kLexRing - 1)][lane];
+                const double ev = ring[e_t][j & (kLexRing - 1)][e_lane];
                 const bool wrote = lane_on && (unsigned)(d - xp - 2 * t) < (unsigned)H;
                 if (wrote || lane == 0) lex_st(wrote ? xq + (long)(d - 4 * t) * P + xl : scratch + j, v);
                 if (lane < 2 * T) lex_st((d >= d_begin && d <= d_end) ? e_mine + ((long)(d - d_begin) * T) * 2 + lane : scratch + 8 + lane, ev);
@@ -783,8 +783,8 @@ __device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLex
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 lex_lds_barrier();                                           // step d is in the rings
-                const double v = ring[T][j][lane];
-                const double ev = ring[e_t][j][e_lane];
+                const double v = ring[T][j & (kLexRing - 1)][lane];
+                const double ev = ring[e_t][j & (kLexRing - 1)][e_lane];
                 if (strip_interior) lex_st(px, v);
                 else if (wrote || lane == 0) lex_st(wrote ? px : scratch + j, v);
                 if (lane < 2 * T) lex_st(pe, ev);
@@ -796,8 +796,8 @@ __device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLex
             for (int j = 0; j < 8; ++j) {
                 const int d = db + j, y = d - xp - 2 * t;
                 lex_lds_barrier();
-                const double v = ring[T][j][lane];
-                const double ev = ring[e_t][j][e_lane];
+                const double v = ring[T][j & (kLexRing - 1)][lane];
+                const double ev = ring[e_t][j & (kLexRing - 1)][e_lane];
                 const bool wrote = lane_on && y >= 0 && y < H && classify(g, xl, y, y).diag != 0;
                 if (wrote || lane == 0) lex_st(wrote ? xq + (long)(d - 4 * t) * P + xl : scratch + j, v);
                 if (lane < 2 * T) lex_st((d >= d_begin && d <= d_end) ? e_mine + ((long)(d - d_begin) * T) * 2 + lane : scratch + 8 + lane, ev);
@@ -817,7 +817,7 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
          unsigned *__restrict__ progress, unsigned *__restrict__ ticket, const unsigned *__restrict__ order,
          double *__restrict__ edges, long edge_steps, unsigned active_mask, double *__restrict__ partial, long partial_stride)
 {
-    static_assert(kLexRing == 8 && T >= 1, "the unrolled step index is the ring slot");
+    static_assert(kLexRing == 4 && T >= 1, "the unrolled step index mod 4 is the ring slot");
     static_assert(4 * (T - 1) + 4 <= kLexBRows, "a b row stays in LDS from step r-1 to step r+4(T-1)");
     constexpr int kRowW = LexWgShape<T>::kRowW;
     __shared__ double ring[T + 1][kLexRing][kWave];
