@@ -1256,20 +1256,20 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
         static const int pad = getenv("CCP_GS_LEX_PAD_LDS") ? atoi(getenv("CCP_GS_LEX_PAD_LDS")) : 0;   // (occupancy experiments: extra LDS per workgroup)
         if (getenv("CCP_GS_DEBUG")) {
             int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lex_wg<T, false, false>, (T + 2) * kWave, pad);
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lex_wg<T, false>, (T + 2) * kWave, pad);
             fprintf(stderr, "[ccp_gs] k_lex_wg<%d>: %d workgroups per CU, %d groups x %d strips\n", T, nb, groups, S);
         }
         const dim3 block((T + 2) * kWave);
         double *nop = nullptr;
-#define CCP_LEX_WG(CHECK, MASKED, P, STRIDE)                                                                                         \
-    hipLaunchKernelGGL((k_lex_wg<T, CHECK, MASKED>), grid, block, pad, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,    \
+#define CCP_LEX_WG(KERNEL, CHECK, P, STRIDE)                                                                                        \
+    hipLaunchKernelGGL((KERNEL<T, CHECK>), grid, block, pad, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,              \
                        g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, P, STRIDE)
         if (g->masked) {
-            if (partial) CCP_LEX_WG(true, true, partial, lex_partials_per_sweep(g));
-            else CCP_LEX_WG(false, true, nop, 0L);
+            if (partial) CCP_LEX_WG(k_lex_wg_masked, true, partial, lex_partials_per_sweep(g));
+            else CCP_LEX_WG(k_lex_wg_masked, false, nop, 0L);
         } else {
-            if (partial) CCP_LEX_WG(true, false, partial, lex_partials_per_sweep(g));
-            else CCP_LEX_WG(false, false, nop, 0L);
+            if (partial) CCP_LEX_WG(k_lex_wg, true, partial, lex_partials_per_sweep(g));
+            else CCP_LEX_WG(k_lex_wg, false, nop, 0L);
         }
 #undef CCP_LEX_WG
         CCP_HIP(hipGetLastError());

@@ -626,7 +626,8 @@ __device__ __forceinline__ void lex_wg_compute_masked(double &h1, double &acc, d
 
 // What the loader and the storer know about the strip.
 struct LexWgStrip {
-    const unsigned *watch;               // lanes 0..2 of the loader: whose progress to watch (own word: nothing to wait for)
+    const unsigned *words;               // the progress words of this launch (uniform)
+    unsigned watch;                      // lanes 0..2 of the loader: index of the word to watch (own word: nothing to wait for)
     int need_off;                        // ... which has to reach block start + need_off
     unsigned known;
     unsigned *mine;                      // this strip's progress word: steps < value are complete and visible
@@ -638,7 +639,7 @@ __device__ __forceinline__ void lex_wg_gate(LexWgStrip &st, int db)
     bool ok = (int)min(st.known, 0x7fffffffu) >= need;
     while (!__all(ok)) {
         if (!ok) {
-            st.known = __hip_atomic_load(st.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            st.known = __hip_atomic_load(st.words + st.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             ok = (int)min(st.known, 0x7fffffffu) >= need;
         }
         if (!__all(ok)) __builtin_amdgcn_s_sleep(16);        // ~1000 cycles: the word is being written by the strip polled
@@ -660,9 +661,9 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
 {
     constexpr int kCols = LexWgShape<T>::kCols, kGhost = LexWgShape<T>::kGhost;
     constexpr int kGhostOps = (16 * T + kWave - 1) / kWave;                  // 64-lane loads per ghost batch
-    const int c_b0 = min(max(cb + lane, 0), W - 1);
-    const int c_b1 = min(max(cb + kWave + min(lane, max(kCols - kWave - 1, 0)), 0), W - 1);
-    const int c_x = min(max(xs0 + 2 + min(lane, kWave - 2), 0), W - 1);   // as sweep 0's lanes 2.. read x: one and two places to their left
+    const unsigned c_b0 = (unsigned)min(max(cb + lane, 0), W - 1);
+    const unsigned c_b1 = (unsigned)min(max(cb + kWave + min(lane, max(kCols - kWave - 1, 0)), 0), W - 1);
+    const unsigned c_x = (unsigned)min(max(xs0 + 2 + min(lane, kWave - 2), 0), W - 1);   // as sweep 0's lanes 2.. read x: one and two places to their left
     auto b_row = [&](int r) { return bp + (long)min(max(r, 0), n_diag - 1) * P; };
     auto x_row = [&](int r) { return xq + (long)min(max(r, 0), n_diag - 1) * P; };
     // MASKED: is (diagonal row r, this lane's column) a pixel of the canvas?
@@ -671,24 +672,19 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
     auto b_in = [&](double v, int r, int c) { return (!MASKED || on_canvas(r, c)) ? v : lex_fixed_marker(); };
     auto x_in = [&](double v, int r, int c) { return (!MASKED || (lane < kWave - 1 && on_canvas(r, c))) ? v : 0.0; };
     // lane's ghost value(s) of a block: sweep g_t, step g_k, edge g_e -> b row (d - 4 g_t), column kGhost + 2 g_t + g_e
-    int g_t[kGhostOps], g_k[kGhostOps], g_col[kGhostOps];
-    bool g_on[kGhostOps];
-#pragma unroll
-    for (int q = 0; q < kGhostOps; ++q) {
-        const int idx = q * kWave + lane;
-        g_on[q] = idx < 16 * T;
-        g_t[q] = min(idx >> 4, T - 1);
-        g_k[q] = (idx & 15) >> 1;
-        g_col[q] = kGhost + 2 * g_t[q] + (idx & 1);
-    }
+    // (worked out from the lane where needed: the loader is the wave that decides the kernel's register count)
+    auto g_on = [&](int q) { return q * kWave + lane < 16 * T; };
+    auto g_t = [&](int q) { return min((q * kWave + lane) >> 4, T - 1); };
+    auto g_k = [&](int q) { return (lane & 15) >> 1; };
+    auto g_col = [&](int q) { return kGhost + 2 * g_t(q) + (lane & 1); };
     // the left strip's edge value for step blk + g_k (raw: whether that step exists is ghost_valid, applied where
     // the value is used — a select right behind the load would wait for it, and for every prefetch before it)
     auto ghost_load = [&](int blk, int q) -> double {
         if (e_left == nullptr) return 0.0;
-        const int d = blk + g_k[q];
-        return lex_ld(e_left + ((long)(min(max(d, left_begin), left_end) - left_begin) * T + g_t[q]) * 2 + (g_col[q] & 1));
+        const int d = blk + g_k(q);
+        return lex_ld(e_left + ((long)(min(max(d, left_begin), left_end) - left_begin) * T + g_t(q)) * 2 + (g_col(q) & 1));
     };
-    auto ghost_valid = [&](int blk, int q) { const int d = blk + g_k[q]; return e_left != nullptr && d >= left_begin && d <= left_end; };
+    auto ghost_valid = [&](int blk, int q) { const int d = blk + g_k(q); return e_left != nullptr && d >= left_begin && d <= left_end; };
     lex_wg_gate(st, db0);
     {   // what the first steps read before the rings are rolling: x rows db0, db0+1, db0+2 and the ghost values of
         // block db0 (the b rows up to db0: by all waves, in the kernel)
@@ -697,7 +693,7 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
 #pragma unroll
         for (int q = 0; q < kGhostOps; ++q) {
             const double v = ghost_load(db0, q);
-            if (g_on[q]) brow[(db0 + g_k[q] - 4 * g_t[q]) & (kLexBRows - 1)][g_col[q]] = ghost_valid(db0, q) ? v : 0.0;
+            if (g_on(q)) brow[(db0 + g_k(q) - 4 * g_t(q)) & (kLexBRows - 1)][g_col(q)] = ghost_valid(db0, q) ? v : 0.0;
         }
     }
     double qb[8], qb1[8], qx[8];
@@ -707,13 +703,13 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
         qb1[j] = kCols > kWave ? b_row(db0 + 1 + j)[c_b1] : 0.0;
         qx[j] = lex_ld(x_row(db0 + 3 + j) + c_x);
     }
-    const double *pb = bp + (long)(db0 + 9) * P + c_b0, *pb1 = bp + (long)(db0 + 9) * P + c_b1, *px = xq + (long)(db0 + 11) * P + c_x;
+    const double *rb = bp + (long)(db0 + 9) * P, *rx = xq + (long)(db0 + 11) * P;   // (uniform row bases: scalar registers)
     lex_lds_barrier();                                                       // (every wave of the workgroup comes here)
     for (int db = db0; db <= db1; db += 8) {
         if (db > db0) lex_wg_gate(st, db);
         // issued here, looked at after the block's last step: no loaded value but the prefetch slots lives across
         // the loop's back edge
-        const unsigned polled = __hip_atomic_load(st.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned polled = __hip_atomic_load(st.words + st.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         double qg[kGhostOps];
 #pragma unroll
         for (int q = 0; q < kGhostOps; ++q) qg[q] = ghost_load(db + 8, q);
@@ -729,15 +725,14 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
             if (j == 7) {
 #pragma unroll
                 for (int q = 0; q < kGhostOps; ++q)
-                    if (g_on[q]) brow[(db + 8 + g_k[q] - 4 * g_t[q]) & (kLexBRows - 1)][g_col[q]] = ghost_valid(db + 8, q) ? qg[q] : 0.0;
+                    if (g_on(q)) brow[(db + 8 + g_k(q) - 4 * g_t(q)) & (kLexBRows - 1)][g_col(q)] = ghost_valid(db + 8, q) ? qg[q] : 0.0;
             }
             asm volatile("" ::: "memory");
-            qb[j] = lex_ld(pb);                                              // b row d + 9 (sc1 as well: streamed once, and a
-            if (kCols > kWave) qb1[j] = lex_ld(pb1);                         // plain load was measured slower here)
-            qx[j] = lex_ld(px);                                              // x row d + 11
-            pb += P;
-            pb1 += P;
-            px += P;
+            qb[j] = rb[c_b0];                                                // b row d + 9: plain loads (b does not change) — with
+            if (kCols > kWave) qb1[j] = rb[c_b1];                            // sc1 here two workgroups sharing a CU run at half speed
+            qx[j] = lex_ld(rx + c_x);                                        // x row d + 11
+            rb += P;
+            rx += P;
             lex_lds_barrier();
         }
         st.known = max(st.known, polled);
@@ -811,11 +806,14 @@ __device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLex
     }
 }
 
+// Two workgroups share a CU only if 6 of their waves fit one SIMD (a workgroup's T + 2 = 10 waves go 3, 3, 2, 2): at
+// most 80 VGPRs; and above ~53 KB of LDS per workgroup the second one is not placed (traced block start times,
+// whatever the occupancy query says).
 template <int T, bool CHECK, bool MASKED>
-__global__ void __launch_bounds__((T + 2) * kWave)
-k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S,
-         unsigned *__restrict__ progress, unsigned *__restrict__ ticket, const unsigned *__restrict__ order,
-         double *__restrict__ edges, long edge_steps, unsigned active_mask, double *__restrict__ partial, long partial_stride)
+__device__ __forceinline__ void lex_wg_body(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S,
+                                            unsigned *__restrict__ progress, unsigned *__restrict__ ticket,
+                                            const unsigned *__restrict__ order, double *__restrict__ edges, long edge_steps,
+                                            unsigned active_mask, double *__restrict__ partial, long partial_stride)
 {
     static_assert(kLexRing == 4 && T >= 1, "the unrolled step index mod 4 is the ring slot");
     static_assert(4 * (T - 1) + 4 <= kLexBRows, "a b row stays in LDS from step r-1 to step r+4(T-1)");
@@ -852,16 +850,18 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
     // One progress word per strip, written by the storer.  The loader watches: lane 0 the left strip (edge
     // values), lanes 1 and 2 the two strips of the previous group sweep 0 reads x from.
     LexWgStrip st;
-    st.mine = progress + (((long)ch * G + grp) * S + s) * kLexWordStride;
-    st.watch = st.mine;
+    const unsigned my_word = (unsigned)((((long)ch * G + grp) * S + s) * kLexWordStride);
+    st.words = progress;
+    st.mine = progress + my_word;
+    st.watch = my_word;
     st.need_off = INT_MIN / 2;
     st.known = 0;
     if (lane == 0 && s > 0) {
-        st.watch = st.mine - kLexWordStride;
+        st.watch = my_word - kLexWordStride;
         st.need_off = 16;                                    // before block [db, db+7]: the ghost batch of block db+8
     }
     if (grp > 0 && (lane == 1 || (lane == 2 && s + 1 < S))) {
-        st.watch = progress + (((long)ch * G + grp - 1) * S + s + (lane - 1)) * kLexWordStride;
+        st.watch = (unsigned)((((long)ch * G + grp - 1) * S + s + (lane - 1)) * kLexWordStride);
         st.need_off = 19 + 4 * (T - 1);                      // x row db+18, written by sweep T-1 at step db+18+4(T-1)
     }
 
@@ -909,6 +909,29 @@ k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom
     __builtin_amdgcn_s_waitcnt(0);                                           // this wave's (write-through) stores acknowledged
     lex_lds_barrier();
     if (wv == T + 1 && lane == 0) __hip_atomic_store(st.mine, kLexDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// The kernels.  Two workgroups share a CU only if 6 of their waves fit one SIMD (a workgroup's T + 2 = 10 waves go
+// 3, 3, 2, 2): at most 80 VGPRs — the loader, which decides the count, needs 82, and is held to 80 (2 spills) where
+// sharing pays: +5..11 % on plain grids from 4096^2 up.  (Above ~53 KB of LDS per workgroup the second one is not
+// placed at all — traced block start times — whatever the occupancy query says; the rings take 42 KB.)  The
+// Dirichlet-mask variant carries three more values in the loader and loses more to the spills than it gains.
+template <int T, bool CHECK>
+__global__ void __launch_bounds__((T + 2) * kWave) __attribute__((amdgpu_waves_per_eu(6, 8)))
+k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S, unsigned *__restrict__ progress,
+         unsigned *__restrict__ ticket, const unsigned *__restrict__ order, double *__restrict__ edges, long edge_steps,
+         unsigned active_mask, double *__restrict__ partial, long partial_stride)
+{
+    lex_wg_body<T, CHECK, false>(xd, bd, g, lg, G, S, progress, ticket, order, edges, edge_steps, active_mask, partial, partial_stride);
+}
+
+template <int T, bool CHECK>
+__global__ void __launch_bounds__((T + 2) * kWave)
+k_lex_wg_masked(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S, unsigned *__restrict__ progress,
+                unsigned *__restrict__ ticket, const unsigned *__restrict__ order, double *__restrict__ edges, long edge_steps,
+                unsigned active_mask, double *__restrict__ partial, long partial_stride)
+{
+    lex_wg_body<T, CHECK, true>(xd, bd, g, lg, G, S, progress, ticket, order, edges, edge_steps, active_mask, partial, partial_stride);
 }
 
 // eps[k*channels + ch] = sum of the partials of iteration k in a fixed order.  grid = (iterations, channels)
