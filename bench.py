@@ -228,7 +228,7 @@ def config0(capi):
                       "storer wave, all passes in one launch per pass depth)", "ms": rep.seconds * 1e3,
             "pixel_updates_per_s": ups,
             "bytes_model": f"{LEX_WG_BYTES_PER_UPDATE:.2f} B per update at 8 sweeps per pass (b 76/62 x 8/8, x read 63/62 x 8/8, x write "
-                           "8/8, edge values 2 x 16/62); PMC on 16384^2: 4.33 B (profiles/r02_pmc_*_lex_wg_16384.csv)",
+                           "8/8, edge values 2 x 16/62); PMC on 16384^2: 4.2 B (profiles/r02_pmc_*_lex_wg_16384.csv)",
             "frac": ups * LEX_WG_BYTES_PER_UPDATE / 1e9 / HBM_PEAK_GBS,
             "bound_note": "not a bandwidth-bound kernel: lock-step steps of ~0.2 us (LDS round trip + barrier, tools/step_bench.hip); at "
                           "this size 10 strips x 12 passes on a critical path of ~(H + 64 + 60 strips) steps per pass",
