@@ -350,20 +350,14 @@ def main():
     halo_note = None
     solver = None
     if halo == "abi":
-        # the library's own RCCL communicator; should any rank fail to set it up, ALL ranks fall back to the
-        # torch.distributed exchange (decided together), so that a scaling run still produces its line
-        err = None
-        try:
-            solver = rowblock.make_solver(blk, rank, world, max(ghost, 2), dist, parts, H, halo="abi", overlap=not args.no_overlap)
-        except Exception as e:                                        # CcpError (CCP_ERR_RCCL ...), OSError
-            err = f"{type(e).__name__}: {e}"
-        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device="cuda")
-        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        if int(flag.item()) != 0:
-            if solver is not None:
-                solver.close()
-            solver, halo = None, "torch"
-            halo_note = f"ccp_comm_* setup failed on at least one rank ({err or 'another rank'}): torch.distributed halo exchange used instead"
+        # the library's own RCCL communicator on every rank, or — decided together, every rank walking through the
+        # same collectives whatever failed where — the torch.distributed exchange on every rank, so that a scaling
+        # run still produces its line (rowblock_abi.setup_abi_solver)
+        from coursecomputationalphotography_amd import rowblock_abi
+        solver, why = rowblock_abi.setup_abi_solver(blk, rank, world, max(ghost, 2), dist, parts, H, overlap=not args.no_overlap)
+        if solver is None:
+            halo = "torch"
+            halo_note = f"{why}: torch.distributed halo exchange used instead"
     if solver is None:
         solver = rowblock.make_solver(blk, rank, world, max(ghost, 2), dist, parts, H, halo="torch", overlap=False)
     g = blk.grid

@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "ccp_grid_sweep", "ccp_grid_sweep_edges_first", "ccp_grid_stream_wait_edges", "ccp_grid_tune", "ccp_grid_set_fused", "ccp_grid_set_tiling", "ccp_grid_get_tiling", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_gauss_seidel_lexicographic", "ccp_grid_conjugate_gradient",
     "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_assemble_from_images", "ccp_grid_store_u8",
     "ccp_grid_set_x_u8", "ccp_grid_last_timing", "ccp_grid_region_begin", "ccp_grid_region_end",
-    "ccp_comm_unique_id", "ccp_comm_create", "ccp_comm_destroy", "ccp_comm_info", "ccp_comm_all_reduce_sum", "ccp_comm_all_reduce_max",
+    "ccp_comm_probe", "ccp_comm_unique_id", "ccp_comm_create", "ccp_comm_destroy", "ccp_comm_info", "ccp_comm_all_reduce_sum", "ccp_comm_all_reduce_max",
     "ccp_grid_attach_comm", "ccp_grid_set_overlap", "ccp_grid_exchange_halos", "ccp_grid_sweep_rowblocked",
     "ccp_grid_gauss_seidel_rowblocked", "ccp_grid_residual_norm2_global", "ccp_grid_comm_stats",
 )
@@ -187,6 +187,7 @@ def load() -> C.CDLL:
     L.ccp_grid_last_timing.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i32)]
     L.ccp_grid_region_begin.argtypes = [vp]
     L.ccp_grid_region_end.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(i64), C.POINTER(i64)]
+    L.ccp_comm_probe.argtypes = [i32]
     L.ccp_comm_unique_id.argtypes = [vp]
     L.ccp_comm_create.argtypes = [vp, i32, i32, i32, C.POINTER(vp)]
     L.ccp_comm_destroy.argtypes = [vp]
@@ -233,6 +234,12 @@ def _i32(a) -> np.ndarray:
 
 
 COMM_ID_BYTES = 128
+
+
+def comm_probe(device: int = 0) -> None:
+    """Raises CcpError unless this process can take part in a communicator on `device` (not collective)."""
+    _share_rccl_with_torch()
+    check(load().ccp_comm_probe(device), "ccp_comm_probe")
 
 
 def comm_unique_id() -> bytes:

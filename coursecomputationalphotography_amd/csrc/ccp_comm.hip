@@ -2,11 +2,42 @@
 #include "ccp_comm.hpp"
 
 #include <dlfcn.h>
+#include <link.h>
 
 #include <cstring>
 #include <mutex>
+#include <set>
+#include <string>
 
 namespace ccp {
+
+namespace {
+
+// Distinct files mapped in this process whose name contains `needle` (dl_iterate_phdr).
+struct LoadedCopies {
+    const char *needle;
+    std::set<std::string> paths;
+};
+int collect_copies(struct dl_phdr_info *info, size_t, void *data)
+{
+    auto *lc = static_cast<LoadedCopies *>(data);
+    if (info->dlpi_name && std::strstr(info->dlpi_name, lc->needle)) {
+        char real[4096];
+        lc->paths.insert(realpath(info->dlpi_name, real) ? std::string(real) : std::string(info->dlpi_name));
+    }
+    return 0;
+}
+std::set<std::string> loaded_copies(const char *needle)
+{
+    LoadedCopies lc{needle, {}};
+    dl_iterate_phdr(collect_copies, &lc);
+    return lc.paths;
+}
+
+}  // namespace
+
+// Why the communicator layer is unusable ("" while it is usable); ccp_comm_probe prints it under CCP_GS_DEBUG.
+static std::string g_rccl_refusal;
 
 const RcclApi *rccl_api()
 {
@@ -16,11 +47,33 @@ const RcclApi *rccl_api()
     std::call_once(once, [] {
         // by soname: a copy already in the process wins (e.g. the one PyTorch-ROCm ships with its HIP runtime)
         const char *override_path = getenv("CCP_GS_RCCL_LIB");
-        void *h = dlopen(override_path ? override_path : "librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        // RTLD_NOLOAD first: a collective library the process already carries is THE one to use — it belongs to
+        // the HIP runtime the process runs on.  Only a process without one gets the soname lookup.
+        void *h = nullptr;
+        if (!override_path) {
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+        }
+        if (!h) h = dlopen(override_path ? override_path : "librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!h && !override_path) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!h) {
-            if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] cannot load RCCL: %s\n", dlerror());
+            const char *why = dlerror();
+            g_rccl_refusal = std::string("cannot load RCCL: ") + (why ? why : "?");
+            if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] %s\n", g_rccl_refusal.c_str());
             return;
+        }
+        // One HIP runtime and one collective library per process.  Two copies of either (say /opt/rocm's next to
+        // the ones a Python package bundles) each keep their own device state and their own exit handlers: at
+        // best the communicator runs on a runtime the grid handles do not live on, at worst the process aborts
+        // in the teardown.  Refused here, whatever order the host program loaded things in.
+        for (const char *needle : {"libamdhip64.so", "librccl.so"}) {
+            const std::set<std::string> copies = loaded_copies(needle);
+            if (copies.size() > 1) {
+                g_rccl_refusal = std::string("two copies of ") + needle + " are mapped in this process:";
+                for (const std::string &c : copies) g_rccl_refusal += " " + c;
+                if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] RCCL refused: %s\n", g_rccl_refusal.c_str());
+                return;
+            }
         }
         bool all = true;
         auto sym = [&](const char *name) -> void * {
@@ -52,6 +105,21 @@ using namespace ccp;
 extern "C" {
 
 static_assert(sizeof(ncclUniqueId) == CCP_COMM_ID_BYTES, "ccp_gs.h promises the size of ncclUniqueId");
+
+// Can this process take part in a communicator on `device`?  Not collective: a host program calls it on every
+// rank and lets the ranks agree BEFORE the collective ccp_comm_create, so that a rank without RCCL (or without
+// the device) does not leave the others waiting inside ncclCommInitRank.
+int ccp_comm_probe(int32_t device)
+try {
+    const RcclApi *api = rccl_api();
+    if (!api) {
+        if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] ccp_comm_probe: %s\n", g_rccl_refusal.c_str());
+        return CCP_ERR_RCCL;
+    }
+    int v = 0;
+    if (api->GetVersion(&v) != ncclSuccess) return CCP_ERR_RCCL;
+    return select_device(device);
+} CCP_ABI_CATCH
 
 int ccp_comm_unique_id(uint8_t *id_out)
 try {

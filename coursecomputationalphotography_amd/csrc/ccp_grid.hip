@@ -32,6 +32,13 @@ struct ccp_grid {
     unsigned long long *edge_counter = nullptr;   // device memory: kEdgeRing counters, the pass of epoch e uses slot e % kEdgeRing
     unsigned long long *edge_flag = nullptr;      // hipMallocSignalMemory
     unsigned long long edge_epoch = 0;
+    // wait_mode 1 only: the polling kernel gives up after edge_timeout_ticks (it must not hold a queue for ever
+    // when something — a profiler serialising dispatches — keeps the pass from running beside it).  Giving up
+    // lets the exchange send rows that may not be final, so the kernel records it here (host-mapped memory) and
+    // every later call on the handle, and every call that hands results to the host, fails with CCP_ERR_STATE:
+    // a lost hand-off is an error, never a silently wrong ghost row.
+    unsigned *edge_timeout = nullptr;
+    unsigned long long edge_timeout_ticks = 200000000ull;   // 100 MHz constant clock: 2 s (CCP_GS_EDGE_TIMEOUT_TICKS)
     int wait_mode = 0;                   // 0: hipStreamWaitValue64, 1: a one-wave polling kernel (CCP_GS_EDGE_WAIT=spin, or no wait-value support)
     bool edge_signal = true;             // CCP_GS_EDGE_SIGNAL=0: the flag is only published after the whole pass
     // RCCL (ccp_grid_attach_comm): neighbour ranks, the rows their ghost zones take, the stream the
@@ -55,6 +62,9 @@ struct ccp_grid {
     int live_T = -1, live_R = -1, live_lo = -1, live_hi = -1;
     long unknowns = 0;           // mask bytes set (owned rows), for the statistics
     bool fuse = true;            // use k_fused_sweep for unchecked sweeps
+    bool xcd_swizzle = false;    // CCP_GS_XCD=1: tiles of a pass in XCD-contiguous runs (measured 2-4 % slower at 16384^2: off)
+    const char *trace_file = nullptr;   // CCP_GS_TRACE_FILE: per-wave start/end stamps of every fused pass are appended here (diagnostics; syncs)
+    DevBuf<unsigned long long> trace;
     bool short_edges = true;     // chunk rows at an image edge are short (CCP_GS_SHORT_EDGES=0 turns it off)
     int side_rows_override = 0;  // CCP_GS_SIDE_ROWS
     int fuse_tmax = kFusedMaxT;  // iterations fused per launch (<= kFusedMaxT)
@@ -99,11 +109,21 @@ struct ccp_grid {
 
 namespace {
 
+// Did a polling kernel give up on the edge flag (see ccp_grid::edge_timeout)?
+int edge_timeout_status(const ccp_grid *g)
+{
+    if (g->edge_timeout && __atomic_load_n(g->edge_timeout, __ATOMIC_ACQUIRE) != 0) {
+        if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] an edge hand-off timed out: ghost rows may hold rows that were not final\n");
+        return CCP_ERR_STATE;
+    }
+    return CCP_OK;
+}
+
 int bind(ccp_grid *g)
 {
     if (!g) return CCP_ERR_BAD_ARG;
     if (hipSetDevice(g->device) != hipSuccess) return CCP_ERR_NO_DEVICE;
-    return CCP_OK;
+    return edge_timeout_status(g);
 }
 
 long sweep_blocks_x(const ccp_grid *g) { return (g->geom.pitch + (long)kBlock * g->cpt - 1) / ((long)kBlock * g->cpt); }
@@ -267,6 +287,7 @@ int launch_fused_masked(ccp_grid *g, FusedParams &P, int l1, long *l1_blocks)
     P.edge_counter = nullptr;
     P.edge_flag = nullptr;
     P.edge_target = P.edge_epoch = 0;
+    P.trace = nullptr;
     const int waves = kBlock / kWave;
     dim3 grid((unsigned)((P.n_strips + waves - 1) / waves), (unsigned)P.n_chunks, (unsigned)g->desc.channels);
     if (l1_blocks) {
@@ -318,6 +339,7 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     P.partial = g->partial.p;
     P.partial_border = g->partial.p + g->partial_region;
     P.active = active;
+    P.xcd_swizzle = g->xcd_swizzle ? 1 : 0;
     const bool want_edge = edge_rows > 0 && l1 == 0 && active == nullptr && g->edge_counter && g->edge_signal;
     P.mask = g->maskp.p;
     if (g->masked) return launch_fused_masked<T>(g, P, l1, l1_blocks);
@@ -371,6 +393,16 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
         P.edge_counter = g->edge_counter + (g->edge_epoch % kEdgeRing);
     }
     if (signalled) *signalled = edge;
+    // diagnostics: per-wave time stamps of this pass (ordinary launch first, border launch behind it)
+    const size_t trace_plain = (size_t)grid.x * grid.y * grid.z * waves * 4, trace_border = (size_t)bgrid.x * bgrid.z * waves * 4;
+    unsigned long long *trace_p = nullptr, *trace_b = nullptr;
+    if (g->trace_file) {
+        if (g->trace.n < trace_plain + trace_border) CCP_TRY(g->trace.alloc(trace_plain + trace_border));
+        CCP_HIP(hipMemsetAsync(g->trace.p, 0, (trace_plain + trace_border) * sizeof(unsigned long long), g->stream));
+        trace_p = g->trace.p;
+        trace_b = g->trace.p + trace_plain;
+    }
+    P.trace = trace_b;
     constexpr int TC = T <= kFusedMaxCheckedT ? T : 1;       // per-sweep sums exist up to kFusedMaxCheckedT
     hipStream_t bstream = g->stream2;
     // The border launch sees everything queued on the main stream so far, runs beside the ordinary
@@ -385,6 +417,7 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
         hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll, true>), bgrid, dim3(kBlock), 0, bstream, P, g->force_border ? 1 : 0);
     }
     if (any_plain) {
+        P.trace = trace_p;
         if (l1 == 2) hipLaunchKernelGGL((k_fused_sweep<TC, 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
         else if (l1 == 1) hipLaunchKernelGGL((k_fused_sweep<T, 1, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P);
         else if (edge) hipLaunchKernelGGL((k_fused_sweep<T, 0, kFusedUnroll, true>), grid, dim3(kBlock), 0, g->stream, P);
@@ -392,6 +425,7 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     }
     if (n_border) {
         const int fb = g->force_border ? 1 : 0;
+        P.trace = trace_b;
         if (l1 == 2) hipLaunchKernelGGL((k_fused_border<TC, 2, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
         else if (l1 == 1) hipLaunchKernelGGL((k_fused_border<T, 1, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
         else if (!edge) hipLaunchKernelGGL((k_fused_border<T, 0, kFusedUnroll>), bgrid, dim3(kBlock), 0, bstream, P, fb);
@@ -399,6 +433,18 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
         CCP_HIP(hipStreamWaitEvent(g->stream, g->ev_side, 0));
     }
     CCP_HIP(hipGetLastError());
+    if (g->trace_file) {
+        CCP_HIP(hipStreamSynchronize(g->stream));
+        std::vector<unsigned long long> host(trace_plain + trace_border);
+        CCP_HIP(hipMemcpy(host.data(), g->trace.p, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(g->trace_file, "ab")) {
+            const unsigned long long head[8] = {0x43435054524143ull, (unsigned long long)T, grid.x, grid.y, grid.z, bgrid.x, (unsigned long long)host.size(),
+                                                (unsigned long long)P.rows_per_chunk};
+            fwrite(head, sizeof(head), 1, f);
+            fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+            fclose(f);
+        }
+    }
     g->last_launches++;
     g->region_launches++;
     g->region_iterations += T;
@@ -425,15 +471,19 @@ __global__ void k_publish_flag(unsigned long long *flag, unsigned long long epoc
     if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_store(flag, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// One wave polling the flag (wait_mode 1).  Bounded: gives up after ~2 s of device time, so a lost
-// signal costs the overlap, never the process (the flag is always published again after the pass).
-__global__ void k_wait_flag(const unsigned long long *flag, unsigned long long epoch)
+// One wave polling the flag (wait_mode 1).  Bounded, so that it cannot hold a hardware queue for ever; a wait
+// that gives up is RECORDED in *timed_out (host-mapped) and turns into CCP_ERR_STATE on the host side — what
+// follows it on the stream may have sent rows that were not final.
+__global__ void k_wait_flag(const unsigned long long *flag, unsigned long long epoch, unsigned long long ticks, unsigned *timed_out)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < epoch) {
         __builtin_amdgcn_s_sleep(64);
-        if (wall_clock64() - t0 > 200000000ull) break;             // 100 MHz constant clock
+        if (wall_clock64() - t0 > ticks) {                         // 100 MHz constant clock
+            __hip_atomic_store(timed_out, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            break;
+        }
     }
 }
 
@@ -461,7 +511,7 @@ int edge_wait_on_stream(ccp_grid *g, hipStream_t s)
     if (g->wait_mode == 0) {
         CCP_HIP(hipStreamWaitValue64(s, g->edge_flag, g->edge_epoch, hipStreamWaitValueGte, ~0ull));
     } else {
-        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, s, g->edge_flag, g->edge_epoch);
+        hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(64), 0, s, g->edge_flag, g->edge_epoch, g->edge_timeout_ticks, g->edge_timeout);
         CCP_HIP(hipGetLastError());
     }
     return CCP_OK;
@@ -613,7 +663,7 @@ int transfer_rows(ccp_grid *g, double *dev_base, int channel, double *rows, int 
         CCP_HIP(hipStreamSynchronize(g->stream));
         done += chunk;
     }
-    return CCP_OK;
+    return edge_timeout_status(g);
 }
 
 }  // namespace
@@ -651,6 +701,8 @@ try {
     if (const char *e = getenv("CCP_GS_SHFL")) g->shfl = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SHORT_EDGES")) g->short_edges = atoi(e) != 0;
+    if (const char *e = getenv("CCP_GS_XCD")) g->xcd_swizzle = atoi(e) != 0;
+    if (const char *e = getenv("CCP_GS_TRACE_FILE")) g->trace_file = e[0] ? e : nullptr;
     if (const char *e = getenv("CCP_GS_SIDE_ROWS")) g->side_rows_override = atoi(e);
     if (const char *e = getenv("CCP_GS_LEX_MODE")) g->lex_mode = strcmp(e, "planes") == 0 ? 0 : (strcmp(e, "strips") == 0 ? 1 : (strcmp(e, "skew") == 0 ? 2 : 3));
     if (const char *e = getenv("CCP_GS_LEX_T")) g->lex_tmax = std::max(1, std::min(8, atoi(e)));
@@ -699,8 +751,11 @@ try {
         if (hipMalloc(reinterpret_cast<void **>(&g->edge_counter), sizeof(unsigned long long) * kEdgeRing) != hipSuccess ||
             hipExtMallocWithFlags(reinterpret_cast<void **>(&g->edge_flag), sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess ||
             hipMemset(g->edge_counter, 0, sizeof(unsigned long long) * kEdgeRing) != hipSuccess ||
-            hipMemset(g->edge_flag, 0, sizeof(unsigned long long)) != hipSuccess)
+            hipMemset(g->edge_flag, 0, sizeof(unsigned long long)) != hipSuccess ||
+            hipHostMalloc(reinterpret_cast<void **>(&g->edge_timeout), sizeof(unsigned), hipHostMallocMapped) != hipSuccess)
             st = CCP_ERR_HIP;
+        if (g->edge_timeout) *g->edge_timeout = 0;
+        if (const char *e = getenv("CCP_GS_EDGE_TIMEOUT_TICKS")) g->edge_timeout_ticks = strtoull(e, nullptr, 10);
     }
     if (st == CCP_OK && (hipMemset(g->x.p, 0, elems * sizeof(double)) != hipSuccess ||
                          hipMemset(g->b.p, 0, elems * sizeof(double)) != hipSuccess))
@@ -735,6 +790,7 @@ try {
     if (g->ev_ready) (void)hipEventDestroy(g->ev_ready);
     if (g->edge_counter) (void)hipFree(g->edge_counter);
     if (g->edge_flag) (void)hipFree(g->edge_flag);
+    if (g->edge_timeout) (void)hipHostFree(g->edge_timeout);
     delete g;
     return CCP_OK;
 } CCP_ABI_CATCH
@@ -763,7 +819,7 @@ int ccp_grid_synchronize(ccp_grid *g)
 try {
     CCP_TRY(bind(g));
     CCP_HIP(hipStreamSynchronize(g->stream));
-    return CCP_OK;
+    return edge_timeout_status(g);
 } CCP_ABI_CATCH
 
 int ccp_grid_set_b_host(ccp_grid *g, int32_t channel, const double *rows, int32_t first_row, int32_t n_rows)
@@ -1511,7 +1567,7 @@ int small_to_rr_bb(ccp_grid *g, double *rr_bb)
         rr_bb[ch] = host[2 * ch];
         rr_bb[C + ch] = host[2 * ch + 1];
     }
-    return CCP_OK;
+    return edge_timeout_status(g);
 }
 
 }  // namespace
@@ -1536,7 +1592,7 @@ try {
     CCP_HIP(hipGetLastError());
     CCP_HIP(hipMemcpyAsync(per_channel, g->small.p, sizeof(double) * C, hipMemcpyDeviceToHost, g->stream));
     CCP_HIP(hipStreamSynchronize(g->stream));
-    return CCP_OK;
+    return edge_timeout_status(g);
 } CCP_ABI_CATCH
 
 int ccp_grid_assemble_rhs(ccp_grid *g, const float *gx, const float *gy, int64_t row_stride_bytes, const int32_t *constraint)

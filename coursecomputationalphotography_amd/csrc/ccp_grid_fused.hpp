@@ -102,6 +102,14 @@ struct FusedParams {
     // `pitch` bytes): 1 = unknown, 0 = fixed at zero
     const unsigned char *__restrict__ mask;
     int first_edge, last_edge;
+    // Workgroups are dealt round-robin over the 8 XCDs (MI355X_MICROARCH.md, Workgroup dispatch): with
+    // xcd_swizzle every XCD walks a CONTIGUOUS run of tiles (strip groups fastest) in dispatch order, so the
+    // workgroups that share an L2 at any moment are neighbours in x and the halo columns they both read are
+    // fetched from HBM once.  Speed only: placement is never assumed for correctness.
+    int xcd_swizzle;
+    // Diagnostics (CCP_GS_TRACE_FILE): 4 words per wave — start and end time (100 MHz constant clock), HW_ID |
+    // XCC_ID << 32, and chunk | strip << 16 | channel << 32 | kernel << 40 — written by lane 0; nullptr otherwise.
+    unsigned long long *__restrict__ trace;
     unsigned long long *__restrict__ edge_counter;
     unsigned long long *__restrict__ edge_flag;
     unsigned long long edge_target, edge_epoch;
@@ -129,6 +137,45 @@ __device__ __forceinline__ void fused_signal_edge(const FusedParams &P)
         const unsigned long long old = __hip_atomic_fetch_add(P.edge_counter, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1 == P.edge_target)
             __hip_atomic_store(P.edge_flag, P.edge_epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+// The tile coordinates of this workgroup: blockIdx, or — xcd_swizzle — the id-th tile of the run of tiles its
+// XCD walks.  Block id = 8k + x goes to XCD x (observed); XCD x owns tiles [x q + min(x, r), ...) with
+// q = n / 8, r = n % 8, of which this is the k-th: a bijection of [0, n) for every n.
+__device__ __forceinline__ void fused_tile_coords(const FusedParams &P, unsigned &bx, unsigned &by, unsigned &bz)
+{
+    bx = blockIdx.x;
+    by = blockIdx.y;
+    bz = blockIdx.z;
+    if (P.xcd_swizzle) {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        const unsigned n = gx * gy * gridDim.z;
+        const unsigned id = bx + gx * (by + gy * bz);
+        const unsigned xcd = id & 7u, k = id >> 3;
+        const unsigned q = n >> 3, r = n & 7u;
+        const unsigned tile = xcd * q + (xcd < r ? xcd : r) + k;
+        bx = tile % gx;
+        const unsigned t = tile / gx;
+        by = t % gy;
+        bz = t / gy;
+    }
+}
+
+__device__ __forceinline__ void fused_trace_begin(const FusedParams &P, unsigned long long &t0)
+{
+    if (P.trace) t0 = wall_clock64();
+}
+__device__ __forceinline__ void fused_trace_end(const FusedParams &P, unsigned long long t0, long slot, int chunk, int sx, int ch, int kernel)
+{
+    if (P.trace && (threadIdx.x & (kWave - 1)) == 0) {
+        unsigned long long *r = P.trace + 4 * slot;
+        r[0] = t0;
+        r[1] = wall_clock64();
+        r[2] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11))        // HW_REG_HW_ID, 32 bits
+               | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 32);   // HW_REG_XCC_ID[3:0]
+        r[3] = (unsigned long long)(unsigned)chunk | ((unsigned long long)(unsigned)sx << 16) | ((unsigned long long)ch << 32) |
+               ((unsigned long long)kernel << 40);
     }
 }
 
@@ -482,7 +529,8 @@ __device__ __forceinline__ bool fused_is_border_tile(const FusedParams &P, int c
 }
 
 template <int L1, int AN>
-__device__ __forceinline__ void fused_write_partials(double (&acc)[AN], double *__restrict__ partial, int ch, double *scratch)
+__device__ __forceinline__ void fused_write_partials(double (&acc)[AN], double *__restrict__ partial, int ch, double *scratch,
+                                                     unsigned bx, unsigned by)
 {
     if (L1 != 0) {
         // partial[((t*channels + ch)*gridDim.y + by)*gridDim.x + bx], t = 0 for L1 = 1
@@ -490,7 +538,7 @@ __device__ __forceinline__ void fused_write_partials(double (&acc)[AN], double *
         for (int t = 0; t < AN; ++t) {
             const double total = block_sum(acc[t], scratch);
             if (threadIdx.x == 0)
-                partial[(((long)t * gridDim.z + ch) * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = total;
+                partial[(((long)t * gridDim.z + ch) * gridDim.y + by) * gridDim.x + bx] = total;
         }
     }
 }
@@ -504,9 +552,11 @@ k_fused_sweep(FusedParams P)
     __shared__ double scratch[kBlock / kWave];
     // readfirstlane: tell the compiler the wave index is uniform, so strip/row addressing is SALU
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int sx = blockIdx.x * (kBlock / kWave) + wave;
-    const int ch = blockIdx.z;
-    const int chunk = EDGE ? fused_chunk_of(P, (int)blockIdx.y) : (int)blockIdx.y;
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (!EDGE) fused_tile_coords(P, bx, by, bz);             // (an EDGE pass keeps dispatch order: its edge chunks go first)
+    const int sx = (int)bx * (kBlock / kWave) + wave;
+    const int ch = (int)bz;
+    const int chunk = EDGE ? fused_chunk_of(P, (int)by) : (int)by;
     int ra, rb;
     fused_chunk_rows(P, chunk, ra, rb);
     constexpr int AN = L1 == 2 ? T : 1;
@@ -517,10 +567,13 @@ k_fused_sweep(FusedParams P)
     if (run && sx < P.n_strips && ra < rb && !fused_is_border_tile(P, chunk, sx)) {
         const Geom &g = P.g;
         const long off = (long)ch * g.ch_stride;
+        unsigned long long t0 = 0;
+        fused_trace_begin(P, t0);
         fused_wave<T, false, L1, UNR, AN>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc);
         if (EDGE && fused_is_edge_chunk(P, chunk)) fused_signal_edge(P);
+        fused_trace_end(P, t0, (((long)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * (kBlock / kWave) + wave, chunk, sx, ch, 0);
     }
-    fused_write_partials<L1, AN>(acc, P.partial, ch, scratch);
+    fused_write_partials<L1, AN>(acc, P.partial, ch, scratch, bx, by);
 }
 
 // Dirichlet-mask grid: every tile is an ordinary tile (rows and columns outside the block read as zero
@@ -540,9 +593,11 @@ k_fused_sweep_masked(FusedParams P, const unsigned char *__restrict__ tile_live)
 {
     __shared__ double scratch[kBlock / kWave];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int sx = blockIdx.x * (kBlock / kWave) + wave;
-    const int ch = blockIdx.z;
-    const int chunk = blockIdx.y;
+    unsigned bx, by, bz;
+    fused_tile_coords(P, bx, by, bz);
+    const int sx = (int)bx * (kBlock / kWave) + wave;
+    const int ch = (int)bz;
+    const int chunk = (int)by;
     int ra, rb;
     fused_chunk_rows(P, chunk, ra, rb);
     constexpr int AN = L1 == 2 ? T : 1;
@@ -555,7 +610,7 @@ k_fused_sweep_masked(FusedParams P, const unsigned char *__restrict__ tile_live)
         const long off = (long)ch * g.ch_stride;
         fused_wave<T, false, L1, UNR, AN, true>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc, false, P.mask);
     }
-    fused_write_partials<L1, AN>(acc, P.partial, ch, scratch);
+    fused_write_partials<L1, AN>(acc, P.partial, ch, scratch, bx, by);
 }
 
 // tile_live[chunk * n_strips + strip] = does the tile's extended region (its rows and columns plus the 2T
@@ -623,11 +678,15 @@ k_fused_border(FusedParams P, int force_border)
         if (ra < rb) {
             const Geom &g = P.g;
             const long off = (long)ch * g.ch_stride;
+            unsigned long long t0 = 0;
+            fused_trace_begin(P, t0);
             fused_wave<T, true, L1, UNR, AN>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc, force_border != 0);
             if (EDGE && fused_is_edge_chunk(P, chunk)) fused_signal_edge(P);
+            // (the border launch's records follow the ordinary launch's: P.trace is offset by the host)
+            fused_trace_end(P, t0, ((long)blockIdx.z * gridDim.x + blockIdx.x) * (kBlock / kWave) + wave, chunk, sx, ch, id < n_full ? 1 : 2);
         }
     }
-    fused_write_partials<L1, AN>(acc, P.partial_border, ch, scratch);
+    fused_write_partials<L1, AN>(acc, P.partial_border, ch, scratch, blockIdx.x, blockIdx.y);
 }
 
 }  // namespace ccp

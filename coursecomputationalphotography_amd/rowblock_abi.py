@@ -54,3 +54,61 @@ class AbiRowBlockSolver:
             self.block.grid.attach_comm(None)
             self.comm.close()
             self.comm = None
+
+
+def _all_ok(dist, ok: bool, group=None) -> bool:
+    """True iff EVERY rank reports ok: one all-reduce every rank takes part in, whatever it found."""
+    import torch
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    flag = torch.tensor([0 if ok else 1], dtype=torch.int32, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    return int(flag.item()) == 0
+
+
+def setup_abi_solver(block, rank: int, world: int, ghost: int, dist, parts, height: int, overlap: bool = True,
+                     group=None, capi_module=None):
+    """The library's own communicator on every rank — or on none.  Returns (solver, None) or (None, reason).
+
+    Every rank walks through the SAME sequence of torch.distributed collectives whatever fails where, so a rank
+    that cannot load RCCL (or whose id creation fails) never leaves the others inside a mismatched collective:
+      1. rank 0 creates the id — or a `None` sentinel — and the broadcast ALWAYS runs;
+      2. every rank probes (ccp_comm_probe: RCCL loadable, device selectable; not collective) and the ranks agree;
+      3. only then the collective ccp_comm_create (ncclCommInitRank) + ccp_grid_attach_comm, and the ranks agree again.
+    `capi_module`: test seam (a stand-in for coursecomputationalphotography_amd.capi)."""
+    capi = capi_module
+    if capi is None:
+        from . import capi
+    err = None
+    uid = None
+    if rank == 0:
+        try:
+            uid = capi.comm_unique_id()
+        except Exception as e:                                    # CcpError (CCP_ERR_RCCL ...), OSError
+            err = f"{type(e).__name__}: {e}"
+    box = [uid]
+    if world > 1:
+        dist.broadcast_object_list(box, src=0, group=group)      # always: the id or the sentinel
+    uid = box[0]
+    if uid is None and err is None:
+        err = "rank 0 could not create the communicator id"
+    if err is None:
+        try:
+            capi.comm_probe(block.grid.desc.device)
+        except Exception as e:
+            err = f"{type(e).__name__}: {e}"
+    if world > 1 and not _all_ok(dist, err is None, group):
+        return None, f"ccp_comm_* unavailable on at least one rank ({err or 'another rank'})"
+    if err is not None:
+        return None, err
+    solver = None
+    try:
+        solver = AbiRowBlockSolver(block, rank, world, ghost, dist, parts, height, overlap=overlap, unique_id=uid)
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    if world > 1 and not _all_ok(dist, err is None, group):
+        if solver is not None:
+            solver.close()
+        return None, f"ccp_comm_create / ccp_grid_attach_comm failed on at least one rank ({err or 'another rank'})"
+    if err is not None:
+        return None, err
+    return solver, None

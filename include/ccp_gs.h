@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCP_GS_ABI_VERSION 2
+#define CCP_GS_ABI_VERSION 3
 
 typedef enum ccp_status {
     CCP_OK = 0,
@@ -314,6 +314,10 @@ int ccp_grid_conjugate_gradient(ccp_grid *g, double epsilon, int32_t max_iterati
  * RCCL is bound at run time (librccl.so.1); CCP_ERR_RCCL reports a missing library or a failed call. */
 #define CCP_COMM_ID_BYTES 128
 typedef struct ccp_comm ccp_comm;
+/* Can this process take part in a communicator on `device` (RCCL loadable — exactly one copy of it and of the
+ * HIP runtime mapped in the process — and the device selectable)?  Not collective: call it on every rank and let
+ * the ranks agree before the collective ccp_comm_create.  CCP_OK / CCP_ERR_RCCL / CCP_ERR_NO_DEVICE. */
+int ccp_comm_probe(int32_t device);
 int ccp_comm_unique_id(uint8_t *id_out /* CCP_COMM_ID_BYTES */);
 int ccp_comm_create(const uint8_t *id /* CCP_COMM_ID_BYTES */, int32_t rank, int32_t world, int32_t device, ccp_comm **out);
 int ccp_comm_destroy(ccp_comm *c);
@@ -339,7 +343,11 @@ int ccp_grid_gauss_seidel_rowblocked(ccp_grid *g, double epsilon, int32_t max_it
 /* ccp_grid_residual_norm2 summed over all blocks (refreshes stale ghost rows first).  Collective. */
 int ccp_grid_residual_norm2_global(ccp_grid *g, double *rr_bb);
 /* Statistics: exchanges issued; how the exchange waits for the edge rows (0 hipStreamWaitValue64, 1 polling
- * kernel, -1 no neighbours); rows sent up / down per exchange.  Outputs may be NULL. */
+ * kernel, -1 no neighbours); rows sent up / down per exchange.  Outputs may be NULL.
+ * The polling kernel (mode 1) is bounded (2 s of device time): should it ever give up, the rows it was
+ * guarding may have travelled before they were final, and EVERY later call on the handle — in particular
+ * every call that hands results to the host — returns CCP_ERR_STATE.  A lost hand-off is an error, never a
+ * silently wrong ghost row. */
 int ccp_grid_comm_stats(ccp_grid *g, int64_t *exchanges, int32_t *wait_mode, int32_t *send_up_rows, int32_t *send_down_rows);
 
 /* Per-channel sums over the OWNED rows: rr = sum (b - A x)^2, bb = sum b^2 (2*channels

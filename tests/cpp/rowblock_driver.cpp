@@ -11,6 +11,9 @@
 // ccp_grid_gauss_seidel_rowblocked and prints one line:
 //   rank R rows [a,b) iterations K converged C l1 <step> rr <sum> bb <sum> abs <sum over owned rows of |x|>
 // The sums rr, bb are global (all-reduced inside the library); abs is local.
+//
+// rank = -1: ALL ranks as threads of this one process (one handle pair per host thread, as the ABI asks) —
+// with CCP_GS_RCCL_LIB=tests/cpp/libfake_rccl.so that is how a one-GPU test box runs the multi-rank path.
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -30,10 +33,17 @@
         }                                                                                     \
     } while (0)
 
+struct Args {
+    int world, W, H, ghost, iters, check_every;
+    double epsilon;
+};
+
+static int run_rank(const Args &a, int rank, int device, const uint8_t *id);
+
 int main(int argc, char **argv)
 {
     if (argc < 8) {
-        std::fprintf(stderr, "usage: rowblock_driver world rank id-file W H ghost iterations [check_every] [epsilon]\n");
+        std::fprintf(stderr, "usage: rowblock_driver world rank|-1 id-file W H ghost iterations [check_every] [epsilon]\n");
         return 64;
     }
     const int world = std::atoi(argv[1]), rank = std::atoi(argv[2]);
@@ -41,14 +51,25 @@ int main(int argc, char **argv)
     const int W = std::atoi(argv[4]), H = std::atoi(argv[5]), ghost = std::atoi(argv[6]), iters = std::atoi(argv[7]);
     const int check_every = argc > 8 ? std::atoi(argv[8]) : 0;
     const double epsilon = argc > 9 ? std::atof(argv[9]) : 0.0;
+    const Args args{world, W, H, ghost, iters, check_every, epsilon};
     const int n_dev = ccp_device_count();
     if (n_dev < 1) {
         std::fprintf(stderr, "no HIP device: this path has no CPU fallback\n");
         return 2;
     }
-    const int device = rank % n_dev;
 
     uint8_t id[CCP_COMM_ID_BYTES];
+    if (rank < 0) {
+        // every rank a thread of this process
+        OK(ccp_comm_unique_id(id));
+        std::vector<int> rc((size_t)world, 0);
+        std::vector<std::thread> ts;
+        for (int r = 0; r < world; ++r) ts.emplace_back([&, r] { rc[(size_t)r] = run_rank(args, r, r % n_dev, id); });
+        for (auto &t : ts) t.join();
+        for (int r = 0; r < world; ++r)
+            if (rc[(size_t)r] != 0) return rc[(size_t)r];
+        return 0;
+    }
     if (rank == 0) {
         OK(ccp_comm_unique_id(id));
         const std::string tmp = id_file + ".tmp";
@@ -63,6 +84,13 @@ int main(int argc, char **argv)
         if (!f || std::fread(id, 1, sizeof(id), f) != sizeof(id)) return 4;
         std::fclose(f);
     }
+    return run_rank(args, rank, rank % n_dev, id);
+}
+
+static int run_rank(const Args &a, int rank, int device, const uint8_t *id)
+{
+    const int world = a.world, W = a.W, H = a.H, ghost = a.ghost, iters = a.iters, check_every = a.check_every;
+    const double epsilon = a.epsilon;
     ccp_comm *comm = nullptr;
     OK(ccp_comm_create(id, rank, world, device, &comm));
 
