@@ -52,7 +52,7 @@ MIN_BYTES_PER_PIXEL_PASS = 20.0  # what an unchecked pass must move: black x 4 +
 # MI355X for this shape, pinned so that every run uses the tiling the committed PMC traffic profile and the
 # full-width oracle test (tests/test_gpu_fullsize.py) were made with.  --tune re-times it on the box.
 DEFAULT_TILING = {(16384, 16384, 1): (8, 364)}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "r03_traffic.json"), os.path.join(ROOT, "profiles", "r02_traffic.json")]
 
 
 def parse():
@@ -82,8 +82,10 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs[0], [1], [4] (N=1)")
     ap.add_argument("--reference-order-iters", type=int, default=128)
     ap.add_argument("--converge-cap", type=int, default=6000)
-    ap.add_argument("--cpu-sample", type=int, default=4096, help="edge of the CPU baseline sample grid")
-    ap.add_argument("--cpu-iters", type=int, default=96, help="CPU baseline sweeps (about 15 s of host time at the default sample)")
+    ap.add_argument("--cpu-sample", type=int, default=16384,
+                    help="edge of the CPU baseline grid: the headline system itself by default (needs ~45 GB of host memory; "
+                         "a 4096^2 sample is timed instead where less than 80 GB is available)")
+    ap.add_argument("--cpu-iters", type=int, default=0, help="CPU baseline sweeps (default: 3 at 16384^2, 96 at the 4096^2 sample)")
     return ap.parse_args()
 
 
@@ -99,24 +101,62 @@ def cpu_gs_timed(v, c, r, b, iters):
         return "port", time.perf_counter() - t0
 
 
+def mem_available_gb():
+    try:
+        with open("/proc/meminfo") as fh:
+            for line in fh:
+                if line.startswith("MemAvailable:"):
+                    return int(line.split()[1]) / 1048576.0
+    except OSError:
+        pass
+    return 0.0
+
+
 def cpu_baseline(sample: int, iters: int):
-    """Reference gaussSeidel (lexicographic, single thread by construction) on a sample grid."""
+    """Reference gaussSeidel (lexicographic, single thread by construction): by default on the headline system
+    itself — 16384^2, 3 sweeps, as BASELINE.md section 3 plans — built by the oracle's closed-form generator
+    (orc_poisson_csr) with b = A x_true as everywhere else; on hosts with less memory a 4096^2 sample."""
+    import oracle
     from coursecomputationalphotography_amd import synth
-    v, c, r = synth.poisson_csr(sample, sample)
-    b, _ = synth.poisson_system(sample, sample, 1234)
+    note = ""
+    if sample > 8192 and mem_available_gb() < 80.0:
+        note = f" (a {sample}^2 system needs ~45 GB of host memory, {mem_available_gb():.0f} GB available: sample instead)"
+        sample = 4096
+    if iters <= 0:
+        iters = 3 if sample > 8192 else 96
+    t0 = time.perf_counter()
+    v, c, r = oracle.Oracle().poisson_csr(sample, sample)
+    b = synth.poisson_apply(sample, sample, synth.x_true(sample * sample, 1234))
+    setup = time.perf_counter() - t0
     kind, secs = cpu_gs_timed(v, c, r, b, iters)
-    return {"value": sample * sample * iters / secs, "unit": "pixel-updates/s", "cores": 1, "kind": kind,
+    return {"value": float(sample) * sample * iters / secs, "unit": "pixel-updates/s", "cores": 1, "kind": kind,
             "host_cores_available": os.cpu_count(),
-            "sample": f"{sample}x{sample} single-channel Poisson, {iters} lexicographic iterations, "
-                      f"{secs:.2f} s inside gaussSeidel (sweep is serial by construction)"}
+            "sample": f"{sample}x{sample} single-channel Poisson{' (the headline system itself)' if sample == 16384 else ''}, "
+                      f"{iters} lexicographic iterations, {secs:.2f} s inside gaussSeidel (sweep is serial by construction; "
+                      f"{setup:.1f} s to build the system on the host){note}"}
 
 
 def load_traffic(key):
-    try:
-        with open(TRAFFIC_FILE) as fh:
-            return json.load(fh).get(key)
-    except (OSError, ValueError):
-        return None
+    for path in TRAFFIC_FILES:
+        try:
+            with open(path) as fh:
+                hit = json.load(fh).get(key)
+        except (OSError, ValueError):
+            hit = None
+        if hit:
+            return hit
+    return None
+
+
+def traffic_fields(key, seconds_per_launch):
+    """`traffic` of a configs[] kernel from the committed PMC summaries (HBM bytes per launch), or nulls."""
+    tr = load_traffic(key)
+    if not tr:
+        return {"traffic": None, "traffic_key": key}
+    t = tr["hbm_bytes_per_launch"]
+    return {"traffic": t, "traffic_key": key, "traffic_source": tr["source"],
+            "traffic_gbs": t / seconds_per_launch / 1e9 if seconds_per_launch > 0 else None,
+            "traffic_frac_of_peak": t / seconds_per_launch / 1e9 / HBM_PEAK_GBS if seconds_per_launch > 0 else None}
 
 
 def roofline_of_pass(W, rows, C, T, R, ms_per_launch, value, world):
@@ -289,6 +329,27 @@ def config4(capi):
     x8, _ = m.gauss_seidel(b, 0.0, 8, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
     m.close()
     csr_bytes = 12.0 * nnz + 32.0 * n
+    # the same matrix on the GENERAL path (what BASELINE configs[4] names: sliced-ELL images of the stored matrix,
+    # colour-ordered sweep), the recognition switched off for this handle (CCP_GS_MASKED=0 is read at create)
+    sell = None
+    try:
+        os.environ["CCP_GS_MASKED"] = "0"
+        ms_ = capi.CsrMatrix()
+        os.environ.pop("CCP_GS_MASKED", None)
+        ms_.upload_compressed(v, c, r)
+        ms_.set_colouring(colour, 2)
+        ms_.gauss_seidel(b, 0.0, 2, check_every=0)                        # builds the schedule
+        xs, reps = ms_.gauss_seidel(b, 0.0, iters, check_every=0)
+        sell = {"path": ms_.last_path(), "ms_per_iteration": reps.seconds * 1e3 / iters, "row_updates_per_s": n * iters / reps.seconds,
+                "bytes_model": "SURVEY §8d CSR model: 12 B per stored entry + 32 B per row", "bytes_per_iteration": csr_bytes,
+                "achieved_gbs": csr_bytes * iters / reps.seconds / 1e9, "frac": csr_bytes * iters / reps.seconds / 1e9 / HBM_PEAK_GBS,
+                "same_bits_as_region_grid": bool(np.array_equal(xs, x)),
+                **traffic_fields("sell_mask_8192", reps.seconds / (2 * iters))}
+        ms_.close()
+    except Exception as e:                                               # an extra must never cost the line
+        sell = {"error": f"{type(e).__name__}: {e}"}
+    finally:
+        os.environ.pop("CCP_GS_MASKED", None)
     ups = n * iters / rep.seconds
     if path.startswith("region grid"):
         # recognised as the Laplacian of a raster region: swept matrix-free by the Dirichlet-mask grid.  Bytes an
@@ -307,6 +368,8 @@ def config4(capi):
                         "5-point Laplacian restricted to the mask, 2-colour Gauss-Seidel",
             "path": path, "ms_per_iteration": rep.seconds * 1e3 / iters, "iters": iters, "row_updates_per_s": ups,
             "bytes_model": model_txt, "frac": frac,
+            **(traffic_fields("region_grid_mask_8192", rep.seconds / max(passes, 1)) if path.startswith("region grid") else {}),
+            "general_csr_path": sell,
             "csr_model_bytes_per_iteration": csr_bytes,
             "x_over_csr_streaming_roofline": csr_bytes * iters / rep.seconds / 1e9 / HBM_PEAK_GBS,
             "rel_residual_after": float(np.sqrt(rr / bb)),

@@ -20,7 +20,7 @@ struct CgState {
     int active;
     int converged;
     int iterations;      // the reference's `cnt`
-    int pad;
+    int pcur;            // fused loop: which of the two direction buffers holds the current p
     double rlen;         // r'r of the current residual
     double alpha;
     double beta;
@@ -131,6 +131,102 @@ k_cg_direction(double *__restrict__ p, const double *__restrict__ r, long n, con
     const double beta = st->beta;
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock)
         p[i] = r[i] + beta * p[i];
+}
+
+// ---- fused loop (matrix-free grid path): 72 B per unknown and iteration instead of 88 -------------------------
+// The three vector passes of an iteration are folded into the two that have to exist:
+//   A(k)  [apply(...), supplied by the caller]   x += alpha_{k-1} p_{k-1};  p_k = r + beta_{k-1} p_{k-1};  Ap = A p_k
+//                                                (p_k of the four neighbours recomputed from r and p_{k-1});
+//                                                partial sums of p_k'Ap.   x rw 16 + r 8 + p r/w 16 + Ap w 8 = 48 B
+//   B(k)  k_cg_residual                          r += (-alpha_k) Ap;  partial sums of r'r.          r rw 16 + Ap 8 = 24 B
+// The same operations on the same operands in the same order as the unfused loop — x's update merely waits for the
+// next pass over p, the last one is applied by k_cg_axpy_final — so the iterates are the unfused loop's bit for bit.
+// p is double-buffered: a neighbour's p_{k-1} must still be readable while another workgroup stores its p_k.
+static __global__ void __launch_bounds__(kBlock)
+k_cg_alpha_fused(const double *__restrict__ partial, int count, int k, CgState *__restrict__ st)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const double pap = reduce_partials(partial, count, scratch);
+    if (threadIdx.x == 0 && st->active) {
+        st->alpha = st->rlen / pap;                       // (sparse-matrix.h:420)
+        st->pcur = k & 1;
+    }
+}
+
+static __global__ void __launch_bounds__(kBlock)
+k_cg_residual(double *__restrict__ r, const double *__restrict__ ap, long n, double *__restrict__ partial, const CgState *__restrict__ st)
+{
+    __shared__ double scratch[kBlock / kWave];
+    double acc = 0.0;
+    if (st->active) {
+        const double nalpha = -st->alpha;
+        // (k_cg_update's traversal: which thread sums which elements decides the bits of r'r)
+        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) {
+            const double v = r[i] + nalpha * ap[i];      // (:422)
+            r[i] = v;
+            acc += v * v;                                 // (:423)
+        }
+    }
+    const double t = block_sum(acc, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t;
+}
+
+// the x update the loop still owes: x += alpha_K p_K (:421 of the last iteration that ran)
+static __global__ void __launch_bounds__(kBlock)
+k_cg_axpy_final(double *__restrict__ x, const double *__restrict__ p0, const double *__restrict__ p1, long n, const CgState *__restrict__ st)
+{
+    const double alpha = st->alpha;
+    const double *__restrict__ p = st->pcur ? p1 : p0;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) x[i] = x[i] + alpha * p[i];
+}
+
+// `apply(x, r, p_in, p_out, ap, &n_partials)` enqueues A(k); n is even (whole colour half-rows).
+template <typename Spmv, typename Apply>
+int cg_solve_fused(Spmv &&spmv, Apply &&apply, const double *b, double *x, double *r, double *p0, double *p1, double *ap, long n,
+                   double epsilon, int max_iteration, CgState *st_dev, double *partial, hipStream_t stream, hipEvent_t ev0,
+                   hipEvent_t ev1, ccp_gs_report *report)
+{
+    const int blocks = (int)std::max<long>(1, std::min<long>(2048, (n + kBlock - 1) / kBlock));
+    CgState host{};
+    host.active = 1;                                                         // alpha = beta = 0: A(1) leaves x alone, p_1 = r
+    CCP_HIP(hipMemcpyAsync(st_dev, &host, sizeof(host), hipMemcpyHostToDevice, stream));
+    CCP_HIP(hipEventRecord(ev0, stream));
+    CCP_TRY(spmv(x, r));                                                     // r = A x      (:406)
+    hipLaunchKernelGGL(k_cg_init, dim3(blocks), dim3(kBlock), 0, stream, b, r, p0, n, partial);   // r = b - r, p = r
+    hipLaunchKernelGGL(k_cg_set_rlen, dim3(1), dim3(kBlock), 0, stream, partial, blocks, st_dev);
+    CCP_HIP(hipGetLastError());
+    int issued = 0;
+    bool active = max_iteration > 0 && n > 0;
+    while (active && issued < max_iteration) {
+        const int batch = std::min(16, max_iteration - issued);
+        for (int k = issued + 1; k <= issued + batch; ++k) {
+            int dot_blocks = 0;
+            double *p_in = (k & 1) ? p0 : p1, *p_out = (k & 1) ? p1 : p0;    // iteration k reads buffer (k-1)&1, writes k&1
+            CCP_TRY(apply(x, r, p_in, p_out, ap, &dot_blocks));
+            hipLaunchKernelGGL(k_cg_alpha_fused, dim3(1), dim3(kBlock), 0, stream, partial, dot_blocks, k, st_dev);
+            hipLaunchKernelGGL(k_cg_residual, dim3(blocks), dim3(kBlock), 0, stream, r, ap, n, partial, st_dev);
+            hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(kBlock), 0, stream, partial, blocks, epsilon, st_dev);
+        }
+        CCP_HIP(hipGetLastError());
+        issued += batch;
+        CCP_HIP(hipMemcpyAsync(&host, st_dev, sizeof(host), hipMemcpyDeviceToHost, stream));
+        CCP_HIP(hipStreamSynchronize(stream));
+        active = host.active != 0;
+    }
+    hipLaunchKernelGGL(k_cg_axpy_final, dim3(blocks), dim3(kBlock), 0, stream, x, p0, p1, n, st_dev);
+    CCP_HIP(hipGetLastError());
+    CCP_HIP(hipEventRecord(ev1, stream));
+    CCP_HIP(hipMemcpyAsync(&host, st_dev, sizeof(host), hipMemcpyDeviceToHost, stream));
+    CCP_HIP(hipStreamSynchronize(stream));
+    if (report) {
+        float ms = 0.f;
+        CCP_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        report->iterations = host.iterations;
+        report->converged = host.converged;
+        report->last_l1_step = host.r1norm;
+        report->seconds = ms * 1e-3;
+    }
+    return CCP_OK;
 }
 
 // The loop.  `spmv(in, out)` enqueues out := A in on `stream` (all device pointers);

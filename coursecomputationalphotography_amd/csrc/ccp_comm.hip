@@ -49,13 +49,22 @@ const RcclApi *rccl_api()
         const char *override_path = getenv("CCP_GS_RCCL_LIB");
         // RTLD_NOLOAD first: a collective library the process already carries is THE one to use — it belongs to
         // the HIP runtime the process runs on.  Only a process without one gets the soname lookup.
+        //
+        // RTLD_LOCAL, never RTLD_GLOBAL.  RCCL pulls in librocm_smi64.so, which exports C++ globals
+        // (amd::smi::Device::devInfoTypesStrings, a std::map) that libamd_smi.so — loaded by PyTorch-ROCm when it is
+        // imported — exports as well.  With librocm_smi64 in the GLOBAL lookup scope, libamd_smi's references bind to
+        // librocm_smi64's instance: both libraries' static initialisers construct the one map, both exit handlers
+        // destroy it, and the process dies at exit with "double free or corruption (!prev)" inside
+        // std::map<amd::smi::DevInfoTypes, char const*>::~map() (round 2's gpurun_out/exit_v4.txt; stack and library
+        // list taken with rocgdb: tools/exit_probe.py, profiles/r03_exit_probe.txt).  Only dlsym() on this handle is
+        // ever needed, so nothing has to be global.
         void *h = nullptr;
         if (!override_path) {
-            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
-            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
+            h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+            if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
         }
-        if (!h) h = dlopen(override_path ? override_path : "librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-        if (!h && !override_path) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen(override_path ? override_path : "librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h && !override_path) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
         if (!h) {
             const char *why = dlerror();
             g_rccl_refusal = std::string("cannot load RCCL: ") + (why ? why : "?");

@@ -1088,8 +1088,12 @@ try {
                 if (!nz) continue;
                 std::memcpy(&m->col[m->row_ptr[i]], col_offset + row_begin[i], sizeof(int32_t) * (size_t)nz);
                 std::memcpy(&m->val[m->row_ptr[i]], values + row_begin[i], sizeof(double) * (size_t)nz);
+                // columns in range and STRICTLY increasing within a row, as the reference keeps them (at() is a binary
+                // search, sparse-matrix.h:627-645): insert() relies on it (lower_bound) and so does the recognition of
+                // region matrices (a duplicated coupling would be counted twice)
                 for (long k = m->row_ptr[i]; k < m->row_ptr[i + 1]; ++k)
-                    if (m->col[k] < 0 || m->col[k] >= n_cols) bad.store(1, std::memory_order_relaxed);
+                    if (m->col[k] < 0 || m->col[k] >= n_cols || (k > m->row_ptr[i] && m->col[k] <= m->col[k - 1]))
+                        bad.store(1, std::memory_order_relaxed);
             }
         });
         if (bad.load()) return CCP_ERR_BAD_ARG;
@@ -1115,6 +1119,9 @@ try {
     if (const char *e = getenv("CCP_GS_MASKED")) m->allow_region = atoi(e) != 0;
     if (m->grid) ccp_grid_destroy(m->grid);
     m->grid = nullptr;
+    if (m->region_grid) ccp_grid_destroy(m->region_grid);      // canvas-sized buffers of the previous matrix (GBs at 8192^2)
+    m->region_grid = nullptr;
+    m->region_wants_two_colouring = false;
     if (const char *e = getenv("CCP_GS_STRUCTURED")) m->allow_structured = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_ONE_BLOCK")) m->allow_one_block = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_PIPELINE")) m->allow_pipeline = atoi(e) != 0;

@@ -3,6 +3,7 @@
 #include "ccp_grid_fused.hpp"
 #include "ccp_grid_lex.hpp"
 #include "ccp_cg.hpp"
+#include "ccp_grid_cg.hpp"
 #include "ccp_comm.hpp"
 
 #include <algorithm>
@@ -32,11 +33,12 @@ struct ccp_grid {
     unsigned long long *edge_counter = nullptr;   // device memory: kEdgeRing counters, the pass of epoch e uses slot e % kEdgeRing
     unsigned long long *edge_flag = nullptr;      // hipMallocSignalMemory
     unsigned long long edge_epoch = 0;
-    // wait_mode 1 only: the polling kernel gives up after edge_timeout_ticks (it must not hold a queue for ever
-    // when something — a profiler serialising dispatches — keeps the pass from running beside it).  Giving up
-    // lets the exchange send rows that may not be final, so the kernel records it here (host-mapped memory) and
-    // every later call on the handle, and every call that hands results to the host, fails with CCP_ERR_STATE:
-    // a lost hand-off is an error, never a silently wrong ghost row.
+    // Bounded device-side waits record giving up here (host-mapped memory): the polling kernel of wait_mode 1, which
+    // gives up after edge_timeout_ticks (it must not hold a queue for ever when something — a profiler serialising
+    // dispatches — keeps the pass from running beside it) and so lets the exchange send rows that may not be final;
+    // and a wave of k_fused_multi whose input tiles never completed.  Every later call on the handle, and every call
+    // that hands results to the host, then fails with CCP_ERR_STATE: a lost hand-off is an error, never a silently
+    // wrong row.
     unsigned *edge_timeout = nullptr;
     unsigned long long edge_timeout_ticks = 200000000ull;   // 100 MHz constant clock: 2 s (CCP_GS_EDGE_TIMEOUT_TICKS)
     int wait_mode = 0;                   // 0: hipStreamWaitValue64, 1: a one-wave polling kernel (CCP_GS_EDGE_WAIT=spin, or no wait-value support)
@@ -51,7 +53,7 @@ struct ccp_grid {
     bool overlap = true;                 // exchange beside the rest of the last pass (ccp_grid_set_overlap)
     long exchanges = 0;                  // halo exchanges issued (statistics)
     DevBuf<double> x, b;
-    DevBuf<double> cg_r, cg_p, cg_ap;   // conjugate-gradient work vectors, one channel each
+    DevBuf<double> cg_r, cg_p, cg_p2, cg_ap;   // conjugate-gradient work vectors, one channel each (p double-buffered: fused loop)
     DevBuf<CgState> cg_state;
     DevBuf<double> x_alt;        // ping-pong partner of x for the temporally blocked sweep
     // Dirichlet-mask grid (CCP_GRID_DIRICHLET_MASK): uniform 5-point stencil on the pixels whose mask byte
@@ -62,6 +64,8 @@ struct ccp_grid {
     int live_T = -1, live_R = -1, live_lo = -1, live_hi = -1;
     long unknowns = 0;           // mask bytes set (owned rows), for the statistics
     bool fuse = true;            // use k_fused_sweep for unchecked sweeps
+    int multi = 0;               // CCP_GS_MULTI=1: consecutive passes of equal depth as ONE launch (k_fused_multi)
+    DevBuf<unsigned> multi_words; // its ticket and per-tile completion counters
     bool xcd_swizzle = false;    // CCP_GS_XCD=1: tiles of a pass in XCD-contiguous runs (measured 2-4 % slower at 16384^2: off)
     const char *trace_file = nullptr;   // CCP_GS_TRACE_FILE: per-wave start/end stamps of every fused pass are appended here (diagnostics; syncs)
     DevBuf<unsigned long long> trace;
@@ -269,6 +273,23 @@ void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P, int edge_rows =
     }
 }
 
+// Which tiles of a Dirichlet-mask grid hold unknowns: one census per tiling (depth, chunk rows, row range).
+int masked_tile_census(ccp_grid *g, const FusedParams &P, int T)
+{
+    if (g->live_T != T || g->live_R != P.rows_per_chunk || g->live_lo != P.st_lo || g->live_hi != P.st_hi) {
+        const size_t tiles = (size_t)P.n_chunks * P.n_strips;
+        if (g->tile_live.n < tiles) CCP_TRY(g->tile_live.alloc(tiles));
+        hipLaunchKernelGGL(k_masked_tile_census, dim3((unsigned)P.n_strips, (unsigned)P.n_chunks), dim3(kWave), 0, g->stream, P, T,
+                           g->tile_live.p);
+        CCP_HIP(hipGetLastError());
+        g->live_T = T;
+        g->live_R = P.rows_per_chunk;
+        g->live_lo = P.st_lo;
+        g->live_hi = P.st_hi;
+    }
+    return CCP_OK;
+}
+
 // One pass of depth T over a Dirichlet-mask grid: every tile is an ordinary tile (zero lies outside the block
 // as it does outside the region), tiles without any unknown in reach leave at once.
 template <int T>
@@ -294,18 +315,7 @@ int launch_fused_masked(ccp_grid *g, FusedParams &P, int l1, long *l1_blocks)
         l1_blocks[0] = (long)grid.x * grid.y;
         l1_blocks[1] = 0;
     }
-    // which tiles hold unknowns: one census per tiling (depth, chunk rows, row range)
-    if (g->live_T != T || g->live_R != P.rows_per_chunk || g->live_lo != P.st_lo || g->live_hi != P.st_hi) {
-        const size_t tiles = (size_t)P.n_chunks * P.n_strips;
-        if (g->tile_live.n < tiles) CCP_TRY(g->tile_live.alloc(tiles));
-        hipLaunchKernelGGL(k_masked_tile_census, dim3((unsigned)P.n_strips, (unsigned)P.n_chunks), dim3(kWave), 0, g->stream, P, T,
-                           g->tile_live.p);
-        CCP_HIP(hipGetLastError());
-        g->live_T = T;
-        g->live_R = P.rows_per_chunk;
-        g->live_lo = P.st_lo;
-        g->live_hi = P.st_hi;
-    }
+    CCP_TRY(masked_tile_census(g, P, T));
     if (l1 == 2 && T > kMaskedMaxCheckedT) return CCP_ERR_BAD_ARG;
     constexpr int TMC = T <= kMaskedMaxCheckedT ? T : 1;
     if (l1 == 2) hipLaunchKernelGGL((k_fused_sweep_masked<TMC, 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P, g->tile_live.p);
@@ -451,6 +461,107 @@ int launch_fused_t(ccp_grid *g, const double *xin, double *xout, int st_lo, int 
     return CCP_OK;
 }
 
+// `n_passes` passes of depth T as ONE launch (k_fused_multi): xin -> xout -> xin ...; st_lo/st_hi per pass.  Returns
+// CCP_ERR_UNSUPPORTED when the shape does not qualify (the caller then issues the passes one by one).
+template <int T>
+int launch_fused_multi_t(ccp_grid *g, int n_passes, const double *xin, double *xout, const int *st_lo, const int *st_hi)
+{
+    if (n_passes < 2 || n_passes > kMultiMaxPasses || g->trace_file) return CCP_ERR_UNSUPPORTED;
+    if (g->masked && T > kMaskedMaxT) return CCP_ERR_UNSUPPORTED;
+    FusedMultiParams M{};
+    FusedParams &P = M.P;
+    P.xin = xin;
+    P.xout = xout;
+    P.b = g->b.p;
+    P.g = g->geom;
+    P.st_lo = st_lo[0];
+    P.st_hi = st_hi[0];
+    P.rows_per_chunk = (g->tuned && g->tune_rows[T] > 0) ? g->tune_rows[T] : g->rows_per_chunk;
+    const int U = fused_useful_px(T);
+    P.n_strips = (g->geom.W + U - 1) / U;
+    P.partial = g->partial.p;
+    P.partial_border = g->partial.p + g->partial_region;
+    P.active = nullptr;
+    P.xcd_swizzle = 0;
+    P.mask = g->maskp.p;
+    P.trace = nullptr;
+    const int HS = 2 * T;
+    if (g->masked) {
+        // every tile an ordinary tile, uniform chunks (launch_fused_masked's geometry)
+        P.first_rows = P.last_rows = P.first_edge = P.last_edge = 0;
+        P.n_chunks = (P.st_hi - P.st_lo + P.rows_per_chunk - 1) / P.rows_per_chunk;
+        P.nb_top = P.nb_bot = P.ns_left = P.ns_right = 0;
+        P.side_rows = P.side_rows_edge = P.rows_per_chunk;
+        P.side_subs = 1;
+        CCP_TRY(masked_tile_census(g, P, T));
+    } else {
+        fused_tile_counts(g, T, P, 0);
+        const int R = P.rows_per_chunk;
+        int sr = std::max(16, (R + 2 * HS) * 2 / 5 - 2 * HS);
+        sr += sr & 1;
+        if (g->side_rows_override > 0) sr = std::max(2, g->side_rows_override);
+        P.side_rows = std::min(sr, R);
+        P.side_subs = (R + P.side_rows - 1) / P.side_rows;
+        P.side_rows_edge = P.side_rows;
+    }
+    P.edge_counter = nullptr;
+    P.edge_flag = nullptr;
+    P.edge_epoch = P.edge_target = 0;
+    // a tile waits for the tiles two chunks up and down: of any two adjacent chunks at least one must be as tall
+    // as the halo (2T rows) — true when the regular and the special chunk heights are, whatever the remainder chunk
+    if (P.rows_per_chunk < HS || (P.first_rows > 0 && P.first_rows < HS) || (P.last_rows > 0 && P.last_rows < HS)) return CCP_ERR_UNSUPPORTED;
+    for (int c = 0; c + 1 < P.n_chunks; ++c) {
+        int ra, rb, rc, rd;
+        fused_chunk_rows(P, c, ra, rb);
+        fused_chunk_rows(P, c + 1, rc, rd);
+        if (rb - ra < HS && rd - rc < HS) return CCP_ERR_UNSUPPORTED;
+    }
+    for (int q = 0; q < n_passes; ++q) {
+        if (st_hi[q] <= st_lo[q] || st_lo[q] < st_lo[0] || st_hi[q] > st_hi[0]) return CCP_ERR_UNSUPPORTED;
+        M.st_lo[q] = st_lo[q];
+        M.st_hi[q] = st_hi[q];
+    }
+    const int waves = kBlock / kWave;
+    const int edge_chunks = std::min(P.nb_top + P.nb_bot, P.n_chunks);
+    const int edge_strips = std::min(P.ns_left + P.ns_right, P.n_strips);
+    const long n_border = g->masked ? 0 : (long)edge_chunks * (P.n_strips - edge_strips) + (long)P.n_chunks * edge_strips * P.side_subs;
+    M.n_passes = n_passes;
+    M.gx = (P.n_strips + waves - 1) / waves;
+    M.gy = P.n_chunks;
+    M.bgx = (int)((n_border + waves - 1) / waves);
+    M.channels = g->desc.channels;
+    const size_t cells = (size_t)n_passes * M.channels * P.n_chunks * P.n_strips;
+    if (g->multi_words.n < cells + 2) CCP_TRY(g->multi_words.alloc(cells + 2));
+    CCP_HIP(hipMemsetAsync(g->multi_words.p, 0, (cells + 2) * sizeof(unsigned), g->stream));
+    M.ticket = g->multi_words.p;
+    M.cells = g->multi_words.p + 2;
+    M.error = g->edge_timeout;
+    M.tile_live = g->tile_live.p;
+    const long total = (long)n_passes * (M.bgx + (long)M.gx * M.gy) * M.channels;
+    if (total > 0x7fffffffL) return CCP_ERR_UNSUPPORTED;
+    constexpr int TM = T <= kMaskedMaxT ? T : 1;
+    if (g->masked) hipLaunchKernelGGL((k_fused_multi<TM, kFusedUnroll, true>), dim3((unsigned)total), dim3(kBlock), 0, g->stream, M);
+    else hipLaunchKernelGGL((k_fused_multi<T, kFusedUnroll>), dim3((unsigned)total), dim3(kBlock), 0, g->stream, M);
+    CCP_HIP(hipGetLastError());
+    g->last_launches += n_passes;
+    g->region_launches += n_passes;
+    g->region_iterations += (long)T * n_passes;
+    return CCP_OK;
+}
+
+template <int TMAX>
+struct FusedMultiDepth {
+    static int launch(int T, ccp_grid *g, int n, const double *xin, double *xout, const int *lo, const int *hi)
+    {
+        if (T == TMAX) return launch_fused_multi_t<TMAX>(g, n, xin, xout, lo, hi);
+        return FusedMultiDepth<TMAX - 1>::launch(T, g, n, xin, xout, lo, hi);
+    }
+};
+template <>
+struct FusedMultiDepth<0> {
+    static int launch(int, ccp_grid *, int, const double *, double *, const int *, const int *) { return CCP_ERR_UNSUPPORTED; }
+};
+
 // run-time depth -> the instantiation of that depth
 template <int TMAX>
 struct FusedDepth {
@@ -591,10 +702,37 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool
     }
     std::sort(plan.begin(), plan.end(), std::greater<int>());
     double *cur = g->x.p, *alt = g->x_alt.p;
-    for (size_t k = 0; k < plan.size(); ++k) {
+    for (size_t k = 0; k < plan.size();) {
+        // consecutive passes of one depth as ONE launch (k_fused_multi), where that is switched on and the shape
+        // qualifies; the pass that carries the stop rule or the edge hand-off keeps its own kernels
+        if (g->multi && active == nullptr) {
+            size_t j = k;
+            while (j < plan.size() && plan[j] == plan[k] && (int)(j - k) < kMultiMaxPasses &&
+                   !(j + 1 == plan.size() && (l1_last || edge_rows > 0)))
+                ++j;
+            const int n = (int)(j - k), T = plan[k];
+            const bool shrinking = g->shrink_top || g->shrink_bottom;
+            if (n >= 2 && !(shrinking && g->half_sweeps_since_refresh + 2 * T * n > g->desc.ghost)) {
+                int lo[kMultiMaxPasses], hi[kMultiMaxPasses];
+                for (int q = 0; q < n; ++q) {
+                    const int s = g->half_sweeps_since_refresh + 2 * T * (q + 1);
+                    lo[q] = g->shrink_top ? std::min(s, g->ghost_top) : 0;
+                    hi[q] = g->geom.local_rows - (g->shrink_bottom ? std::min(s, g->ghost_bottom) : 0);
+                }
+                const int st = FusedMultiDepth<kFusedMaxT>::launch(T, g, n, cur, alt, lo, hi);
+                if (st == CCP_OK) {
+                    if (shrinking) g->half_sweeps_since_refresh += 2 * T * n;
+                    if (n & 1) std::swap(cur, alt);
+                    k = j;
+                    continue;
+                }
+                if (st != CCP_ERR_UNSUPPORTED) return st;
+            }
+        }
         const bool last = k + 1 == plan.size();
         CCP_TRY(launch_fused(g, plan[k], cur, alt, active, (l1_last && last) ? 1 : 0, l1_blocks, last ? edge_rows : 0));
         std::swap(cur, alt);
+        ++k;
     }
     if (edge_rows > 0) CCP_TRY(edge_epoch_publish_after_pass(g));
     return CCP_OK;
@@ -702,6 +840,7 @@ try {
     if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SHORT_EDGES")) g->short_edges = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_XCD")) g->xcd_swizzle = atoi(e) != 0;
+    if (const char *e = getenv("CCP_GS_MULTI")) g->multi = atoi(e);
     if (const char *e = getenv("CCP_GS_TRACE_FILE")) g->trace_file = e[0] ? e : nullptr;
     if (const char *e = getenv("CCP_GS_SIDE_ROWS")) g->side_rows_override = atoi(e);
     if (const char *e = getenv("CCP_GS_LEX_MODE")) g->lex_mode = strcmp(e, "planes") == 0 ? 0 : (strcmp(e, "strips") == 0 ? 1 : (strcmp(e, "skew") == 0 ? 2 : 3));
@@ -751,12 +890,13 @@ try {
         if (hipMalloc(reinterpret_cast<void **>(&g->edge_counter), sizeof(unsigned long long) * kEdgeRing) != hipSuccess ||
             hipExtMallocWithFlags(reinterpret_cast<void **>(&g->edge_flag), sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess ||
             hipMemset(g->edge_counter, 0, sizeof(unsigned long long) * kEdgeRing) != hipSuccess ||
-            hipMemset(g->edge_flag, 0, sizeof(unsigned long long)) != hipSuccess ||
-            hipHostMalloc(reinterpret_cast<void **>(&g->edge_timeout), sizeof(unsigned), hipHostMallocMapped) != hipSuccess)
+            hipMemset(g->edge_flag, 0, sizeof(unsigned long long)) != hipSuccess)
             st = CCP_ERR_HIP;
-        if (g->edge_timeout) *g->edge_timeout = 0;
         if (const char *e = getenv("CCP_GS_EDGE_TIMEOUT_TICKS")) g->edge_timeout_ticks = strtoull(e, nullptr, 10);
     }
+    // the word in which a kernel records a bounded wait that gave up (k_wait_flag, k_fused_multi): host-mapped
+    if (st == CCP_OK && hipHostMalloc(reinterpret_cast<void **>(&g->edge_timeout), sizeof(unsigned), hipHostMallocMapped) != hipSuccess) st = CCP_ERR_HIP;
+    if (g->edge_timeout) *g->edge_timeout = 0;
     if (st == CCP_OK && (hipMemset(g->x.p, 0, elems * sizeof(double)) != hipSuccess ||
                          hipMemset(g->b.p, 0, elems * sizeof(double)) != hipSuccess))
         st = CCP_ERR_HIP;
@@ -1511,6 +1651,7 @@ try {
     if (!g->cg_r.p) {
         CCP_TRY(g->cg_r.alloc((size_t)n));
         CCP_TRY(g->cg_p.alloc((size_t)n));
+        CCP_TRY(g->cg_p2.alloc((size_t)n));
         CCP_TRY(g->cg_ap.alloc((size_t)n));
         CCP_TRY(g->cg_state.alloc(1));
     }
@@ -1531,8 +1672,39 @@ try {
             *n_partials = (int)(grid.x * grid.y * grid.z);
             return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
         };
-        CCP_TRY(cg_solve(spmv, spmv_dot, g->b.p + (long)ch * n, g->x.p + (long)ch * n, g->cg_r.p, g->cg_p.p, g->cg_ap.p, n, epsilon,
-                         max_iteration, g->cg_state.p, g->partial.p, s, g->ev0, g->ev1, report ? report + ch : nullptr));
+        // CCP_GS_CG_FUSED: 0 the three-pass loop (88 B), 2 the fused loop with the row-per-block pass A (its iterates are
+        // the three-pass loop's bit for bit), otherwise the fused loop with the marching pass A (default)
+        const int fused_mode = getenv("CCP_GS_CG_FUSED") ? atoi(getenv("CCP_GS_CG_FUSED")) : 1;
+        const bool fused = fused_mode != 0;
+        if (!fused) {
+            CCP_TRY(cg_solve(spmv, spmv_dot, g->b.p + (long)ch * n, g->x.p + (long)ch * n, g->cg_r.p, g->cg_p.p, g->cg_ap.p, n, epsilon,
+                             max_iteration, g->cg_state.p, g->partial.p, s, g->ev0, g->ev1, report ? report + ch : nullptr));
+            continue;
+        }
+        // fused loop: 72 B per unknown and iteration (ccp_cg.hpp); same iterates bit for bit
+        CCP_HIP(hipMemsetAsync(g->cg_p2.p, 0, sizeof(double) * n, s));
+        const int march_rows = 32;
+        const dim3 mgrid((unsigned)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)), (unsigned)((geo.local_rows + march_rows - 1) / march_rows));
+        auto apply = [&](double *xv, const double *rv, const double *p_in, double *p_out, double *apv, int *n_partials) -> int {
+            if (fused_mode != 2) {
+                if (g->masked)
+                    hipLaunchKernelGGL((k_cg_apply_march<true>), mgrid, dim3(kBlock), 0, s, xv, rv, p_in, p_out, apv, geo, march_rows, g->partial.p, g->maskp.p, g->cg_state.p);
+                else
+                    hipLaunchKernelGGL((k_cg_apply_march<false>), mgrid, dim3(kBlock), 0, s, xv, rv, p_in, p_out, apv, geo, march_rows, g->partial.p,
+                                       static_cast<const unsigned char *>(nullptr), g->cg_state.p);
+                *n_partials = (int)(mgrid.x * mgrid.y);
+                return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
+            }
+            if (g->masked)
+                hipLaunchKernelGGL((k_cg_apply_fused<2, true>), grid, dim3(kBlock), 0, s, xv, rv, p_in, p_out, apv, geo, g->partial.p, g->maskp.p, g->cg_state.p);
+            else
+                hipLaunchKernelGGL((k_cg_apply_fused<2, false>), grid, dim3(kBlock), 0, s, xv, rv, p_in, p_out, apv, geo, g->partial.p,
+                                   static_cast<const unsigned char *>(nullptr), g->cg_state.p);
+            *n_partials = (int)(grid.x * grid.y * grid.z);
+            return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
+        };
+        CCP_TRY(cg_solve_fused(spmv, apply, g->b.p + (long)ch * n, g->x.p + (long)ch * n, g->cg_r.p, g->cg_p.p, g->cg_p2.p, g->cg_ap.p, n,
+                               epsilon, max_iteration, g->cg_state.p, g->partial.p, s, g->ev0, g->ev1, report ? report + ch : nullptr));
     }
     return CCP_OK;
 } CCP_ABI_CATCH

@@ -230,13 +230,20 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_rsrc(const double *plane, 
     return __builtin_amdgcn_make_buffer_rsrc((void *)(plane + (long)row * 2 * g.pitch), 0,
                                              exists ? (int)(g.pitch * 16) : 0, 0x00020000);
 }
+// COH: the access carries sc1 (aux bit 4: system-coherence level 1 on gfx942/gfx950) — a store writes through to
+// memory, a load does not trust the XCD's (non-coherent) L2.  What k_fused_multi hands from one pass to the next
+// INSIDE a launch goes through these (MI355X_MICROARCH.md, correctness boundaries: every store of the handed-off
+// bytes sc1 and drained before the counter, every load of them an sc1 load).
+constexpr int kAuxSc1 = 16;
+template <bool COH = false>
 __device__ __forceinline__ double buf_load(__amdgpu_buffer_rsrc_t rs, unsigned voff)
 {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, 0));
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, (int)voff, 0, COH ? kAuxSc1 : 0));
 }
+template <bool COH = false>
 __device__ __forceinline__ void buf_store(double v, __amdgpu_buffer_rsrc_t rs, unsigned voff)
 {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, (int)voff, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rs, (int)voff, 0, COH ? kAuxSc1 : 0);
 }
 
 // Wave-uniform march parameters (SGPRs) and the few per-lane values of a strip.
@@ -262,13 +269,14 @@ struct FusedCtx {
 };
 
 // Row q of x (red, black) and b (red, black); rows outside [m0, m1) and lanes outside the image read 0.
+template <bool COH = false>
 __device__ __forceinline__ void fused_load_row(const FusedCtx &cx, const Geom &g, int q, double (&dst)[4])
 {
     const bool exists = q >= cx.m0 && q < cx.m1;
     const __amdgpu_buffer_rsrc_t rx = row_rsrc(cx.xin, g, q, exists), rbb = row_rsrc(cx.bb, g, q, exists);
-    dst[0] = buf_load(rx, cx.ld_r);
-    dst[1] = buf_load(rx, cx.ld_k);
-    dst[2] = buf_load(rbb, cx.ld_r);
+    dst[0] = buf_load<COH>(rx, cx.ld_r);
+    dst[1] = buf_load<COH>(rx, cx.ld_k);
+    dst[2] = buf_load(rbb, cx.ld_r);                   // (b never changes during a solve: plain loads)
     dst[3] = buf_load(rbb, cx.ld_k);
 }
 
@@ -303,7 +311,7 @@ constexpr int kStepFast = 0, kStepBorder = 2, kStepSide = 3;
 // MASKED (Dirichlet-mask grid): the update is fma(sum, q, b/4) with q = 1/4 for an unknown and 0 for a pixel
 // fixed at zero (whose b is 0): the same instruction count as the plain update, the mask costs registers (a
 // q window) instead of instructions.  The stencil is the uniform 5-point one — no degree logic anywhere.
-template <int T, int MODE, int L1, int UNR, int NT, int AN, bool MASKED = false, int NQ = 1>
+template <int T, int MODE, int L1, int UNR, int NT, int AN, bool MASKED = false, int NQ = 1, bool COH = false>
 __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], double (&br)[NT], double (&bk)[NT],
                                            double (&acc)[AN], const FusedCtx &cx, const Geom &g, int f, int i,
                                            double (&qr)[NQ], double (&qk)[NQ])
@@ -384,8 +392,8 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
         const int r = f - HS;
         const int sr = Win::slot(i, HS);
         const __amdgpu_buffer_rsrc_t ro = row_rsrc(cx.xout, g, r, r >= cx.ra && r < cx.rb);
-        buf_store(wr[sr], ro, cx.st_r);
-        buf_store(wk[sr], ro, cx.st_k);
+        buf_store<COH>(wr[sr], ro, cx.st_r);
+        buf_store<COH>(wk[sr], ro, cx.st_k);
     }
     // keep the machine scheduler from pulling later steps' work up across this point:
     // unconstrained it hoists all G steps together and spills the register window
@@ -396,7 +404,7 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
 // BORDERTILE = false: every pixel the wave can touch is ordinary: one straight-line loop of
 // kStepFast trips.  BORDERTILE = true: each trip picks among the three bodies (force_border:
 // debug, every trip takes kStepBorder).
-template <int T, bool BORDERTILE, int L1, int UNR, int AN, bool MASKED = false>
+template <int T, bool BORDERTILE, int L1, int UNR, int AN, bool MASKED = false, bool COH = false>
 __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, double *__restrict__ xout,
                                            const double *__restrict__ bb, const Geom &g, int sx,
                                            int ra, int rb, double (&acc)[AN], bool force_border = false,
@@ -450,7 +458,7 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     for (int s = 0; s < NQ; ++s) qr[s] = qk[s] = 0.0;
 #pragma unroll
     for (int i = 0; i < G; ++i) {
-        fused_load_row(cx, g, base + i, land[i]);
+        fused_load_row<COH>(cx, g, base + i, land[i]);
         if (MASKED) fused_load_mask(cx, g, base + i, landm[i]);
     }
 #pragma unroll
@@ -466,14 +474,14 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     for (int fb = base; fb <= f_end; fb += G) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
-            fused_load_row(cx, g, fb + G + i, land[i]);
+            fused_load_row<COH>(cx, g, fb + G + i, land[i]);
             if (MASKED) fused_load_mask(cx, g, fb + G + i, landm[i]);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (!BORDERTILE) {
 #pragma unroll
             for (int i = 0; i < G; ++i)
-                fused_step<T, kStepFast, L1, UNR, NT, AN, MASKED, NQ>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
+                fused_step<T, kStepFast, L1, UNR, NT, AN, MASKED, NQ, COH>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
         } else {
             // rows the trip updates that matter: fb-HS .. fb+G-2, clipped to the rows this wave holds
             const int r_first = max(fb - HS, cx.m0), r_last = min(fb + G - 2, cx.m1 - 1);
@@ -481,15 +489,15 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
             if (rows_plain && cx.col_interior) {
 #pragma unroll
                 for (int i = 0; i < G; ++i)
-                    fused_step<T, kStepFast, L1, UNR, NT, AN, false, NQ>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
+                    fused_step<T, kStepFast, L1, UNR, NT, AN, false, NQ, COH>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
             } else if (rows_plain) {
 #pragma unroll
                 for (int i = 0; i < G; ++i)
-                    fused_step<T, kStepSide, L1, UNR, NT, AN, false, NQ>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
+                    fused_step<T, kStepSide, L1, UNR, NT, AN, false, NQ, COH>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
             } else {
 #pragma unroll
                 for (int i = 0; i < G; ++i)
-                    fused_step<T, kStepBorder, L1, UNR, NT, AN, false, NQ>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
+                    fused_step<T, kStepBorder, L1, UNR, NT, AN, false, NQ, COH>(wr, wk, br, bk, acc, cx, g, fb + i, i, qr, qk);
             }
         }
 #pragma unroll
@@ -687,6 +695,157 @@ k_fused_border(FusedParams P, int force_border)
         }
     }
     fused_write_partials<L1, AN>(acc, P.partial_border, ch, scratch, blockIdx.x, blockIdx.y);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Several passes of depth T in ONE launch (k_fused_multi): no drain, no fill and no idle chip between them.
+//
+// Between two dependent pass launches the chip idles ~18-26 us (profiles/r02_edge_pass_trace.json): the last tiles
+// of a pass trickle out, the next launch starts from an empty chip.  That is 1.5 % of a 16384^2 pass but 8-14 % of a
+// 4096^2 x 3 pass or of one 2048-row block of an 8-GPU run.  Here the tiles of ALL passes of a group are handed out
+// by one ticket counter, pass-major (within a pass the slow border tiles first); a wave that takes tile (c, s) of
+// pass q waits — polling fifteen counters — until the tiles (c-2..c+2, s-1..s+1) of pass q-1 are complete: they wrote
+// everything its trapezoid reads, and they have read everything it overwrites (the passes ping-pong between two
+// buffers).  A wave only ever waits for tickets smaller than its own, all of which are held by workgroups already
+// started, so the grid always drains whatever the dispatch order (the ticket, not blockIdx, names the work).
+//
+// What one pass hands to the next travels through memory INSIDE the launch, between CUs of different XCDs whose L2s
+// are not coherent: every x store is sc1 (write-through) and drained (s_waitcnt vmcnt(0)) before the wave counts its
+// tile complete with an agent-scope atomic, and every x load is an sc1 load (COH in fused_wave) — the valid form of
+// MI355X_MICROARCH.md's correctness boundaries.  b is read with plain loads (it does not change).
+//
+// All passes share the tiling of the first one (the widest row range); a later pass of a row block with ghost rows
+// stores fewer rows per side (validity recedes 2T rows per pass) and simply clips its tiles' rows.  A tile cut into
+// side sub-tiles is complete when all of them are.  Every spin is bounded (~1 s): a wave that gives up raises
+// *error — the host turns that into CCP_ERR_STATE — and goes on, so a logic error costs a result, never the GPU.
+constexpr int kMultiMaxPasses = 8;
+
+struct FusedMultiParams {
+    FusedParams P;                 // pass 0: xin -> xout with the group's tiling; odd passes run xout -> xin
+    int n_passes;
+    int st_lo[kMultiMaxPasses], st_hi[kMultiMaxPasses];   // rows pass q finalises and stores
+    int gx, gy, bgx;               // workgroups of the ordinary tiles (gx strips-of-4 x gy chunks) and of the border tiles, per channel
+    int channels;
+    unsigned *__restrict__ ticket;
+    unsigned *__restrict__ cells;  // [pass][channel][chunk][strip] waves that completed the tile
+    unsigned *__restrict__ error;
+    const unsigned char *__restrict__ tile_live;   // MASKED: which tiles hold any unknown (k_masked_tile_census); the others never run
+};
+
+// waves that make up tile (chunk, sx): 1, or the non-empty side sub-tiles of an edge strip
+__device__ __forceinline__ unsigned fused_multi_expected(const FusedParams &P, int chunk, int sx)
+{
+    const bool side = sx < P.ns_left || sx >= P.n_strips - P.ns_right;
+    if (!side) return 1u;
+    int c0, c1;
+    fused_chunk_rows(P, chunk, c0, c1);
+    const int n = (c1 - c0 + P.side_rows - 1) / P.side_rows;
+    return (unsigned)min(n, P.side_subs);
+}
+
+// MASKED (Dirichlet-mask grid): every tile is an ordinary one, tiles without an unknown in reach are complete without
+// running (a waiter expects nothing from them).
+template <int T, int UNR, bool MASKED = false>
+__global__ void __launch_bounds__(kBlock, 2)
+k_fused_multi(FusedMultiParams M)
+{
+    __shared__ unsigned s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(M.ticket, 1u);
+    __syncthreads();
+    const FusedParams &P = M.P;
+    const Geom &g = P.g;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int lane = (int)(threadIdx.x & (kWave - 1));
+    const unsigned per_pass = (unsigned)(M.bgx + M.gx * M.gy) * (unsigned)M.channels;
+    const unsigned tk = __builtin_amdgcn_readfirstlane(s_ticket);
+    const int q = (int)(tk / per_pass);
+    if (q >= M.n_passes) return;
+    unsigned i = tk % per_pass;
+    // ---- which tile -------------------------------------------------------------------------------------------
+    int chunk = 0, sx = 0, ch = 0, ra = 0, rb = 0;
+    bool border = false, have = false;
+    const int edge_chunks = min(P.nb_top + P.nb_bot, P.n_chunks);
+    const int edge_strips = min(P.ns_left + P.ns_right, P.n_strips);
+    if (!MASKED && i < (unsigned)(M.bgx * M.channels)) {
+        // a workgroup of k_fused_border's enumeration: top/bottom chunk rows (inner strips), then the side sub-tiles
+        border = true;
+        ch = (int)(i / (unsigned)M.bgx);
+        const int id = (int)(i % (unsigned)M.bgx) * (kBlock / kWave) + wave;
+        const int inner = P.n_strips - edge_strips;
+        const int n_full = edge_chunks * inner;
+        const int n_side = P.n_chunks * edge_strips * P.side_subs;
+        if (id < n_full + n_side) {
+            if (id < n_full) {
+                const int e = id / inner;
+                sx = P.ns_left + id % inner;
+                chunk = e < P.nb_top ? e : P.n_chunks - edge_chunks + e;
+                fused_chunk_rows(P, chunk, ra, rb);
+            } else {
+                int k = id - n_full;
+                const int sub = k % P.side_subs;
+                k /= P.side_subs;
+                const int e = k % edge_strips;
+                chunk = k / edge_strips;
+                sx = e < P.ns_left ? e : P.n_strips - edge_strips + e;
+                int c0, c1;
+                fused_chunk_rows(P, chunk, c0, c1);
+                ra = c0 + sub * P.side_rows;
+                rb = min(ra + P.side_rows, c1);
+            }
+            have = ra < rb;
+        }
+    } else {
+        i -= (unsigned)(M.bgx * M.channels);
+        const unsigned per_ch = (unsigned)(M.gx * M.gy);
+        ch = (int)(i / per_ch);
+        const unsigned r = i % per_ch;
+        chunk = (int)(r / (unsigned)M.gx);
+        sx = (int)(r % (unsigned)M.gx) * (kBlock / kWave) + wave;
+        fused_chunk_rows(P, chunk, ra, rb);
+        have = sx < P.n_strips && ra < rb;
+        if (have) have = MASKED ? M.tile_live[(long)chunk * P.n_strips + sx] != 0 : !fused_is_border_tile(P, chunk, sx);
+    }
+    if (!have) return;
+    // ---- wait for the nine tiles of the previous pass around this one ------------------------------------------
+    const long cells_per_pass = (long)M.channels * P.n_chunks * P.n_strips;
+    if (q > 0) {
+        const unsigned *prev = M.cells + (long)(q - 1) * cells_per_pass + (long)ch * P.n_chunks * P.n_strips;
+        // chunks c-2 .. c+2: the one chunk of a pass that may be shorter than the halo (the remainder of the rows) has
+        // full-height neighbours, so two chunks either way always cover the 2T rows a trapezoid reaches
+        const int dc = lane / 3 - 2, ds = lane % 3 - 1;
+        const int c2 = chunk + dc, s2 = sx + ds;
+        const bool mine = lane < 15 && c2 >= 0 && c2 < P.n_chunks && s2 >= 0 && s2 < P.n_strips;
+        const unsigned need = !mine ? 0u : (MASKED ? (unsigned)(M.tile_live[(long)c2 * P.n_strips + s2] != 0) : fused_multi_expected(P, c2, s2));
+        const unsigned *word = prev + (mine ? (long)c2 * P.n_strips + s2 : 0);
+        bool ok = !mine;
+        const unsigned long long t0 = wall_clock64();
+        while (!__all(ok)) {
+            if (!ok) ok = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t0 > 100000000ull) {              // 1 s of the 100 MHz clock: never in a correct run
+                if (lane == 0) __hip_atomic_store(M.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    // ---- the tile -------------------------------------------------------------------------------------------
+    const int r0 = max(ra, M.st_lo[q]), r1 = min(rb, M.st_hi[q]);
+    if (r0 < r1) {
+        const long off = (long)ch * g.ch_stride;
+        const double *xin = ((q & 1) ? P.xout : P.xin) + off;
+        double *xout = ((q & 1) ? const_cast<double *>(P.xin) : P.xout) + off;
+        double acc[1] = {0.0};
+        if (MASKED) fused_wave<T, false, 0, UNR, 1, MASKED, true>(xin, xout, P.b + off, g, sx, r0, r1, acc, false, P.mask);
+        else if (border) fused_wave<T, true, 0, UNR, 1, false, true>(xin, xout, P.b + off, g, sx, r0, r1, acc, false);
+        else fused_wave<T, false, 0, UNR, 1, false, true>(xin, xout, P.b + off, g, sx, r0, r1, acc);
+    }
+    // ---- publish: the (write-through) stores acknowledged, then the count ----------------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // compiler ordering only
+    __builtin_amdgcn_s_waitcnt(0);
+    if (lane == 0)
+        __hip_atomic_fetch_add(M.cells + (long)q * cells_per_pass + ((long)ch * P.n_chunks + chunk) * P.n_strips + sx, 1u, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace ccp

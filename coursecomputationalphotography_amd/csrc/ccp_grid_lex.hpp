@@ -463,6 +463,9 @@ constexpr int kLexRing = 4;                        // result rows kept per sweep
 constexpr int kLexBRows = 32;
 constexpr int kLexSlackRows = 128;                 // diagonal rows allocated beyond the last one (k_lex_wg prefetches past the image)
 constexpr int kLexScratch = 32;                    // doubles per workgroup the storer of k_lex_wg may write to and nobody reads
+constexpr int kLexStoresPerBlock = 8 * 2 + 1;      // k_lex_wg's storer: two stores per step (x row, edge values) + the publication, per 8-step block
+constexpr int kLexPublishLagBlocks = 2;            // ... publishes the steps before block db - 8*2 ...
+constexpr int kLexPublishVmcnt = 48;               // ... once at most this many of its stores are outstanding (< 3 blocks' worth)
 constexpr int kLexWordStride = 32;                 // progress words of k_lex_wg: one per 128-byte line (the word a strip's
                                                    // storer writes is polled by its neighbours' loaders)
 
@@ -798,11 +801,19 @@ __device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLex
                 if (lane < 2 * T) lex_st((d >= d_begin && d <= d_end) ? e_mine + ((long)(d - d_begin) * T) * 2 + lane : scratch + 8 + lane, ev);
             }
         }
-        // Stores complete in issue order, and a block issues 17 of them (16 + this publication): once at most the 48
-        // youngest are outstanding — this block's, the one before and most of a third — every store of the blocks
-        // before those has been acknowledged.  Publish their steps, without draining.
-        asm volatile("s_waitcnt vmcnt(48)" ::: "memory");
-        if (lane == 0) __hip_atomic_store(st.mine, (unsigned)max(db - 16, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // Stores complete in issue order, and a block issues kLexStoresPerBlock of them (two per step + this
+        // publication): once at most the kLexPublishVmcnt youngest are outstanding — this block's, the one before and
+        // most of a third — every store of the blocks before those three has been acknowledged.  Publish their steps
+        // (everything before block db - 8 kLexPublishLagBlocks), without draining.
+        // REQUIRED CODEGEN: exactly kLexStoresPerBlock vector-memory instructions per block in this wave — the three
+        // branches above each issue their two stores per step unconditionally (masked lanes go to scratch slots) so
+        // that the compiler can neither merge nor drop one; a build whose storer issued FEWER would publish early.
+        // The static_assert ties the count waited for to the lag published; tests/test_gpu_lex.py checks the bits.
+        static_assert(kLexPublishVmcnt < (kLexPublishLagBlocks + 1) * kLexStoresPerBlock && kLexPublishVmcnt <= 63,
+                      "the stores of block db - 8 (kLexPublishLagBlocks + 1) must all lie outside the youngest kLexPublishVmcnt");
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kLexPublishVmcnt) : "memory");
+        if (lane == 0)
+            __hip_atomic_store(st.mine, (unsigned)max(db - 8 * kLexPublishLagBlocks, 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 

@@ -184,8 +184,15 @@ public:
         const bool inside = row >= 0 && row < n_rows_ && col >= 0 && col < n_cols_;
         if (val == T(0)) erase(row, col);
         else put(std::move(val), row, col);
-        if (dev_ && !dirty_ && inside) ccp::throw_on(ccp_csr_insert(dev_, row, col, as_double), "ccp_csr_insert");
-        else dirty_ = true;
+        if (dev_ && !dirty_ && inside) {
+            // the host arrays already hold the edit: should forwarding it fail, the device copy no longer matches them
+            // and the next solve must upload again instead of running on a matrix that silently differs
+            const int st = ccp_csr_insert(dev_, row, col, as_double);
+            if (st != CCP_OK) dirty_ = true;
+            ccp::throw_on(st, "ccp_csr_insert");
+        } else {
+            dirty_ = true;
+        }
     }
 
     // How the device copy has been maintained so far: whole images built and uploaded, rows patched in

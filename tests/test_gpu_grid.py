@@ -283,3 +283,42 @@ def test_grid_conjugate_gradient_matrix_free(capi, orc):
         want, it = om.conjugate_gradient(bs[ch], 1e-10, 12, init)
         assert rel_l2(g.get_x(ch).ravel(), want) <= 1e-9
     g.close()
+
+
+@pytest.mark.parametrize("W,H,masked", [(37, 29, False), (1000, 300, False), (300, 200, True)])
+def test_fused_cg_loop_gives_the_three_pass_loops_bits(capi, monkeypatch, W, H, masked):
+    """The 72-byte loop (x's update and the new direction folded into the SpMV pass, csrc/ccp_grid_cg.hpp) performs the
+    operations of sparse-matrix.h:419-427 on the same operands in the same order as the three-pass loop
+    (CCP_GS_CG_FUSED=0): with the row-per-block pass A (=2) identical iterates, iteration counts and stop decisions —
+    stop rule hit, cap hit, cap 0; with the marching pass A (=1, default) the same to rounding."""
+    from coursecomputationalphotography_amd import synth
+    mask = None
+    if masked:
+        mask = synth.disc_mask(W, H, seed=7)
+    out = {}
+    for fused in ("0", "2", "1"):
+        monkeypatch.setenv("CCP_GS_CG_FUSED", fused)
+        g = capi.Grid(W, H, 2, mask=mask)
+        g.randomize_x(99, 0.0, 255.0)
+        g.b_from_x()
+        res = []
+        for eps, cap, start in ((0.0, 17, 0.0), (1e-3, 400, 1.0), (0.0, 0, 3.0), (0.0, 1, 0.0)):
+            g.fill_x(start)
+            reps = g.conjugate_gradient(eps, cap)
+            res.append(([r.iterations for r in reps], [r.converged for r in reps], [r.last_l1_step for r in reps],
+                        [g.get_x(ch).copy() for ch in range(2)]))
+        g.close()
+        out[fused] = res
+    for a, b in zip(out["0"], out["2"]):
+        assert a[0] == b[0] and a[1] == b[1] and a[2] == b[2]
+        for xa, xb in zip(a[3], b[3]):
+            assert np.array_equal(xa, xb)
+    # the marching pass A (default) groups the partial sums of p'Ap differently: same counts and decisions, iterates
+    # equal to rounding
+    # equal to rounding (a run to convergence amplifies the last bits of alpha as conjugate gradient does: the step
+    # norm at the stop agrees to a few digits, the solution to 1e-9)
+    for k, (a, b) in enumerate(zip(out["0"], out["1"])):
+        assert a[0] == b[0] and a[1] == b[1]
+        assert np.allclose(a[2], b[2], rtol=1e-2 if k == 1 else 1e-8, atol=1e-300)
+        for xa, xb in zip(a[3], b[3]):
+            assert np.linalg.norm(xa - xb) <= (1e-7 if k == 1 else 1e-10) * max(np.linalg.norm(xa), 1e-300)

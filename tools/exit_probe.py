@@ -1,7 +1,8 @@
 """Root-causing the at-exit abort recorded in round 2 (gpurun_out/exit_v4.txt: "double free or corruption (!prev)"
-when torch is imported AFTER libccp_gs.so has used RCCL).  Each variant runs in a child process with
-tools/abort_bt.so preloaded (C stack of the abort) and prints which libamdhip64 / librccl / libhsa-runtime64 copies
-are mapped before it exits.
+when torch is imported AFTER libccp_gs.so has used RCCL).  Each variant runs in a child process and prints which
+libamdhip64 / librccl / libhsa-runtime64 copies are mapped before it exits; a variant that dies is run once more under
+rocgdb (batch mode) for the C stack of the abort.  (An in-process SIGABRT handler printing a backtrace hangs here: the
+abort comes from inside free() during exit handlers.)
 
   python tools/exit_probe.py            -> runs every variant as a child, one report each
   python tools/exit_probe.py <variant>  -> the child itself
@@ -58,13 +59,30 @@ def main():
     if len(sys.argv) > 1:
         return child(sys.argv[1])
     env = dict(os.environ)
-    env["LD_PRELOAD"] = os.path.join(ROOT, "tools", "abort_bt.so")
     env["CCP_GS_DEBUG"] = "1"
-    for v in ("default_order", "rccl_by_path_no_torch", "rccl_by_path_then_torch", "rocm_runtime_then_torch"):
-        r = subprocess.run([sys.executable, os.path.abspath(__file__), v], env=env, capture_output=True, text=True, timeout=600)
-        print(f"===== {v}: exit code {r.returncode}")
-        print(r.stdout[-6000:])
-        print(r.stderr[-6000:])
+    only = os.environ.get("EXIT_PROBE_VARIANTS")
+    names = only.split(",") if only else ["default_order", "rccl_by_path_no_torch", "rccl_by_path_then_torch", "rocm_runtime_then_torch"]
+    for v in names:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), v], env=env, capture_output=True, text=True, timeout=150)
+            rc, out, err = r.returncode, r.stdout, r.stderr
+        except subprocess.TimeoutExpired as e:
+            rc, out, err = "timeout", (e.stdout or b"").decode(errors="replace"), (e.stderr or b"").decode(errors="replace")
+        print(f"===== {v}: exit code {rc}", flush=True)
+        print(out[-6000:], flush=True)
+        print(err[-3000:], flush=True)
+        if rc not in (0,):
+            gdb = "/opt/rocm/bin/rocgdb"
+            if os.path.exists(gdb):
+                cmd = ["timeout", "-k", "10", "240", gdb, "-batch", "-ex", "set pagination off", "-ex", "run", "-ex", "bt 40",
+                       "-ex", "info sharedlibrary", "--args", sys.executable, os.path.abspath(__file__), v]
+                try:
+                    g = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+                    print(f"===== {v} under rocgdb: exit code {g.returncode}", flush=True)
+                    print(g.stdout[-12000:], flush=True)
+                    print(g.stderr[-3000:], flush=True)
+                except subprocess.TimeoutExpired:
+                    print(f"===== {v} under rocgdb: timed out", flush=True)
 
 
 if __name__ == "__main__":

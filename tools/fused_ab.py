@@ -12,7 +12,7 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from coursecomputationalphotography_amd import capi  # noqa: E402
 
-TAG = {"lib": os.environ.get("CCP_GS_LIB", "default"), "xcd": os.environ.get("CCP_GS_XCD", "1")}
+TAG = {"lib": os.path.basename(os.environ.get("CCP_GS_LIB", "default")), "multi": os.environ.get("CCP_GS_MULTI", "0")}
 
 
 def timed(g, iters, steps=6):
@@ -47,14 +47,16 @@ def case(name, W, H, C, T, R, iters, row_begin=0, rows=None, ghost=0):
 def main():
     which = sys.argv[1:] or ["big", "mid", "block"]
     if "big" in which:
-        for R in (364, 496):
+        for R in (364, 496, 256, 728):
             case("16384x16384x1", 16384, 16384, 1, 8, R, 32)
     if "mid" in which:
         case("4096x4096x3 tuned", 4096, 4096, 3, 8, 0, 32)
-        for R in (132, 184, 256, 274, 312, 342, 404):
+        for R in (96, 140, 184, 256, 274, 342, 404, 512):
             case("4096x4096x3", 4096, 4096, 3, 8, R, 32)
     if "block" in which:
         case("16384x2048 block of 8 (ghost 64) tuned", 16384, 16384, 1, 8, 0, 32, 2048 * 4, 2048, 64)
+        for R in (128, 198, 256, 344, 520):
+            case("16384x2048 block of 8 (ghost 64)", 16384, 16384, 1, 8, R, 32, 2048 * 4, 2048, 64)
     if "region" in which:
         from coursecomputationalphotography_amd import synth
         mask = synth.disc_mask(8192, 8192, seed=4321)

@@ -2,7 +2,8 @@
 k_fused_sweep / k_fused_border themselves) turned into a timeline — waves in flight over time, tile durations by kind,
 how many CUs carry one or two workgroups, when the last tile of each kind starts.
 
-  python tools/pass_trace.py W H C T R [row_begin rows ghost]      -> one JSON object on stdout
+  python tools/pass_trace.py W H C T R [row_begin rows ghost [edge]]      -> one JSON object on stdout
+(edge = 1: the pass is issued as the edges-first pass of a row block — ccp_grid_sweep_edges_first)
 """
 import json
 import os
@@ -84,6 +85,7 @@ def main():
     a = [int(v) for v in sys.argv[1:]]
     W, H, C, T, R = a[:5]
     rb, rows, ghost = (a[5:8] + [0, 0, 0])[:3] if len(a) > 5 else (0, None, 0)
+    edge = len(a) > 8 and a[8] != 0
     path = tempfile.mktemp(suffix=".trace")
     os.environ["CCP_GS_TRACE_FILE"] = path
     from coursecomputationalphotography_amd import capi
@@ -92,15 +94,21 @@ def main():
     g.b_from_x()
     g.fill_x(1.0)
     g.set_tiling(T, R)
-    g.sweep(2 * T)
-    g.halo_refreshed()
-    g.sweep(2 * T)
+    if edge:
+        g.sweep_edges_first(2 * T, ghost)
+        g.halo_refreshed()
+        g.sweep_edges_first(2 * T, ghost)
+    else:
+        g.sweep(2 * T)
+        g.halo_refreshed()
+        g.sweep(2 * T)
     g.synchronize()
     g.close()
     passes = parse(path)
     os.unlink(path)
     res = summarise(*passes[-1])
     res["shape"] = [W, H, C, rb, rows, ghost]
+    res["edges_first"] = bool(edge)
     print(json.dumps(res), flush=True)
 
 
