@@ -74,6 +74,13 @@ struct DevBuf {
     }
 };
 
+}  // namespace ccp
+struct ccp_grid;
+namespace ccp {
+// Library-internal (not part of the C ABI): install the mask of a Dirichlet-mask grid from a DEVICE buffer that is
+// already in the grid's layout (one byte per element of a channel plane, colour half-rows of `pitch` bytes).
+int grid_set_mask_split_device(ccp_grid *g, const unsigned char *split_mask_dev, long unknowns);
+
 inline int select_device(int device)
 {
     int count = 0;

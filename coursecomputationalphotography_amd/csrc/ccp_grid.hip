@@ -246,7 +246,11 @@ void fused_tile_counts(const ccp_grid *g, int T, FusedParams &P, int edge_rows =
     if (P.first_edge || P.last_edge) {
         // the edge chunks take tile slots too: give the middle correspondingly fewer, taller chunks, so the
         // pass needs no more rounds on the chip's wave slots than it would without the hand-off (one
-        // workgroup past a whole round costs a round)
+        // workgroup past a whole round costs a round).  (Round 3 tried the alternative — regular chunks of the usual
+        // height plus short FOLLOW-UP chunks dispatched last, which take over the slots the edge tiles free after a
+        // third of the pass: 0.760 ms per 32-iteration interval of a 2048-row block against 0.752 ms for this scheme and
+        // 0.714 ms without the hand-off, profiles/r03_rank_block_edges.jsonl — two more chunk rows of halo cost what
+        // the better packing saves.)
         const int n_whole = (rows + R - 1) / R;
         const int n_mid = std::max(1, n_whole - P.first_edge - P.last_edge);
         int r_mid = (mid + n_mid - 1) / n_mid;
@@ -858,6 +862,7 @@ try {
             return CCP_ERR_UNSUPPORTED;
         }
         g->fuse_tmax = std::min(g->fuse_tmax, kMaskedMaxT);
+        if (!getenv("CCP_GS_CHUNK")) g->rows_per_chunk = 160;   // what the tuner picks on region canvases of 4-80 M pixels (untuned handles)
     }
 
     const size_t elems = (size_t)geo.ch_stride * d->channels;
@@ -1014,6 +1019,27 @@ try {
     if (g->x_alt.p) CCP_TRY(zero_unmasked(g, g->x_alt.p));
     return CCP_OK;
 } CCP_ABI_CATCH
+
+}  // extern "C"
+
+// Library-internal twin of ccp_grid_set_mask_host for a mask that is already on the device in the grid's layout
+// (the region recognition builds it there: ccp_csr.hip).  Asynchronous on the handle's stream.
+int ccp::grid_set_mask_split_device(ccp_grid *g, const unsigned char *split_mask_dev, long unknowns)
+{
+    CCP_TRY(bind(g));
+    if (!g->masked) return CCP_ERR_STATE;
+    if (!split_mask_dev) return CCP_ERR_BAD_ARG;
+    CCP_HIP(hipMemcpyAsync(g->maskp.p, split_mask_dev, (size_t)g->geom.ch_stride, hipMemcpyDeviceToDevice, g->stream));
+    g->unknowns = unknowns;
+    g->live_T = -1;                                      // the tile census belongs to the old mask
+    CCP_TRY(zero_unmasked(g, g->x.p));
+    CCP_TRY(zero_unmasked(g, g->b.p));
+    if (g->x_alt.p) CCP_TRY(zero_unmasked(g, g->x_alt.p));
+    CCP_HIP(hipStreamSynchronize(g->stream));            // the caller's buffer may go
+    return CCP_OK;
+}
+
+extern "C" {
 
 int ccp_grid_fill_x(ccp_grid *g, double value)
 try {
