@@ -23,6 +23,35 @@ using namespace ccp;
 
 namespace {
 
+// Host array that is NOT value-initialised when it is sized (std::vector<T>::resize zero-fills — one thread touching
+// 2.5 GB of fresh pages cost ccp_csr_upload 0.3 s at 41.75 M unknowns); every element is written by the parallel
+// copy that follows a resize().
+template <typename T>
+struct HostArr {
+    std::unique_ptr<T[]> p;
+    size_t n = 0;
+    void resize(size_t count)
+    {
+        p.reset(count ? new T[count] : nullptr);
+        n = count;
+    }
+    size_t size() const { return n; }
+    T *data() { return p.get(); }
+    const T *data() const { return p.get(); }
+    T &operator[](size_t i) { return p[i]; }
+    const T &operator[](size_t i) const { return p[i]; }
+    void swap(HostArr &o)
+    {
+        p.swap(o.p);
+        std::swap(n, o.n);
+    }
+    void assign(const T *first, const T *last)
+    {
+        resize((size_t)(last - first));
+        if (n) std::memcpy(p.get(), first, n * sizeof(T));
+    }
+};
+
 // Sliced-ELL image of the matrix for one row schedule, resident on the device.
 struct Schedule {
     bool built = false;
@@ -76,8 +105,20 @@ struct ccp_csr {
     int n_rows = 0, n_cols = 0;
     // host copy of the live entries in compressed form (slack removed), storage order kept
     std::vector<long> row_ptr;
-    std::vector<int> col;
-    std::vector<double> val;
+    HostArr<int> col;
+    HostArr<double> val;
+    // the same three arrays resident on the device (uploaded once per compact host copy: the region recognition and
+    // the construction of the sliced-ELL images run there)
+    DevBuf<long> d_row_ptr;
+    DevBuf<int> d_col;
+    DevBuf<double> d_val;
+    bool dev_csr_valid = false;            // row offsets and columns are resident
+    bool dev_val_valid = false;            // ... and the values (only the images need them)
+    // ccp_csr_upload starts the device copy of the compact host arrays on a thread of its own (pageable source: the
+    // copy occupies its caller) and returns; whoever needs the device arrays, or is about to replace the host arrays,
+    // joins it first (wait_device_upload)
+    std::thread uploader;
+    int uploader_status = CCP_OK;
     std::vector<int> user_colour;
     int user_n_colours = 0;
     std::vector<int> used_colour;          // the colouring the multi-colour schedule was built from
@@ -299,9 +340,8 @@ constexpr int kSliceSlack = 2;          // spare entry columns per slice (never 
 
 int materialise(ccp_csr *m);
 
-int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int n_groups, bool sort_by_permuted)
+int build_schedule_host(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int n_groups, bool sort_by_permuted)
 {
-    CCP_TRY(materialise(m));             // pending edits go into the compact host copy first
     const int n = m->n_rows;
     const double t_begin = now_s();
     std::vector<long> gcount((size_t)n_groups + 1, 0);
@@ -419,6 +459,223 @@ int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int 
     return CCP_OK;
 }
 
+// The compact host copy on the device (once per copy).
+void wait_device_upload(ccp_csr *m)
+{
+    if (m->uploader.joinable()) {
+        m->uploader.join();
+        if (m->uploader_status == CCP_OK) m->dev_csr_valid = m->dev_val_valid = true;
+    }
+}
+
+// Start copying the compact host arrays to the device in the background.
+int start_device_upload(ccp_csr *m)
+{
+    wait_device_upload(m);
+    m->dev_csr_valid = m->dev_val_valid = false;
+    const int n = m->n_rows;
+    const long nnz = m->row_ptr[n];
+    if (n <= 0 || nnz < (1L << 22)) return CCP_OK;        // small matrices: copied when first needed
+    CCP_TRY(m->d_row_ptr.alloc((size_t)n + 1));
+    CCP_TRY(m->d_col.alloc((size_t)nnz));
+    CCP_TRY(m->d_val.alloc((size_t)nnz));
+    m->uploader_status = CCP_OK;
+    m->uploader = std::thread([m, n, nnz] {
+        hipStream_t s = nullptr;
+        bool ok = hipSetDevice(m->device) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipMemcpyAsync(m->d_row_ptr.p, m->row_ptr.data(), sizeof(long) * ((size_t)n + 1), hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(m->d_col.p, m->col.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipMemcpyAsync(m->d_val.p, m->val.data(), sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, s) == hipSuccess;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        if (s) (void)hipStreamDestroy(s);
+        if (!ok) m->uploader_status = CCP_ERR_HIP;
+    });
+    return CCP_OK;
+}
+
+int ensure_device_csr(ccp_csr *m, bool with_values)
+{
+    wait_device_upload(m);
+    const int n = m->n_rows;
+    const long nnz = m->row_ptr[n];
+    if (!m->dev_csr_valid) {
+        CCP_TRY(m->d_row_ptr.alloc((size_t)n + 1));
+        CCP_TRY(m->d_col.alloc((size_t)std::max<long>(nnz, 1)));
+        CCP_HIP(hipMemcpyAsync(m->d_row_ptr.p, m->row_ptr.data(), sizeof(long) * ((size_t)n + 1), hipMemcpyHostToDevice, m->stream));
+        if (nnz) CCP_HIP(hipMemcpyAsync(m->d_col.p, m->col.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, m->stream));
+        m->dev_val_valid = false;
+    }
+    if (with_values && !m->dev_val_valid) {
+        CCP_TRY(m->d_val.alloc((size_t)std::max<long>(nnz, 1)));
+        if (nnz) CCP_HIP(hipMemcpyAsync(m->d_val.p, m->val.data(), sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, m->stream));
+    }
+    CCP_HIP(hipStreamSynchronize(m->stream));
+    m->dev_csr_valid = true;
+    if (with_values) m->dev_val_valid = true;
+    return CCP_OK;
+}
+
+// build_schedule with everything that is per row or per entry on the device: the stable ordering of the rows by group
+// (radix sort), the inverse permutation, the slice widths and offsets (scan) and the fill of the image.  The host keeps
+// what is per group and per slice (a few hundred thousand entries) and the mirrors incremental edits need.
+// 41.75 M unknowns, 208 M entries: 0.65 s on the host (permutation, slice table, fill, 4.4 GB upload) -> ~30 ms.
+int build_schedule_device(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int n_groups, bool sort_by_permuted)
+{
+    const int n = m->n_rows;
+    const double t_begin = now_s();
+    CCP_TRY(ensure_device_csr(m, true));
+    const double t_csr = now_s();
+    hipStream_t s = m->stream;
+    // rows per group (host: the caller's vector), slices per group
+    std::vector<long> gcount((size_t)n_groups + 1, 0);
+    {
+        const unsigned hw = std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        const long chunk = ((long)n + hw - 1) / hw;
+        std::vector<std::vector<long>> local(hw, std::vector<long>((size_t)n_groups, 0));
+        std::atomic<int> bad{0};
+        parallel_ranges(hw, 1, [&](long lo, long hi) {
+            for (long w = lo; w < hi; ++w)
+                for (long i = w * chunk; i < std::min<long>(n, (w + 1) * chunk); ++i) {
+                    const int g = group[i];
+                    if (g < 0 || g >= n_groups) bad.store(1, std::memory_order_relaxed);
+                    else local[w][g]++;
+                }
+        });
+        if (bad.load()) return CCP_ERR_STATE;
+        for (unsigned w = 0; w < hw; ++w)
+            for (int g = 0; g < n_groups; ++g) gcount[(size_t)g + 1] += local[w][g];
+        for (int g = 0; g < n_groups; ++g) gcount[g + 1] += gcount[g];
+    }
+    std::vector<int> srow0, srows;
+    sc.group_slice_ptr.assign((size_t)n_groups + 1, 0);
+    sc.group_block_off.assign((size_t)n_groups + 1, 0);
+    for (int g = 0; g < n_groups; ++g) {
+        for (long r = gcount[g]; r < gcount[g + 1]; r += kWave) {
+            srow0.push_back((int)r);
+            srows.push_back((int)std::min<long>(kWave, gcount[g + 1] - r));
+        }
+        sc.group_slice_ptr[g + 1] = (int)srow0.size();
+        const int slices = sc.group_slice_ptr[g + 1] - sc.group_slice_ptr[g];
+        sc.group_block_off[g + 1] = sc.group_block_off[g] + (slices + kBlock / kWave - 1) / (kBlock / kWave);
+    }
+    sc.n_slices = (int)srow0.size();
+    sc.n_groups = n_groups;
+    const int n_slices = sc.n_slices;
+    // the stable order of the rows by group
+    DevBuf<int> d_group, d_keys, d_iota, d_inv;
+    DevBuf<unsigned char> d_tmp;
+    CCP_TRY(sc.perm.alloc((size_t)n));
+    CCP_TRY(d_inv.alloc((size_t)n));
+    const unsigned nb = (unsigned)std::max<long>(1, std::min<long>(8192, ((long)n + kBlock - 1) / kBlock));
+    if (n_groups <= 1) {
+        hipLaunchKernelGGL(k_iota, dim3(nb), dim3(kBlock), 0, s, sc.perm.p, (long)n);
+    } else {
+        CCP_TRY(d_group.alloc((size_t)n));
+        CCP_TRY(d_keys.alloc((size_t)n));
+        CCP_TRY(d_iota.alloc((size_t)n));
+        CCP_HIP(hipMemcpyAsync(d_group.p, group.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_iota, dim3(nb), dim3(kBlock), 0, s, d_iota.p, (long)n);
+        int bits = 1;
+        while ((1L << bits) < n_groups) ++bits;
+        size_t bytes = 0;
+        CCP_HIP(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, d_group.p, d_keys.p, d_iota.p, sc.perm.p, n, 0, bits, s));
+        CCP_TRY(d_tmp.alloc(bytes));
+        CCP_HIP(hipcub::DeviceRadixSort::SortPairs(d_tmp.p, bytes, d_group.p, d_keys.p, d_iota.p, sc.perm.p, n, 0, bits, s));
+    }
+    hipLaunchKernelGGL(k_invert_perm, dim3(nb), dim3(kBlock), 0, s, sc.perm.p, d_inv.p, (long)n);
+    CCP_HIP(hipGetLastError());
+    // slices: widths, offsets
+    CCP_TRY(upload_vec(sc.slice_row0, srow0, s));
+    CCP_TRY(upload_vec(sc.slice_rows, srows, s));
+    CCP_TRY(sc.slice_width.alloc((size_t)std::max(n_slices, 1)));
+    CCP_TRY(sc.slice_off.alloc((size_t)std::max(n_slices, 1)));
+    DevBuf<long> d_cells;
+    CCP_TRY(d_cells.alloc((size_t)std::max(n_slices, 1)));
+    const unsigned sb = (unsigned)std::max(1, (n_slices + kBlock / kWave - 1) / (kBlock / kWave));
+    std::vector<int> swidth((size_t)n_slices), scap((size_t)n_slices);
+    std::vector<long> soff((size_t)n_slices);
+    long total = 0;
+    if (n_slices) {
+        hipLaunchKernelGGL(k_slice_widths, dim3(sb), dim3(kBlock), 0, s, m->d_row_ptr.p, sc.perm.p, sc.slice_row0.p, sc.slice_rows.p, n_slices,
+                           kSliceSlack, sc.slice_width.p, d_cells.p);
+        size_t bytes = 0;
+        CCP_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, d_cells.p, sc.slice_off.p, n_slices, s));
+        if (d_tmp.n < bytes) CCP_TRY(d_tmp.alloc(bytes));
+        CCP_HIP(hipcub::DeviceScan::ExclusiveSum(d_tmp.p, bytes, d_cells.p, sc.slice_off.p, n_slices, s));
+        CCP_HIP(hipMemcpyAsync(swidth.data(), sc.slice_width.p, sizeof(int) * (size_t)n_slices, hipMemcpyDeviceToHost, s));
+        CCP_HIP(hipMemcpyAsync(soff.data(), sc.slice_off.p, sizeof(long) * (size_t)n_slices, hipMemcpyDeviceToHost, s));
+        CCP_HIP(hipStreamSynchronize(s));
+        for (int k = 0; k < n_slices; ++k) scap[k] = swidth[k] + kSliceSlack;
+        total = soff[n_slices - 1] + (long)scap[n_slices - 1] * kWave;
+    }
+    const double t_table = now_s();
+    // the image; the arrays end in a reserve that relocated (grown) slices move into
+    const long reserve = std::max<long>(1L << 16, total / 64);
+    const size_t n_entries = (size_t)std::max<long>(total, 1);
+    CCP_TRY(sc.cols.alloc(n_entries + (size_t)reserve));
+    CCP_TRY(sc.vals.alloc(n_entries + (size_t)reserve));
+    if (total == 0) {
+        CCP_HIP(hipMemsetAsync(sc.cols.p, 0xff, sizeof(int), s));
+        CCP_HIP(hipMemsetAsync(sc.vals.p, 0, sizeof(double), s));
+    } else if (sort_by_permuted) {
+        hipLaunchKernelGGL((k_slice_fill<true>), dim3(sb), dim3(kBlock), 0, s, m->d_row_ptr.p, m->d_col.p, m->d_val.p, sc.perm.p, d_inv.p, n,
+                           sc.slice_row0.p, sc.slice_rows.p, sc.slice_width.p, sc.slice_off.p, n_slices, kSliceSlack, sc.cols.p, sc.vals.p);
+    } else {
+        hipLaunchKernelGGL((k_slice_fill<false>), dim3(sb), dim3(kBlock), 0, s, m->d_row_ptr.p, m->d_col.p, m->d_val.p, sc.perm.p, d_inv.p, n,
+                           sc.slice_row0.p, sc.slice_rows.p, sc.slice_width.p, sc.slice_off.p, n_slices, kSliceSlack, sc.cols.p, sc.vals.p);
+    }
+    CCP_HIP(hipGetLastError());
+    CCP_TRY(upload_vec(sc.group_ptr_dev, sc.group_slice_ptr, s));
+    CCP_TRY(upload_vec(sc.group_block_off_dev, sc.group_block_off, s));
+    sc.max_group_slices = 0;
+    for (int g = 0; g < n_groups; ++g)
+        sc.max_group_slices = std::max(sc.max_group_slices, sc.group_slice_ptr[g + 1] - sc.group_slice_ptr[g]);
+    // host mirrors for incremental edits
+    sc.inv.resize((size_t)n);
+    if (n) CCP_HIP(hipMemcpyAsync(sc.inv.data(), d_inv.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s));
+    CCP_HIP(hipStreamSynchronize(s));
+    if (getenv("CCP_GS_DEBUG"))
+        fprintf(stderr, "[ccp_gs] schedule of %d slices on the device: matrix upload %.3f s, ordering + slice table %.3f s, fill + mirrors %.3f s\n",
+                n_slices, t_csr - t_begin, t_table - t_csr, now_s() - t_table);
+    sc.gstart.swap(gcount);
+    sc.group_of = group;
+    sc.h_soff.swap(soff);
+    sc.h_swidth.swap(swidth);
+    sc.h_scap.swap(scap);
+    sc.entries_used = total;
+    sc.entries_cap = (long)n_entries + reserve;
+    sc.sort_by_permuted = sort_by_permuted;
+    m->stat_uploads++;
+    sc.built = true;
+    return CCP_OK;
+}
+
+int flush_edits(ccp_csr *m);
+
+// patch_edits: rows edited since the upload (the overlay) are NOT merged into the compact host copy first (one pass
+// over the whole matrix and a second upload of it: 0.7 s at 41.75 M unknowns for a thousand edited rows) — the image
+// is built from the compact copy as it stands and the edited rows are re-laid in it as patches, the way later edits
+// are.  Only for schedules whose row order does not depend on the edited structure (identity, a given colouring).
+int build_schedule(ccp_csr *m, Schedule &sc, const std::vector<int> &group, int n_groups, bool sort_by_permuted, bool patch_edits = false)
+{
+    static const bool on_host = getenv("CCP_GS_SCHEDULE_HOST") && atoi(getenv("CCP_GS_SCHEDULE_HOST")) != 0;
+    const bool patch = patch_edits && !m->overlay.empty();
+    if (!patch) CCP_TRY(materialise(m));             // pending edits go into the compact host copy first
+    if (!on_host && m->n_rows > 0) CCP_TRY(build_schedule_device(m, sc, group, n_groups, sort_by_permuted));
+    else CCP_TRY(build_schedule_host(m, sc, group, n_groups, sort_by_permuted));
+    if (patch) {
+        for (const auto &kv : m->overlay) m->touched.push_back(kv.first);
+        CCP_TRY(flush_edits(m));
+        if (!sc.built) {
+            // an edited row does not fit the order after all: merge and build again
+            CCP_TRY(materialise(m));
+            if (!on_host && m->n_rows > 0) CCP_TRY(build_schedule_device(m, sc, group, n_groups, sort_by_permuted));
+            else CCP_TRY(build_schedule_host(m, sc, group, n_groups, sort_by_permuted));
+        }
+    }
+    return CCP_OK;
+}
+
 // Current content of row i: the overlay if the row was edited since the upload, else the compact copy.
 struct RowView { const int *col; const double *val; long len; };
 RowView row_view(const ccp_csr *m, int i)
@@ -434,11 +691,14 @@ RowView row_view(const ccp_csr *m, int i)
 int materialise(ccp_csr *m)
 {
     if (m->overlay.empty()) return CCP_OK;
+    wait_device_upload(m);                 // (it reads the arrays replaced below)
     const int n = m->n_rows;
     std::vector<long> ptr((size_t)n + 1, 0);
     for (int i = 0; i < n; ++i) ptr[i + 1] = ptr[i] + row_view(m, i).len;
-    std::vector<int> col((size_t)ptr[n]);
-    std::vector<double> val((size_t)ptr[n]);
+    HostArr<int> col;
+    HostArr<double> val;
+    col.resize((size_t)ptr[n]);
+    val.resize((size_t)ptr[n]);
     parallel_ranges(n, 1 << 15, [&](long lo, long hi) {
         for (long i = lo; i < hi; ++i) {
             const RowView r = row_view(m, (int)i);
@@ -454,6 +714,7 @@ int materialise(ccp_csr *m)
     m->compact_poisson_w = -1;
     m->poisson_w = -1;
     m->region_values_ok = -1;
+    m->dev_csr_valid = false;
     return CCP_OK;
 }
 
@@ -789,21 +1050,19 @@ bool embed_region_device(ccp_csr *m, const std::vector<int> &colour, int &W, int
     if (!region_values_fit(m)) return false;
     lap("values");
     hipStream_t s = m->stream;
-    const long nnz = m->row_ptr[n];
-    DevBuf<long> d_ptr;
-    DevBuf<int> d_col, d_colour, d_up, d_flag, d_run_id, d_bad;
+    if (ensure_device_csr(m, false) != CCP_OK) return false;
+    struct Alias { const long *p; } d_ptr{m->d_row_ptr.p};
+    struct AliasI { const int *p; } d_col{m->d_col.p};
+    DevBuf<int> d_colour, d_up, d_flag, d_run_id, d_bad;
     DevBuf<unsigned char> d_left;
-    if (d_ptr.alloc((size_t)n + 1) != CCP_OK || d_col.alloc((size_t)nnz) != CCP_OK || d_colour.alloc((size_t)n) != CCP_OK ||
-        d_up.alloc((size_t)n) != CCP_OK || d_flag.alloc((size_t)n) != CCP_OK || d_run_id.alloc((size_t)n) != CCP_OK ||
-        d_left.alloc((size_t)n) != CCP_OK || d_bad.alloc(4) != CCP_OK)
+    if (d_colour.alloc((size_t)n) != CCP_OK || d_up.alloc((size_t)n) != CCP_OK || d_flag.alloc((size_t)n) != CCP_OK ||
+        d_run_id.alloc((size_t)n) != CCP_OK || d_left.alloc((size_t)n) != CCP_OK || d_bad.alloc(4) != CCP_OK)
         return false;
     auto hip_ok = [](hipError_t e) { return e == hipSuccess; };
-    if (!hip_ok(hipMemcpyAsync(d_ptr.p, m->row_ptr.data(), sizeof(long) * ((size_t)n + 1), hipMemcpyHostToDevice, s)) ||
-        !hip_ok(hipMemcpyAsync(d_col.p, m->col.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, s)) ||
-        !hip_ok(hipMemcpyAsync(d_colour.p, colour.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s)) ||
+    if (!hip_ok(hipMemcpyAsync(d_colour.p, colour.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s)) ||
         !hip_ok(hipMemsetAsync(d_bad.p, 0, sizeof(int) * 4, s)))
         return false;
-    lap("upload of row offsets, columns, colours");
+    lap("matrix (if not resident yet) and colours to the device");
     const unsigned blocks = (unsigned)(((long)n + kBlock - 1) / kBlock);
     hipLaunchKernelGGL(k_region_classify, dim3(blocks), dim3(kBlock), 0, s, d_ptr.p, d_col.p, n, d_up.p, d_left.p, d_flag.p, d_bad.p);
     // runs: inclusive scan of the run-start flags
@@ -989,24 +1248,34 @@ bool colouring_is_checkerboard(const ccp_csr *m)
 int ensure_natural(ccp_csr *m)
 {
     if (m->natural.built) return CCP_OK;
-    CCP_TRY(materialise(m));
     std::vector<int> group((size_t)m->n_rows, 0);
-    return build_schedule(m, m->natural, group, m->n_rows ? 1 : 0, false);
+    return build_schedule(m, m->natural, group, m->n_rows ? 1 : 0, false, true);
 }
 
 // The colouring of the multi-colour sweep: the caller's (checked to be proper) or greedy in row order.
 int resolve_colouring(ccp_csr *m, std::vector<int> &colour, int &nc)
 {
-    CCP_TRY(materialise(m));
     const double t0 = now_s();
     if (!m->user_colour.empty()) {
         colour = m->user_colour;
         nc = m->user_n_colours;
-        // a proper colouring: no stored off-diagonal entry couples two rows of one colour
+        // a proper colouring: no stored off-diagonal entry couples two rows of one colour.  Rows edited since the
+        // upload are checked in their current form (the overlay), the others in the compact host copy.
         std::atomic<int> bad{0};
         const int n = m->n_rows;
+        std::vector<unsigned char> edited;
+        if (!m->overlay.empty()) {
+            edited.assign((size_t)n, 0);
+            for (const auto &kv : m->overlay) {
+                edited[(size_t)kv.first] = 1;
+                for (int c : kv.second.col)
+                    if (c != kv.first && c >= 0 && c < n && colour[c] == colour[kv.first]) bad.store(1, std::memory_order_relaxed);
+            }
+        }
+        const unsigned char *skip = edited.empty() ? nullptr : edited.data();
         parallel_ranges(n, 1 << 16, [&](long lo, long hi) {
-            for (long i = lo; i < hi && !bad.load(std::memory_order_relaxed); ++i)
+            for (long i = lo; i < hi && !bad.load(std::memory_order_relaxed); ++i) {
+                if (skip && skip[i]) continue;
                 for (long k = m->row_ptr[i]; k < m->row_ptr[i + 1]; ++k) {
                     const int c = m->col[k];
                     if (c != (int)i && c >= 0 && c < n && colour[c] == colour[i]) {
@@ -1014,9 +1283,11 @@ int resolve_colouring(ccp_csr *m, std::vector<int> &colour, int &nc)
                         break;
                     }
                 }
+            }
         });
         if (bad.load()) return CCP_ERR_UNSUPPORTED;
     } else {
+        CCP_TRY(materialise(m));
         std::vector<long> lptr;
         std::vector<int> lidx;
         build_lower(m, lptr, lidx);
@@ -1062,7 +1333,7 @@ int ensure_multicolour(ccp_csr *m)
     std::vector<int> colour;
     int nc = 0;
     CCP_TRY(resolve_colouring(m, colour, nc));
-    CCP_TRY(build_schedule(m, m->multicolour, colour, nc, true));
+    CCP_TRY(build_schedule(m, m->multicolour, colour, nc, true, !m->user_colour.empty()));
     m->used_colour.swap(colour);
     m->used_n_colours = nc;
     return CCP_OK;
@@ -1253,6 +1524,7 @@ int ccp_csr_destroy(ccp_csr *m)
 try {
     if (!m) return CCP_OK;
     (void)hipSetDevice(m->device);
+    wait_device_upload(m);
     if (m->ev0) (void)hipEventDestroy(m->ev0);
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     if (m->grid) ccp_grid_destroy(m->grid);
@@ -1268,17 +1540,43 @@ try {
     if (n_rows < 0 || n_cols < 0 || n_values < 0) return CCP_ERR_BAD_ARG;
     if (n_rows > 0 && (!row_begin || !row_num_nze)) return CCP_ERR_BAD_ARG;
     if (n_values > 0 && (!values || !col_offset)) return CCP_ERR_BAD_ARG;
+    wait_device_upload(m);                 // (a copy of the previous matrix may still be in flight)
     // a failed upload must not leave the previous matrix half overwritten but still "uploaded"
     m->uploaded = false;
     m->natural.reset();
     m->multicolour.reset();
     m->lexicographic.reset();
     try {
+        // row offsets of the compact copy: a two-pass prefix sum over fixed chunks of rows (41.75 M rows: the serial
+        // loop was 50 ms of the upload)
         m->row_ptr.assign((size_t)n_rows + 1, 0);
-        for (int i = 0; i < n_rows; ++i) {
-            const long nz = row_num_nze[i];
-            if (nz < 0 || (nz > 0 && (row_begin[i] < 0 || (long)row_begin[i] + nz > n_values))) return CCP_ERR_BAD_ARG;
-            m->row_ptr[i + 1] = m->row_ptr[i] + nz;
+        {
+            const long K = std::max<long>(1, std::min<long>(256, n_rows / (1 << 16)));
+            const long per = ((long)n_rows + K - 1) / K;
+            std::vector<long> chunk_sum((size_t)K + 1, 0);
+            std::atomic<int> bad_rows{0};
+            parallel_ranges(K, 1, [&](long lo, long hi) {
+                for (long c = lo; c < hi; ++c) {
+                    long sum = 0;
+                    for (long i = c * per; i < std::min<long>(n_rows, (c + 1) * per); ++i) {
+                        const long nz = row_num_nze[i];
+                        if (nz < 0 || (nz > 0 && (row_begin[i] < 0 || (long)row_begin[i] + nz > n_values))) bad_rows.store(1, std::memory_order_relaxed);
+                        sum += std::max<long>(nz, 0);
+                    }
+                    chunk_sum[(size_t)c + 1] = sum;
+                }
+            });
+            if (bad_rows.load()) return CCP_ERR_BAD_ARG;
+            for (long c = 0; c < K; ++c) chunk_sum[c + 1] += chunk_sum[c];
+            parallel_ranges(K, 1, [&](long lo, long hi) {
+                for (long c = lo; c < hi; ++c) {
+                    long run = chunk_sum[c];
+                    for (long i = c * per; i < std::min<long>(n_rows, (c + 1) * per); ++i) {
+                        run += row_num_nze[i];
+                        m->row_ptr[i + 1] = run;
+                    }
+                }
+            });
         }
         const long nnz = m->row_ptr[n_rows];
         m->col.resize((size_t)nnz);
@@ -1318,6 +1616,7 @@ try {
     m->compact_poisson_w = -1;
     m->region_state = -1;
     m->region_values_ok = -1;
+    m->dev_csr_valid = false;
     m->edited = false;
     if (const char *e = getenv("CCP_GS_MASKED")) m->allow_region = atoi(e) != 0;
     if (m->grid) ccp_grid_destroy(m->grid);
@@ -1334,7 +1633,7 @@ try {
     CCP_TRY(m->tmp.alloc(vec));
     CCP_TRY(m->state.alloc(1));
     m->uploaded = true;
-    return CCP_OK;
+    return start_device_upload(m);         // the device copy proceeds in the background
 } CCP_ABI_CATCH
 
 int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours)

@@ -146,3 +146,83 @@ k_fill_int(int *__restrict__ p, long n, int v)
 }
 
 }  // namespace ccp
+
+// ---- construction of a sliced-ELL image on the device (ccp_csr.hip: build_schedule_device) ---------------------------
+namespace ccp {
+
+__global__ void __launch_bounds__(kBlock)
+k_iota(int *__restrict__ p, long n)
+{
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock) p[i] = (int)i;
+}
+
+// inv[perm[r]] = r
+__global__ void __launch_bounds__(kBlock)
+k_invert_perm(const int *__restrict__ perm, int *__restrict__ inv, long n)
+{
+    for (long r = (long)blockIdx.x * kBlock + threadIdx.x; r < n; r += (long)gridDim.x * kBlock) inv[perm[r]] = (int)r;
+}
+
+// One wave per slice: the widest row of the slice, and the entries its slab takes ((width + slack) * 64).
+__global__ void __launch_bounds__(kBlock)
+k_slice_widths(const long *__restrict__ row_ptr, const int *__restrict__ perm, const int *__restrict__ slice_row0,
+               const int *__restrict__ slice_rows, int n_slices, int slack, int *__restrict__ width, long *__restrict__ cells)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int s = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (s >= n_slices) return;
+    int len = 0;
+    if (lane < slice_rows[s]) {
+        const int old = perm[slice_row0[s] + lane];
+        len = (int)(row_ptr[old + 1] - row_ptr[old]);
+    }
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) len = max(len, __shfl_xor(len, off, kWave));
+    if (lane == 0) {
+        width[s] = len;
+        cells[s] = (long)(len + slack) * kWave;
+    }
+}
+
+// One wave per slice: padding (column -1, value 0) over the whole slab, then lane t lays row perm[row0 + t] out —
+// entry k at off + k*64 + t, columns mapped through inv (square part only) — and, SORTED, orders its entries by the
+// mapped column with the stable insertion sort of the host statement (rows are a handful of entries).
+template <bool SORTED>
+__global__ void __launch_bounds__(kBlock)
+k_slice_fill(const long *__restrict__ row_ptr, const int *__restrict__ col, const double *__restrict__ val, const int *__restrict__ perm,
+             const int *__restrict__ inv, int n, const int *__restrict__ slice_row0, const int *__restrict__ slice_rows,
+             const int *__restrict__ width, const long *__restrict__ slice_off, int n_slices, int slack, int *__restrict__ cols,
+             double *__restrict__ vals)
+{
+    const int lane = threadIdx.x & (kWave - 1);
+    const int s = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    if (s >= n_slices) return;
+    const long base = slice_off[s];
+    const int cap = width[s] + slack;
+    for (int k = 0; k < cap; ++k) {
+        cols[base + (long)k * kWave + lane] = -1;
+        vals[base + (long)k * kWave + lane] = 0.0;
+    }
+    if (lane >= slice_rows[s]) return;
+    const int old = perm[slice_row0[s] + lane];
+    const long a = row_ptr[old];
+    const int len = (int)(row_ptr[old + 1] - a);
+    for (int k = 0; k < len; ++k) {
+        const int c = col[a + k];
+        const int mc = (c >= 0 && c < n) ? inv[c] : c;
+        const double v = val[a + k];
+        int b = k;
+        if (SORTED) {
+            // (entries 0..k-1 of this lane are in place and sorted: shift the larger ones up)
+            while (b > 0 && cols[base + (long)(b - 1) * kWave + lane] > mc) {
+                cols[base + (long)b * kWave + lane] = cols[base + (long)(b - 1) * kWave + lane];
+                vals[base + (long)b * kWave + lane] = vals[base + (long)(b - 1) * kWave + lane];
+                --b;
+            }
+        }
+        cols[base + (long)b * kWave + lane] = mc;
+        vals[base + (long)b * kWave + lane] = v;
+    }
+}
+
+}  // namespace ccp

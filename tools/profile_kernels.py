@@ -7,6 +7,8 @@ one PMC counter per run; tools/profile_round.sh drives the passes):
   pipe    k_sell_gs_pipe   the same matrix in the reference's own order (pipelined level schedule)
   lex     k_lex_strips     reference-order sweeps of the 16384^2 grid (strip waves; CCP_GS_LEX_MODE=planes: k_lex_plane)
   edge    k_fused_sweep<8,0,2,true>   one interior row block of an 8-GPU run: intervals with the in-launch edge hand-off
+  mid     k_fused_sweep<8,0,2>   BASELINE configs[1]: 4096^2 x 3 channels, the tiling bench.py pins (T=8, R=140)
+  cg      k_cg_apply_march / k_cg_residual   the fused conjugate-gradient loop on 3 x 8192x4096 (the lab8 blend's call)
 usage: profile_kernels.py [--canvas N] [--grid N] [--sweeps K] [apply] [gs] [pipe] [lex]   (default: all four)
 Under --pmc the two launch-bound kernels issue tens of thousands of tiny dispatches, each serialised by the
 counter collection: use a smaller --canvas / --grid there."""
@@ -63,6 +65,25 @@ if "lex" in what:
     g.fill_x(1.0)
     rep = g.gauss_seidel_lexicographic(0.0, a.sweeps, 0)[0]
     print(f"lex: {rep.iterations} sweeps of {W}x{H} in {rep.seconds:.3f} s", flush=True)
+    g.close()
+if "mid" in what:
+    g = capi.Grid(4096, 4096, 3)
+    g.randomize_x(1234, 0.0, 255.0)
+    g.b_from_x()
+    g.fill_x(1.0)
+    g.set_tiling(8, 140)
+    for _ in range(3):
+        g.sweep(32)
+    g.synchronize()
+    print("mid done", flush=True)
+    g.close()
+if "cg" in what:
+    g = capi.Grid(8192, 4096, 3)
+    g.randomize_x(1234, 0.0, 255.0)
+    g.b_from_x()
+    g.fill_x(0.0)
+    g.conjugate_gradient(0.0, 10)
+    print("cg done", flush=True)
     g.close()
 if "edge" in what:
     W = H = 16384

@@ -1,0 +1,30 @@
+#!/bin/bash
+# rocprofv3 passes of round 3 (run on the GPU box from the repo root): kernel trace + stats of the default bench.py
+# command; FETCH_SIZE / WRITE_SIZE passes (separate runs, as the guide prescribes) of the bench's timed kernels and of
+# the configs[1] / [4] / reference-order / CG kernels; summaries under gpurun_out/r03/prof/, copied to profiles/ by hand.
+set -o pipefail
+out=$PWD/gpurun_out/r03/prof
+mkdir -p "$out"
+export TMPDIR=/tmp
+lean="--no-configs --no-cpu-baseline --no-converge --no-parity --no-reference-order"
+rocprofv3 --output-format csv --kernel-trace --stats -d "$out/kt_bench" -o bench -- python3 bench.py --no-cpu-baseline > "$out/bench_under_kt.json" 2> "$out/kt_bench.log" || exit 1
+cp "$(find "$out/kt_bench" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats_bench.csv"
+echo "kt bench done"
+pass() {  # tag, command...
+    tag=$1; shift
+    for c in FETCH_SIZE WRITE_SIZE; do
+        timeout -k 10 400 rocprofv3 --output-format csv --pmc $c -d "$out/pmc_${c}_$tag" -o k -- "$@" > "$out/pmc_${c}_$tag.txt" 2> "$out/pmc_${c}_$tag.log" \
+            && python3 tools/pmc_summary.py "$(find "$out/pmc_${c}_$tag" -name '*counter_collection.csv' | head -1)" "$out/pmc_${c}_$tag.csv"
+        echo "pmc $c $tag rc=$?"
+    done
+}
+pass bench python3 bench.py $lean --steps 3 --warmup 1
+pass mid python3 tools/profile_kernels.py mid
+pass region python3 tools/profile_kernels.py region
+pass sell python3 tools/profile_kernels.py gs
+pass lex python3 tools/profile_kernels.py --sweeps 64 lex
+pass cg python3 tools/profile_kernels.py cg
+python3 tools/make_traffic.py "$out" "$out/traffic.json"
+find "$out" -name '*counter_collection.csv' -delete
+find "$out" -name '*kernel_trace.csv' -size +5M -delete
+ls "$out"
