@@ -2,6 +2,7 @@
 #include "ccp_grid_kernels.hpp"
 #include "ccp_grid_fused.hpp"
 #include "ccp_grid_lex.hpp"
+#include "ccp_grid_lex2.hpp"
 #include "ccp_cg.hpp"
 #include "ccp_grid_cg.hpp"
 #include "ccp_comm.hpp"
@@ -847,7 +848,8 @@ try {
     if (const char *e = getenv("CCP_GS_MULTI")) g->multi = atoi(e);
     if (const char *e = getenv("CCP_GS_TRACE_FILE")) g->trace_file = e[0] ? e : nullptr;
     if (const char *e = getenv("CCP_GS_SIDE_ROWS")) g->side_rows_override = atoi(e);
-    if (const char *e = getenv("CCP_GS_LEX_MODE")) g->lex_mode = strcmp(e, "planes") == 0 ? 0 : (strcmp(e, "strips") == 0 ? 1 : (strcmp(e, "skew") == 0 ? 2 : 3));
+    if (const char *e = getenv("CCP_GS_LEX_MODE"))
+        g->lex_mode = strcmp(e, "planes") == 0 ? 0 : (strcmp(e, "strips") == 0 ? 1 : (strcmp(e, "skew") == 0 ? 2 : (strcmp(e, "wg2") == 0 ? 4 : (strcmp(e, "wg") == 0 ? 3 : g->lex_mode))));
     if (const char *e = getenv("CCP_GS_LEX_T")) g->lex_tmax = std::max(1, std::min(8, atoi(e)));
     if (const char *e = getenv("CCP_GS_LEX_CHUNK")) g->lex_chunk = atoi(e);
     if (const char *e = getenv("CCP_GS_TMAX")) g->fuse_tmax = std::max(1, std::min(kFusedMaxT, atoi(e)));
@@ -1444,12 +1446,13 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
 {
     const LexGeom &lg = g->lexg;
     const int C = g->desc.channels;
-    const int S = (lg.W - 1 + 2 * (T - 1)) / kLexSkewCols + 1;
-    const long edge_steps = kWave + lg.H + 2 * (T - 1);
+    const bool wg2 = g->lex_mode == 4;                       // two pixels per lane and step: strips of 126 skewed columns
+    const int S = (lg.W - 1 + 2 * (T - 1)) / (wg2 ? kLex2Cols : kLexSkewCols) + 1;
+    const long edge_steps = (wg2 ? 2 * kWave : kWave) + lg.H + 2 * (T - 1);
     int chunk = g->lex_chunk;
     if (chunk <= 0) chunk = std::min(lg.W, lg.H) <= 1024 ? 8 : 16;
     chunk = std::max(kLexSkewAhead, std::min(chunk, kWave)) / kLexSkewAhead * kLexSkewAhead;   // whole ring turns per chunk
-    const bool wg = g->lex_mode == 3;
+    const bool wg = g->lex_mode == 3 || wg2;
     const size_t need = (size_t)C * groups * S * (wg ? kLexWordStride : 1), edges = (size_t)C * S * edge_steps * 2 * T + (wg ? (size_t)C * groups * S * kLexScratch : 0);   // (+ the storers' scratch slots)
     if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
     if (wg && (g->lex_order_groups != groups || g->lex_order_strips != S)) {
@@ -1486,7 +1489,13 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
 #define CCP_LEX_WG(KERNEL, CHECK, P, STRIDE)                                                                                        \
     hipLaunchKernelGGL((KERNEL<T, CHECK>), grid, block, pad, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,              \
                        g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, P, STRIDE)
-        if (g->masked) {
+        if (wg2 && g->masked) {
+            if (partial) CCP_LEX_WG(k_lex_wg2_masked, true, partial, lex_partials_per_sweep(g));
+            else CCP_LEX_WG(k_lex_wg2_masked, false, nop, 0L);
+        } else if (wg2) {
+            if (partial) CCP_LEX_WG(k_lex_wg2, true, partial, lex_partials_per_sweep(g));
+            else CCP_LEX_WG(k_lex_wg2, false, nop, 0L);
+        } else if (g->masked) {
             if (partial) CCP_LEX_WG(k_lex_wg_masked, true, partial, lex_partials_per_sweep(g));
             else CCP_LEX_WG(k_lex_wg_masked, false, nop, 0L);
         } else {
@@ -1497,7 +1506,7 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
         CCP_HIP(hipGetLastError());
         return CCP_OK;
     }
-    if (g->masked) return CCP_ERR_UNSUPPORTED;               // (only k_lex_wg knows Dirichlet masks)
+    if (g->masked) return CCP_ERR_UNSUPPORTED;               // (only k_lex_wg / k_lex_wg2 know Dirichlet masks)
     if (partial)
         hipLaunchKernelGGL((k_lex_skew<T, true>), grid, dim3(kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S, chunk,
                            g->lex_progress.p, g->lex_ticket.p, g->lex_edges.p, edge_steps, mask, partial, lex_partials_per_sweep(g));
@@ -1560,7 +1569,7 @@ int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max
 try {
     CCP_TRY(bind(g));
     if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;   // whole image only
-    if (g->masked && g->lex_mode != 3) return CCP_ERR_UNSUPPORTED;   // Dirichlet masks: k_lex_wg only
+    if (g->masked && g->lex_mode < 3) return CCP_ERR_UNSUPPORTED;   // Dirichlet masks: k_lex_wg / k_lex_wg2 only
     if (max_iteration < 0 || check_every < 0) return CCP_ERR_BAD_ARG;
     const int C = g->desc.channels, W = g->desc.width, H = g->desc.height;
     LexGeom &lg = g->lexg;

@@ -461,7 +461,7 @@ k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGe
 // grid = (G * S, channels), block = (T + 2) * 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
 constexpr int kLexRing = 4;                        // result rows kept per sweep: written at step d, read at step d+3, free at d+4
 constexpr int kLexBRows = 32;
-constexpr int kLexSlackRows = 128;                 // diagonal rows allocated beyond the last one (k_lex_wg prefetches past the image)
+constexpr int kLexSlackRows = 320;                 // diagonal rows allocated beyond the last one (k_lex_wg / k_lex_wg2 prefetch past the image: up to ~160 rows at 128-column strips)
 constexpr int kLexScratch = 32;                    // doubles per workgroup the storer of k_lex_wg may write to and nobody reads
 constexpr int kLexStoresPerBlock = 8 * 2 + 1;      // k_lex_wg's storer: two stores per step (x row, edge values) + the publication, per 8-step block
 constexpr int kLexPublishLagBlocks = 2;            // ... publishes the steps before block db - 8*2 ...

@@ -54,7 +54,7 @@ def test_vs_oracle_seeded(capi, orc, W, H):
         assert np.array_equal(x[0], want), (W, H, k, np.abs(x[0] - want).max())
 
 
-@pytest.mark.parametrize("engine", ["wg", "strips", "skew", "planes"])
+@pytest.mark.parametrize("engine", ["wg", "wg2", "strips", "skew", "planes"])
 def test_every_engine_of_the_reference_order(capi, orc, engine, monkeypatch):
     """The four implementations of the reference-order sweep (CCP_GS_LEX_MODE, read when the handle is made;
     default wg) give the oracle's bits and stop where it stops — on grids tall enough that the workgroup

@@ -7,9 +7,18 @@ out=$PWD/gpurun_out/r03/prof
 mkdir -p "$out"
 export TMPDIR=/tmp
 lean="--no-configs --no-cpu-baseline --no-converge --no-parity --no-reference-order"
-rocprofv3 --output-format csv --kernel-trace --stats -d "$out/kt_bench" -o bench -- python3 bench.py --no-cpu-baseline > "$out/bench_under_kt.json" 2> "$out/kt_bench.log" || exit 1
-cp "$(find "$out/kt_bench" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats_bench.csv"
-echo "kt bench done"
+what=${1:-all}
+if [ "$what" = kt ] || [ "$what" = all ]; then
+    t0=$(date +%s)
+    python3 bench.py > "$out/bench_n1.json" 2> "$out/bench_n1.err" &
+    pid=$!
+    while kill -0 $pid 2>/dev/null; do echo "bench.py running ($(( $(date +%s) - t0 )) s)"; sleep 20; done
+    wait $pid; echo "bench rc=$? after $(( $(date +%s) - t0 )) s"; echo "$(( $(date +%s) - t0 ))" > "$out/bench_n1.seconds"
+    rocprofv3 --output-format csv --kernel-trace --stats -d "$out/kt_bench" -o bench -- python3 bench.py --no-cpu-baseline > "$out/bench_under_kt.json" 2> "$out/kt_bench.log" || exit 1
+    cp "$(find "$out/kt_bench" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats_bench.csv"
+    echo "kt bench done"
+    [ "$what" = kt ] && { find "$out" -name '*kernel_trace.csv' -size +5M -delete; exit 0; }
+fi
 pass() {  # tag, command...
     tag=$1; shift
     for c in FETCH_SIZE WRITE_SIZE; do
