@@ -289,8 +289,7 @@ def config1(capi, cpu):
     g.randomize_x(1234, 0.0, 255.0)
     g.b_from_x()
     g.fill_x(1.0)
-    T, R = CONFIG1_TILING                                       # what ccp_grid_tune picks for this shape: pinned, so that the
-    g.set_tiling(T, R)                                          # committed PMC traffic profile is of the tiling that is timed
+    T, R, _ = g.tune(8)                                         # (8, 140) on MI355X: the tiling the committed PMC traffic profile was made with
     g.sweep(ips)
     g.region_begin()
     for _ in range(steps):
@@ -301,7 +300,7 @@ def config1(capi, cpu):
     per_launch = ms / max(launches, 1)
     model = BYTES_PER_PIXEL_PASS * W * H * C
     return {"workload": "4096x4096 3-channel Poisson blend (one matrix, three right-hand sides), red-black Gauss-Seidel",
-            "kernel": f"k_fused_sweep<{T},0,2>", "tiling": {"fused_depth": T, "rows_per_chunk": R, "tuned": False},
+            "kernel": f"k_fused_sweep<{T},0,2>", "tiling": {"fused_depth": T, "rows_per_chunk": R, "tuned": True},
             "ms": ms / steps, "iters": ips, "pixel_updates_per_s": ups,
             "bytes_model": f"{BYTES_PER_PIXEL_PASS:.0f} B per pixel and channel per pass of {T} iterations",
             "avg_launch_ms": per_launch, "frac": model / (per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -341,10 +340,10 @@ def config4(capi):
     # colour-ordered sweep), the recognition switched off for this handle (CCP_GS_MASKED=0 is read at create)
     sell = None
     try:
-        os.environ["CCP_GS_MASKED"] = "0"
+        os.environ["CCP_GS_MASKED"] = "0"                                 # (read when the matrix is uploaded)
         ms_ = capi.CsrMatrix()
-        os.environ.pop("CCP_GS_MASKED", None)
         ms_.upload_compressed(v, c, r)
+        os.environ.pop("CCP_GS_MASKED", None)
         ms_.set_colouring(colour, 2)
         ms_.gauss_seidel(b, 0.0, 2, check_every=0)                        # builds the schedule
         xs, reps = ms_.gauss_seidel(b, 0.0, iters, check_every=0)

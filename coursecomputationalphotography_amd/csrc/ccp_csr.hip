@@ -164,7 +164,7 @@ struct ccp_csr {
     int region_w = 0, region_h = 0;
     bool allow_region = true;              // CCP_GS_MASKED=0 keeps such matrices on the sliced-ELL path
     int region_values_ok = -1;             // every stored value is 4 (diagonal) or -1: -1 unknown, 0 no, 1 yes (compact host copy)
-    int region_solves = 0;                 // solves on the region grid so far (its tiling is tuned at the third)
+    int region_solves = 0;                 // solves on the region grid so far (its tiling is tuned at the second)
     bool region_tuned = false;
     int last_path = 0;                     // CCP_PATH_* of the last solve
     long last_launches = 0;                // sweep launches of the last solve on a grid twin
@@ -1812,9 +1812,9 @@ try {
             hipStream_t s = m->stream;
             ccp_grid *g = m->region_grid;
             CCP_TRY(ccp_grid_set_stream(g, s));
-            // the first solves run on the default tiling of a mask grid; a matrix that keeps being solved gets its
-            // tiling timed once (speed only: ~0.1 s at 41.75 M unknowns, fifty times a 50-sweep solve)
-            if (!m->region_tuned && ++m->region_solves >= 3) {
+            // the first solve runs on the default tiling of a mask grid; a matrix that is solved again gets its tiling
+            // timed once (speed only: ~0.1 s at 41.75 M unknowns, forty times a 50-sweep solve)
+            if (!m->region_tuned && ++m->region_solves >= 2) {
                 CCP_TRY(ccp_grid_tune(g, 8, nullptr, nullptr, nullptr));
                 m->region_tuned = true;
             }

@@ -122,7 +122,7 @@ __device__ __forceinline__ void lex2_compute(Pair &h1, double &acc, Pair (*ring)
     const Stencil sa = classify(g, a_on ? xa : 0, 1, 1), sb = classify(g, b_on ? xb : 0, 1, 1);
     const bool a_off = !a_on || sa.diag == 0, b_off = !b_on || sb.diag == 0;
     const bool a_x0 = !a_off && !sa.left, a_xl = !a_off && !sa.right;
-    const bool b_x0 = !b_off && !sb.left, b_xl = !b_off && !sb.right;
+    const bool b_xl = !b_off && !sb.right;                               // (B is never column 0: its column is odd)
     const bool a_wrote = KIND == 0 ? !ghost : !a_off, b_wrote = KIND == 0 ? !ghost : !b_off;
     // inner blocks: every real pixel of the wave has 1 <= y <= H-2 at all 8 steps.  A: y = d - x'_A - 2t, B: one less;
     // x'_A ranges over xs0+2 .. xs0+126
@@ -160,7 +160,6 @@ __device__ __forceinline__ void lex2_compute(Pair &h1, double &acc, Pair (*ring)
                         q = a3 / 3.0;
                     }
                     nv.a = a_x0 ? q : nv.a;
-                    if (b_x0) nv.b = (vv.b + ((up_b + right_b) + down_b)) / 3.0;  // (never taken: B's column is odd)
                 }
                 if (KIND & 2) {
                     nv.a = a_xl ? vv.a + left_a : nv.a;                          // column W-1: only the left neighbour, diagonal 1
