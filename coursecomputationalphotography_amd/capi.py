@@ -27,7 +27,7 @@ ORDER_MULTICOLOUR = 1
 # every symbol include/ccp_gs.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "ccp_status_string", "ccp_abi_version", "ccp_device_count",
-    "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_set_colouring", "ccp_csr_get_colouring", "ccp_csr_insert", "ccp_csr_insert_many", "ccp_csr_edit_stats", "ccp_csr_last_path", "ccp_csr_embed_region_host",
+    "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_upload_rows", "ccp_csr_rows_info", "ccp_csr_set_colouring", "ccp_csr_get_colouring", "ccp_csr_insert", "ccp_csr_insert_many", "ccp_csr_edit_stats", "ccp_csr_last_path", "ccp_csr_embed_region_host",
     "ccp_csr_gauss_seidel", "ccp_csr_conjugate_gradient", "ccp_csr_conjugate_gradient_jacobi", "ccp_csr_apply_to_vector", "ccp_csr_residual_norm2",
     "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
@@ -144,6 +144,8 @@ def load() -> C.CDLL:
     L.ccp_csr_create.argtypes = [C.c_int, C.POINTER(vp)]
     L.ccp_csr_destroy.argtypes = [vp]
     L.ccp_csr_upload.argtypes = [vp, i32, i32, i64, vp, vp, vp, vp]
+    L.ccp_csr_upload_rows.argtypes = [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, i32]
+    L.ccp_csr_rows_info.argtypes = [vp] + [C.POINTER(i32)] * 4 + [C.POINTER(i64)] * 2
     L.ccp_csr_set_colouring.argtypes = [vp, vp, i32]
     L.ccp_csr_get_colouring.argtypes = [vp, vp, C.POINTER(i32)]
     L.ccp_csr_insert.argtypes = [vp, i32, i32, dbl]
@@ -335,6 +337,24 @@ class CsrMatrix:
                                     _ptr(row_begin), _ptr(row_num_nze)), "ccp_csr_upload")
         self.n_rows, self.n_cols = n_rows, n_cols
         return self
+
+    def upload_rows(self, comm: "Comm", first_row, n_global, values, col_offset, row_begin, row_num_nze, colour, n_colours):
+        """COLLECTIVE: this handle becomes the block of rows [first_row, first_row + len(row_begin)) of an n_global-row
+        matrix distributed over comm's ranks (global column indices; colour: the owned rows of a proper colouring of the
+        whole matrix).  Afterwards gauss_seidel / apply_to_vector / residual_norm2 take and return the block's own rows."""
+        values, col_offset = _f64(values), _i32(col_offset)
+        row_begin, row_num_nze, colour = _i32(row_begin), _i32(row_num_nze), _i32(colour)
+        n_rows = len(row_begin)
+        check(self.L.ccp_csr_upload_rows(self.h, comm.h, first_row, n_rows, n_global, len(values), _ptr(values), _ptr(col_offset),
+                                         _ptr(row_begin), _ptr(row_num_nze), _ptr(colour), n_colours), "ccp_csr_upload_rows")
+        self.n_rows = self.n_cols = n_rows
+        return self
+
+    def rows_info(self):
+        a = [C.c_int32() for _ in range(4)]
+        b = [C.c_int64() for _ in range(2)]
+        check(self.L.ccp_csr_rows_info(self.h, *[C.byref(t) for t in a + b]), "ccp_csr_rows_info")
+        return dict(zip(("first_row", "n_rows", "n_ghost", "n_peers", "values_sent", "exchanges"), (t.value for t in a + b)))
 
     def upload_compressed(self, values, col_offset, row_offset, n_cols=None):
         """Compressed CSR (n+1 offsets) -> the slack arrays with zero slack."""

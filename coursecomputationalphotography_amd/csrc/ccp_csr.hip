@@ -4,6 +4,7 @@
 #include "ccp_csr_kernels.hpp"
 #include "ccp_csr_region.hpp"
 #include "ccp_cg.hpp"
+#include "ccp_comm.hpp"
 
 #include <hipcub/hipcub.hpp>
 
@@ -16,6 +17,7 @@
 #include <memory>
 #include <thread>
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <unordered_map>
 
@@ -170,6 +172,42 @@ struct ccp_csr {
     long last_launches = 0;                // sweep launches of the last solve on a grid twin
     bool edited = false;                   // ccp_csr_insert changed the matrix since the upload
     bool allow_one_block = true;           // CCP_GS_ONE_BLOCK=0: always one launch per group
+    // Row block of a matrix distributed over the ranks of a communicator (ccp_csr_upload_rows; SURVEY §8e: "row-block by
+    // unknown index with a halo index list").  The handle then holds an EXTENDED square system: the columns its rows
+    // reference outside the block ("ghosts") become empty rows of their own, numbered with the owned rows in the order
+    // of their global indices —
+    //     [ghosts below row_begin | owned rows | ghosts above the block]
+    // — so every schedule, kernel and buffer of the single-GPU path applies unchanged: an empty row has no diagonal and
+    // is skipped by the sweep (sparse-matrix.h:361), colour-major order of the extended rows is the global colour-major
+    // order restricted to them (a row sums its couplings in the order the one-GPU sweep does: same bits), and the ghosts
+    // a peer owns are one contiguous range per colour that the exchange receives straight into x.
+    struct RowBlock {
+        bool on = false;
+        ccp_comm *comm = nullptr;
+        int row_begin = 0, n_local = 0, n_global = 0, n_lo = 0, n_ghost = 0, n_colours = 0, peers = 0;
+        std::vector<int> ghost;                              // global indices of the ghosts, ascending
+        // natural order (applyToVector, residual): one message per peer
+        std::vector<int> nat_send_cnt, nat_send_off, nat_recv_cnt, nat_recv_pos;      // [world]
+        DevBuf<int> nat_send_pos;                            // extended indices to gather, peer by peer
+        // colour-major order (the sweep): one message per peer and colour
+        std::vector<int> col_send_cnt, col_send_off, col_recv_cnt, col_recv_pos;      // [n_colours * world]
+        std::vector<long> col_seg_off;                       // [n_colours + 1] segment of col_send_pos / sendbuf per colour
+        DevBuf<int> col_send_pos;                            // positions in the colour-major x to gather
+        DevBuf<double> sendbuf;
+        long nat_total = 0;                                  // entries of nat_send_pos
+        long exchanges = 0, values_sent = 0;
+        void reset()
+        {
+            on = false;
+            comm = nullptr;
+            row_begin = n_local = n_global = n_lo = n_ghost = n_colours = peers = 0;
+            ghost.clear();
+            nat_send_cnt.clear(); nat_send_off.clear(); nat_recv_cnt.clear(); nat_recv_pos.clear();
+            col_send_cnt.clear(); col_send_off.clear(); col_recv_cnt.clear(); col_recv_pos.clear(); col_seg_off.clear();
+            nat_send_pos.release(); col_send_pos.release(); sendbuf.release();
+            exchanges = values_sent = nat_total = 0;
+        }
+    } rb;
 };
 
 namespace {
@@ -1500,6 +1538,93 @@ int ensure_partial(ccp_csr *m, long blocks)
 
 unsigned blocks_for(long n) { return (unsigned)std::max<long>(1, std::min<long>(4096, (n + kBlock - 1) / kBlock)); }
 
+// ---- row block of a distributed matrix (ccp_csr::RowBlock) ---------------------------------------------------------
+
+// Every rank's status word, gathered: the own status if it is a failure, CCP_ERR_STATE if only a peer failed.  The
+// set-up of a row block is collective; a rank that found its arguments wrong must not leave the others waiting in the
+// next message.
+int rb_agree(ccp_comm *c, hipStream_t s, int status)
+{
+    const RcclApi *api = rccl_api();
+    if (!api) return CCP_ERR_RCCL;
+    int *dev = reinterpret_cast<int *>(c->scratch.p);
+    std::vector<int> all((size_t)c->world);
+    CCP_HIP(hipMemcpyAsync(dev + c->rank, &status, sizeof(int), hipMemcpyHostToDevice, s));
+    CCP_RCCL(api->AllGather(dev + c->rank, dev, 1, ncclInt32, c->comm, s));
+    CCP_HIP(hipMemcpyAsync(all.data(), dev, sizeof(int) * all.size(), hipMemcpyDeviceToHost, s));
+    CCP_HIP(hipStreamSynchronize(s));
+    if (status != CCP_OK) return status;
+    for (int v : all)
+        if (v != CCP_OK) return CCP_ERR_STATE;
+    return CCP_OK;
+}
+
+// One grouped exchange on the handle's stream: `send_cnt[r]` doubles from sendbuf + send_off[r] to rank r, `recv_cnt[r]`
+// doubles from rank r into x + recv_pos[r].
+int rb_messages(ccp_csr *m, const int *send_cnt, const int *send_off, const int *recv_cnt, const int *recv_pos, double *x)
+{
+    ccp_csr::RowBlock &rb = m->rb;
+    const RcclApi *api = rccl_api();
+    if (!api || !rb.comm) return CCP_ERR_STATE;
+    const int W = rb.comm->world;
+    bool any = false;
+    for (int r = 0; r < W; ++r) any |= send_cnt[r] > 0 || recv_cnt[r] > 0;
+    if (!any) return CCP_OK;
+    CCP_RCCL(api->GroupStart());
+    ncclResult_t res = ncclSuccess;
+    for (int r = 0; r < W && res == ncclSuccess; ++r) {
+        if (send_cnt[r] > 0) {
+            res = api->Send(rb.sendbuf.p + send_off[r], (size_t)send_cnt[r], ncclDouble, r, rb.comm->comm, m->stream);
+            rb.values_sent += send_cnt[r];
+        }
+        if (recv_cnt[r] > 0 && res == ncclSuccess)
+            res = api->Recv(x + recv_pos[r], (size_t)recv_cnt[r], ncclDouble, r, rb.comm->comm, m->stream);
+    }
+    const ncclResult_t e = api->GroupEnd();
+    if (res != ncclSuccess) return rccl_fail(res, "ncclSend/ncclRecv", __FILE__, __LINE__);
+    CCP_RCCL(e);
+    rb.exchanges++;
+    return CCP_OK;
+}
+
+// The rows of colour g this block owns have new values: hand the ones other blocks reference to their ghosts and
+// take ours (m->x in colour-major order).
+int rb_exchange_colour(ccp_csr *m, int g)
+{
+    ccp_csr::RowBlock &rb = m->rb;
+    const int W = rb.comm->world;
+    const long seg0 = rb.col_seg_off[(size_t)g], seg = rb.col_seg_off[(size_t)g + 1] - seg0;
+    if (seg > 0) {
+        hipLaunchKernelGGL((k_permute<true>), dim3(blocks_for(seg)), dim3(kBlock), 0, m->stream, rb.sendbuf.p + seg0, m->x.p,
+                           rb.col_send_pos.p + seg0, seg);
+        CCP_HIP(hipGetLastError());
+    }
+    const size_t at = (size_t)g * W;
+    return rb_messages(m, &rb.col_send_cnt[at], &rb.col_send_off[at], &rb.col_recv_cnt[at], &rb.col_recv_pos[at], m->x.p);
+}
+
+// All ghosts of a vector in natural (extended) order.
+int rb_exchange_natural(ccp_csr *m, double *x)
+{
+    ccp_csr::RowBlock &rb = m->rb;
+    const long total = rb.nat_total;
+    if (total > 0) {
+        hipLaunchKernelGGL((k_permute<true>), dim3(blocks_for(total)), dim3(kBlock), 0, m->stream, rb.sendbuf.p, x, rb.nat_send_pos.p, total);
+        CCP_HIP(hipGetLastError());
+    }
+    return rb_messages(m, rb.nat_send_cnt.data(), rb.nat_send_off.data(), rb.nat_recv_cnt.data(), rb.nat_recv_pos.data(), x);
+}
+
+// A vector of the block (n_local host values) into the extended natural order on the device: ghosts 0.
+int rb_stage(ccp_csr *m, double *dst_dev, const double *host_local)
+{
+    const ccp_csr::RowBlock &rb = m->rb;
+    CCP_HIP(hipMemsetAsync(dst_dev, 0, sizeof(double) * (size_t)std::max(m->n_rows, 1), m->stream));
+    if (rb.n_local) CCP_HIP(hipMemcpyAsync(dst_dev + rb.n_lo, host_local, sizeof(double) * (size_t)rb.n_local, hipMemcpyHostToDevice, m->stream));
+    return CCP_OK;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -1618,6 +1743,7 @@ try {
     m->region_values_ok = -1;
     m->dev_csr_valid = false;
     m->edited = false;
+    m->rb.reset();                         // (ccp_csr_upload_rows sets the row block up again after this call)
     if (const char *e = getenv("CCP_GS_MASKED")) m->allow_region = atoi(e) != 0;
     if (m->grid) ccp_grid_destroy(m->grid);
     m->grid = nullptr;
@@ -1636,10 +1762,274 @@ try {
     return start_device_upload(m);         // the device copy proceeds in the background
 } CCP_ABI_CATCH
 
+int ccp_csr_upload_rows(ccp_csr *m, ccp_comm *c, int32_t first_row, int32_t n_rows, int32_t n_global, int64_t n_values,
+                        const double *values, const int32_t *col_offset, const int32_t *row_begin, const int32_t *row_num_nze,
+                        const int32_t *colour, int32_t n_colours)
+try {
+    CCP_TRY(bind(m));
+    if (!c || c->device != m->device) return CCP_ERR_BAD_ARG;
+    const RcclApi *api = rccl_api();
+    if (!api) return CCP_ERR_RCCL;
+    wait_device_upload(m);
+    hipStream_t s = m->stream;
+    const int W = c->world, me = c->rank;
+    const long lo = first_row, hi = (long)first_row + n_rows;
+
+    // ---- 1. the block's own arguments; the columns outside it (the ghosts) ----------------------------------------
+    int status = CCP_OK;
+    if (first_row < 0 || n_rows < 0 || n_global < 0 || hi > n_global || n_values < 0 || n_colours < 1 ||
+        (n_rows > 0 && (!row_begin || !row_num_nze || !colour)) || (n_values > 0 && (!values || !col_offset)))
+        status = CCP_ERR_BAD_ARG;
+    std::vector<int> ghost;
+    if (status == CCP_OK) {
+        std::atomic<int> bad{0};
+        std::mutex merge;
+        parallel_ranges(n_rows, 1 << 15, [&](long a, long b) {
+            std::vector<int> mine;
+            for (long i = a; i < b; ++i) {
+                const long nz = row_num_nze[i], at = row_begin[i];
+                if (colour[i] < 0 || colour[i] >= n_colours || nz < 0 || (nz > 0 && (at < 0 || at + nz > n_values))) {
+                    bad.store(1, std::memory_order_relaxed);
+                    continue;
+                }
+                for (long k = at; k < at + nz; ++k) {
+                    const long col = col_offset[k];
+                    if (col < 0 || col >= n_global || (k > at && col <= col_offset[k - 1])) bad.store(1, std::memory_order_relaxed);
+                    else if (col < lo || col >= hi) mine.push_back((int)col);
+                }
+            }
+            std::sort(mine.begin(), mine.end());
+            mine.erase(std::unique(mine.begin(), mine.end()), mine.end());
+            std::lock_guard<std::mutex> lk(merge);
+            ghost.insert(ghost.end(), mine.begin(), mine.end());
+        });
+        if (bad.load()) status = CCP_ERR_BAD_ARG;
+        std::sort(ghost.begin(), ghost.end());
+        ghost.erase(std::unique(ghost.begin(), ghost.end()), ghost.end());
+    }
+
+    // ---- 2. every rank learns every block: contiguous blocks of one matrix, in rank order -------------------------
+    std::vector<int> part((size_t)W + 1, 0);
+    {
+        const int mine[8] = {first_row, n_rows, n_global, n_colours, status, 0, 0, 0};
+        int *dev = reinterpret_cast<int *>(c->scratch.p);
+        std::vector<int> all((size_t)8 * W);
+        CCP_HIP(hipMemcpyAsync(dev + 8 * me, mine, sizeof(mine), hipMemcpyHostToDevice, s));
+        CCP_RCCL(api->AllGather(dev + 8 * me, dev, 8, ncclInt32, c->comm, s));
+        CCP_HIP(hipMemcpyAsync(all.data(), dev, sizeof(int) * all.size(), hipMemcpyDeviceToHost, s));
+        CCP_HIP(hipStreamSynchronize(s));
+        if (status != CCP_OK) return status;
+        long next = 0;
+        for (int r = 0; r < W; ++r) {
+            if (all[8 * r + 4] != CCP_OK) return CCP_ERR_STATE;              // a peer's arguments were refused
+            if (all[8 * r] != next || all[8 * r + 2] != n_global || all[8 * r + 3] != n_colours) return CCP_ERR_BAD_ARG;
+            part[(size_t)r] = (int)next;
+            next += all[8 * r + 1];
+        }
+        if (next != n_global) return CCP_ERR_BAD_ARG;
+        part[(size_t)W] = n_global;
+    }
+
+    // ---- 3. who asks whom for how many values ---------------------------------------------------------------------
+    const int n_ghost = (int)ghost.size();
+    const int n_lo = (int)(std::lower_bound(ghost.begin(), ghost.end(), (int)lo) - ghost.begin());
+    std::vector<int> req_cnt((size_t)W, 0), req_off((size_t)W, 0);
+    for (int o = 0; o < W; ++o) {
+        const int a = (int)(std::lower_bound(ghost.begin(), ghost.end(), part[(size_t)o]) - ghost.begin());
+        const int b = (int)(std::lower_bound(ghost.begin(), ghost.end(), part[(size_t)o + 1]) - ghost.begin());
+        req_off[(size_t)o] = a;
+        req_cnt[(size_t)o] = b - a;
+    }
+    DevBuf<int> d_cnt, d_req, d_serve;
+    CCP_TRY(d_cnt.alloc((size_t)W * W));
+    std::vector<int> cnt((size_t)W * W);
+    CCP_HIP(hipMemcpyAsync(d_cnt.p + (size_t)me * W, req_cnt.data(), sizeof(int) * W, hipMemcpyHostToDevice, s));
+    CCP_RCCL(api->AllGather(d_cnt.p + (size_t)me * W, d_cnt.p, (size_t)W, ncclInt32, c->comm, s));
+    CCP_HIP(hipMemcpyAsync(cnt.data(), d_cnt.p, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, s));
+    CCP_HIP(hipStreamSynchronize(s));
+    std::vector<int> serve_cnt((size_t)W, 0), serve_off((size_t)W, 0);
+    long serve_total = 0;
+    for (int r = 0; r < W; ++r) {
+        serve_cnt[(size_t)r] = cnt[(size_t)r * W + me];
+        serve_off[(size_t)r] = (int)serve_total;
+        serve_total += serve_cnt[(size_t)r];
+    }
+    if (serve_total > INT32_MAX) status = CCP_ERR_UNSUPPORTED;
+
+    // ---- 4. the halo index lists travel to the owners, the colours of those rows travel back ----------------------
+    CCP_TRY(d_req.alloc((size_t)std::max(n_ghost, 1)));
+    CCP_TRY(d_serve.alloc((size_t)std::max<long>(serve_total, 1)));
+    auto int_exchange = [&](const int *send_base, const int *scnt, const int *soff, int *recv_base, const int *rcnt, const int *roff) -> int {
+        bool any = false;
+        for (int r = 0; r < W; ++r) any |= scnt[r] > 0 || rcnt[r] > 0;
+        if (!any) return CCP_OK;
+        CCP_RCCL(api->GroupStart());
+        ncclResult_t res = ncclSuccess;
+        for (int r = 0; r < W && res == ncclSuccess; ++r) {
+            if (scnt[r] > 0) res = api->Send(send_base + soff[r], (size_t)scnt[r], ncclInt32, r, c->comm, s);
+            if (rcnt[r] > 0 && res == ncclSuccess) res = api->Recv(recv_base + roff[r], (size_t)rcnt[r], ncclInt32, r, c->comm, s);
+        }
+        const ncclResult_t e = api->GroupEnd();
+        if (res != ncclSuccess) return rccl_fail(res, "ncclSend/ncclRecv", __FILE__, __LINE__);
+        CCP_RCCL(e);
+        return CCP_OK;
+    };
+    if (n_ghost) CCP_HIP(hipMemcpyAsync(d_req.p, ghost.data(), sizeof(int) * (size_t)n_ghost, hipMemcpyHostToDevice, s));
+    CCP_TRY(int_exchange(d_req.p, req_cnt.data(), req_off.data(), d_serve.p, serve_cnt.data(), serve_off.data()));
+    std::vector<int> serve((size_t)serve_total), serve_colour((size_t)serve_total, 0), ghost_colour((size_t)n_ghost, 0);
+    if (serve_total) CCP_HIP(hipMemcpyAsync(serve.data(), d_serve.p, sizeof(int) * (size_t)serve_total, hipMemcpyDeviceToHost, s));
+    CCP_HIP(hipStreamSynchronize(s));
+    for (int r = 0; r < W; ++r)
+        for (int k = serve_off[(size_t)r]; k < serve_off[(size_t)r] + serve_cnt[(size_t)r]; ++k) {
+            const long g = serve[(size_t)k];
+            if (g < lo || g >= hi || (k > serve_off[(size_t)r] && g <= serve[(size_t)k - 1])) status = CCP_ERR_STATE;   // not a list of this block's rows
+            else serve_colour[(size_t)k] = colour[g - lo];
+        }
+    if (serve_total) CCP_HIP(hipMemcpyAsync(d_serve.p, serve_colour.data(), sizeof(int) * (size_t)serve_total, hipMemcpyHostToDevice, s));
+    CCP_TRY(int_exchange(d_serve.p, serve_cnt.data(), serve_off.data(), d_req.p, req_cnt.data(), req_off.data()));
+    if (n_ghost) CCP_HIP(hipMemcpyAsync(ghost_colour.data(), d_req.p, sizeof(int) * (size_t)n_ghost, hipMemcpyDeviceToHost, s));
+    CCP_HIP(hipStreamSynchronize(s));
+    for (int k = 0; k < n_ghost; ++k)
+        if (ghost_colour[(size_t)k] < 0 || ghost_colour[(size_t)k] >= n_colours) status = CCP_ERR_STATE;
+    CCP_TRY(rb_agree(c, s, status));
+
+    // ---- 5. the extended system through the ordinary upload: ghosts are empty rows among the owned ones ------------
+    const long n_ext = (long)n_rows + n_ghost;
+    if (n_ext > INT32_MAX) status = CCP_ERR_UNSUPPORTED;
+    if (status == CCP_OK) {
+        try {
+            std::vector<int> ext_begin((size_t)n_ext, 0), ext_nnz((size_t)n_ext, 0), ext_colour((size_t)n_ext, 0);
+            std::unique_ptr<int[]> ext_col(new int[(size_t)std::max<int64_t>(n_values, 1)]);
+            for (int k = 0; k < n_ghost; ++k) ext_colour[(size_t)(k < n_lo ? k : n_rows + k)] = ghost_colour[(size_t)k];
+            parallel_ranges(n_rows, 1 << 15, [&](long a, long b) {
+                for (long i = a; i < b; ++i) {
+                    const long nz = row_num_nze[i], at = row_begin[i];
+                    ext_begin[(size_t)(n_lo + i)] = (int)at;
+                    ext_nnz[(size_t)(n_lo + i)] = (int)nz;
+                    ext_colour[(size_t)(n_lo + i)] = colour[i];
+                    for (long k = at; k < at + nz; ++k) {
+                        const long col = col_offset[k];
+                        if (col >= lo && col < hi) {
+                            ext_col[(size_t)k] = (int)(n_lo + (col - lo));
+                        } else {
+                            const int pos = (int)(std::lower_bound(ghost.begin(), ghost.end(), (int)col) - ghost.begin());
+                            ext_col[(size_t)k] = pos < n_lo ? pos : n_rows + pos;
+                        }
+                    }
+                }
+            });
+            // (slack entries between the rows keep whatever the caller's array holds there: never read, like the reference's)
+            status = ccp_csr_upload(m, (int)n_ext, (int)n_ext, n_values, values, ext_col.get(), ext_begin.data(), ext_nnz.data());
+            if (status == CCP_OK) status = ccp_csr_set_colouring(m, ext_colour.data(), n_colours);
+        } catch (const std::bad_alloc &) {
+            status = CCP_ERR_ALLOC;
+        }
+    }
+    if (status == CCP_OK) {
+        m->allow_structured = false;           // the grid twins know nothing of ghosts
+        m->allow_one_block = false;            // the exchange sits between the colour launches
+        status = ensure_multicolour(m);        // (checks the colouring: CCP_ERR_UNSUPPORTED when two coupled rows share a colour)
+    }
+    status = rb_agree(c, s, status);
+    if (status != CCP_OK) {
+        m->uploaded = false;                   // no half-set-up block: the handle waits for the next upload
+        return status;
+    }
+
+    // ---- 6. the message tables --------------------------------------------------------------------------------------
+    ccp_csr::RowBlock &rb = m->rb;
+    rb.comm = c;
+    rb.row_begin = first_row;
+    rb.n_local = n_rows;
+    rb.n_global = n_global;
+    rb.n_lo = n_lo;
+    rb.n_ghost = n_ghost;
+    rb.n_colours = n_colours;
+    rb.ghost = ghost;
+    auto ext_of_ghost = [&](int k) { return k < n_lo ? k : n_rows + k; };
+    rb.nat_send_cnt = serve_cnt;
+    rb.nat_send_off = serve_off;
+    rb.nat_recv_cnt = req_cnt;
+    rb.nat_recv_pos.assign((size_t)W, 0);
+    rb.peers = 0;
+    for (int r = 0; r < W; ++r) {
+        if (req_cnt[(size_t)r] > 0) rb.nat_recv_pos[(size_t)r] = ext_of_ghost(req_off[(size_t)r]);
+        rb.peers += (req_cnt[(size_t)r] > 0 || serve_cnt[(size_t)r] > 0) ? 1 : 0;
+    }
+    std::vector<int> nat_pos((size_t)serve_total);
+    for (long k = 0; k < serve_total; ++k) nat_pos[(size_t)k] = n_lo + (serve[(size_t)k] - first_row);
+    rb.nat_total = serve_total;
+    const Schedule &sc = m->multicolour;
+    rb.col_send_cnt.assign((size_t)n_colours * W, 0);
+    rb.col_send_off.assign((size_t)n_colours * W, 0);
+    rb.col_recv_cnt.assign((size_t)n_colours * W, 0);
+    rb.col_recv_pos.assign((size_t)n_colours * W, 0);
+    rb.col_seg_off.assign((size_t)n_colours + 1, 0);
+    std::vector<int> col_pos;
+    col_pos.reserve((size_t)serve_total);
+    int table_ok = 1;
+    for (int g = 0; g < n_colours; ++g) {
+        rb.col_seg_off[(size_t)g] = (long)col_pos.size();
+        for (int r = 0; r < W; ++r) {
+            const size_t at = (size_t)g * W + r;
+            rb.col_send_off[at] = (int)col_pos.size();
+            for (int k = serve_off[(size_t)r]; k < serve_off[(size_t)r] + serve_cnt[(size_t)r]; ++k)
+                if (serve_colour[(size_t)k] == g) col_pos.push_back(sc.inv[(size_t)(n_lo + (serve[(size_t)k] - first_row))]);
+            rb.col_send_cnt[at] = (int)col_pos.size() - rb.col_send_off[at];
+            // what rank r owns of my ghosts in colour g: one contiguous range of the colour-major order
+            int first = -1, count = 0;
+            for (int k = req_off[(size_t)r]; k < req_off[(size_t)r] + req_cnt[(size_t)r]; ++k) {
+                if (ghost_colour[(size_t)k] != g) continue;
+                const int pos = sc.inv[(size_t)ext_of_ghost(k)];
+                if (first < 0) first = pos;
+                if (pos != first + count) table_ok = 0;
+                ++count;
+            }
+            rb.col_recv_cnt[at] = count;
+            rb.col_recv_pos[at] = std::max(first, 0);
+        }
+    }
+    rb.col_seg_off[(size_t)n_colours] = (long)col_pos.size();
+    status = table_ok ? CCP_OK : CCP_ERR_STATE;
+    if (status == CCP_OK && serve_total) {
+        status = rb.nat_send_pos.alloc((size_t)serve_total);
+        if (status == CCP_OK) status = rb.col_send_pos.alloc((size_t)serve_total);
+        if (status == CCP_OK) status = rb.sendbuf.alloc((size_t)serve_total);
+        if (status == CCP_OK) {
+            CCP_HIP(hipMemcpyAsync(rb.nat_send_pos.p, nat_pos.data(), sizeof(int) * (size_t)serve_total, hipMemcpyHostToDevice, s));
+            CCP_HIP(hipMemcpyAsync(rb.col_send_pos.p, col_pos.data(), sizeof(int) * (size_t)serve_total, hipMemcpyHostToDevice, s));
+            CCP_HIP(hipStreamSynchronize(s));
+        }
+    }
+    status = rb_agree(c, s, status);
+    if (status != CCP_OK) {
+        m->uploaded = false;
+        rb.reset();
+        return status;
+    }
+    rb.on = true;
+    return CCP_OK;
+} CCP_ABI_CATCH
+
+int ccp_csr_rows_info(ccp_csr *m, int32_t *first_row, int32_t *n_rows, int32_t *n_ghost, int32_t *n_peers,
+                      int64_t *values_sent, int64_t *exchanges)
+try {
+    if (!m) return CCP_ERR_BAD_ARG;
+    if (!m->uploaded || !m->rb.on) return CCP_ERR_STATE;
+    if (first_row) *first_row = m->rb.row_begin;
+    if (n_rows) *n_rows = m->rb.n_local;
+    if (n_ghost) *n_ghost = m->rb.n_ghost;
+    if (n_peers) *n_peers = m->rb.peers;
+    if (values_sent) *values_sent = m->rb.values_sent;
+    if (exchanges) *exchanges = m->rb.exchanges;
+    return CCP_OK;
+} CCP_ABI_CATCH
+
 int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours)
 try {
     if (!m) return CCP_ERR_BAD_ARG;
     if (!m->uploaded) return CCP_ERR_STATE;
+    if (m->rb.on) return CCP_ERR_UNSUPPORTED;      // a row block: its colouring and pattern were agreed with the peers at ccp_csr_upload_rows
     m->multicolour.reset();
     m->user_colour.clear();
     m->user_n_colours = 0;
@@ -1659,6 +2049,7 @@ int ccp_csr_insert(ccp_csr *m, int32_t row, int32_t col, double val)
 try {
     if (!m) return CCP_ERR_BAD_ARG;
     if (!m->uploaded) return CCP_ERR_STATE;
+    if (m->rb.on) return CCP_ERR_UNSUPPORTED;      // a row block: its colouring and pattern were agreed with the peers at ccp_csr_upload_rows
     if (row < 0 || row >= m->n_rows || col < 0 || col >= m->n_cols) return CCP_ERR_BAD_ARG;
     // the row's current content, copied into the overlay on its first edit
     auto it = m->overlay.find(row);
@@ -1766,6 +2157,11 @@ try {
     }
     CCP_TRY(ensure_multicolour(m));          // colours the rows now if no solve has done so yet
     *n_colours = m->used_n_colours;
+    if (m->rb.on) {                          // a row block: the colours of the block's own rows
+        *n_colours = m->rb.n_colours;        // (the whole matrix's count, also on a block that holds none of some colour)
+        if (colour && m->rb.n_local) std::memcpy(colour, m->used_colour.data() + m->rb.n_lo, sizeof(int32_t) * (size_t)m->rb.n_local);
+        return CCP_OK;
+    }
     if (colour && m->n_rows) std::memcpy(colour, m->used_colour.data(), sizeof(int32_t) * (size_t)m->n_rows);
     return CCP_OK;
 } CCP_ABI_CATCH
@@ -1779,6 +2175,9 @@ try {
     if (!b || !x_out || check_every < 0) return CCP_ERR_BAD_ARG;
     if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;   // the reference asserts len(b) == n_cols and sizes x from b
     if (ordering != CCP_ORDER_LEXICOGRAPHIC && ordering != CCP_ORDER_MULTICOLOUR) return CCP_ERR_BAD_ARG;
+    // a row block: the index-order sweep is one dependence chain through all the blocks — only the colour order shards
+    if (m->rb.on && ordering != CCP_ORDER_MULTICOLOUR) return CCP_ERR_UNSUPPORTED;
+    const bool rowblock = m->rb.on;
     if (ordering == CCP_ORDER_MULTICOLOUR && m->allow_structured) {
         // The matrix SolveChannel builds (via Eigen, ConvertFromEigen) is recognised and solved
         // matrix-free by the grid kernels: same sweep order, same arithmetic, same bits as the
@@ -1881,20 +2280,25 @@ try {
     const long n = m->n_rows;
     hipStream_t s = m->stream;
     CCP_TRY(ensure_partial(m, sc.group_block_off[sc.n_groups]));
-    // stage b (and x0) in natural order, gather into schedule order
+    // stage b (and x0) in natural order, gather into schedule order (a row block: b, x0 and x_out hold the block's
+    // own rows; the ghosts sit around them in the extended order and get their first values from their owners)
     if (n) {
-        CCP_HIP(hipMemcpyAsync(m->tmp.p, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
+        if (rowblock) CCP_TRY(rb_stage(m, m->tmp.p, b));
+        else CCP_HIP(hipMemcpyAsync(m->tmp.p, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL((k_permute<true>), dim3(blocks_for(n)), dim3(kBlock), 0, s, m->b.p, m->tmp.p, sc.perm.p, n);
         CCP_HIP(hipGetLastError());
         if (x0) {
             CCP_HIP(hipStreamSynchronize(s));
-            CCP_HIP(hipMemcpyAsync(m->tmp.p, x0, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            if (rowblock) CCP_TRY(rb_stage(m, m->tmp.p, x0));
+            else CCP_HIP(hipMemcpyAsync(m->tmp.p, x0, sizeof(double) * n, hipMemcpyHostToDevice, s));
             hipLaunchKernelGGL((k_permute<true>), dim3(blocks_for(n)), dim3(kBlock), 0, s, m->x.p, m->tmp.p, sc.perm.p, n);
         } else {
             hipLaunchKernelGGL(k_fill_n, dim3(blocks_for(n)), dim3(kBlock), 0, s, m->x.p, n, 1.0);   // sparse-matrix.h:352
         }
         CCP_HIP(hipGetLastError());
     }
+    if (rowblock && x0)
+        for (int g = 0; g < m->rb.n_colours; ++g) CCP_TRY(rb_exchange_colour(m, g));
     CsrSolveState host{};
     host.active = 1;
     host.last_eps = 10.0;                    // sparse-matrix.h:354
@@ -1905,7 +2309,7 @@ try {
     const int *active = reinterpret_cast<const int *>(m->state.p);
     double *eps_accum = reinterpret_cast<double *>(reinterpret_cast<char *>(m->state.p) + offsetof(CsrSolveState, eps_accum));
     int issued = 0;
-    bool any_active = (10.0 > epsilon) && max_iteration > 0 && n > 0;
+    bool any_active = (10.0 > epsilon) && max_iteration > 0 && (n > 0 || rowblock);   // (an empty block still takes part in the stop rule)
     // narrow groups (<= 1024 rows: level schedules of grids up to ~1000 px wide, small matrices): the
     // whole solve in one workgroup; wider groups keep one launch per group (one CU cannot feed them)
     const bool one_block = m->allow_one_block && sc.n_groups > 0 && sc.max_group_slices <= 16;
@@ -1991,20 +2395,29 @@ try {
         while (issued < max_iteration && checks < 8) {
             const int k = issued + 1;
             const bool check = check_every > 0 && (k % check_every == 0);
-            for (int g = 0; g < sc.n_groups; ++g) {
-                const int s0 = sc.group_slice_ptr[g], s1 = sc.group_slice_ptr[g + 1];
-                if (s1 == s0) continue;
-                const unsigned blocks = (unsigned)(sc.group_block_off[g + 1] - sc.group_block_off[g]);
-                if (check)
-                    hipLaunchKernelGGL((k_sell_gs<true>), dim3(blocks), dim3(kBlock), 0, s, view, s0, s1, m->x.p, m->b.p,
-                                       m->partial.p + sc.group_block_off[g], active);
-                else
-                    hipLaunchKernelGGL((k_sell_gs<false>), dim3(blocks), dim3(kBlock), 0, s, view, s0, s1, m->x.p, m->b.p,
-                                       m->partial.p, active);
+            for (int g = 0; g < (rowblock ? m->rb.n_colours : sc.n_groups); ++g) {
+                const int s0 = g < sc.n_groups ? sc.group_slice_ptr[g] : 0, s1 = g < sc.n_groups ? sc.group_slice_ptr[g + 1] : 0;
+                if (s1 > s0) {
+                    const unsigned blocks = (unsigned)(sc.group_block_off[g + 1] - sc.group_block_off[g]);
+                    if (check)
+                        hipLaunchKernelGGL((k_sell_gs<true>), dim3(blocks), dim3(kBlock), 0, s, view, s0, s1, m->x.p, m->b.p,
+                                           m->partial.p + sc.group_block_off[g], active);
+                    else
+                        hipLaunchKernelGGL((k_sell_gs<false>), dim3(blocks), dim3(kBlock), 0, s, view, s0, s1, m->x.p, m->b.p,
+                                           m->partial.p, active);
+                }
+                // a row block: the colour's new values reach the blocks that reference them before the next colour runs
+                if (rowblock) CCP_TRY(rb_exchange_colour(m, g));
             }
             CCP_HIP(hipGetLastError());
             if (check) {
                 hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, m->partial.p, sc.group_block_off[sc.n_groups], 1L, eps_accum, 0);
+                if (rowblock) {
+                    // sparse-matrix.h:376 over the whole matrix: the blocks' step sums added up, on every rank alike
+                    const RcclApi *api = rccl_api();
+                    if (!api) return CCP_ERR_RCCL;
+                    CCP_RCCL(api->AllReduce(eps_accum, eps_accum, 1, ncclDouble, ncclSum, m->rb.comm->comm, s));
+                }
                 hipLaunchKernelGGL(k_csr_check, dim3(1), dim3(64), 0, s, m->state.p, epsilon, k);
                 CCP_HIP(hipGetLastError());
                 ++checks;
@@ -2021,7 +2434,8 @@ try {
     if (n) {
         hipLaunchKernelGGL((k_permute<false>), dim3(blocks_for(n)), dim3(kBlock), 0, s, m->tmp.p, m->x.p, sc.perm.p, n);
         CCP_HIP(hipGetLastError());
-        CCP_HIP(hipMemcpyAsync(x_out, m->tmp.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        if (!rowblock) CCP_HIP(hipMemcpyAsync(x_out, m->tmp.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+        else if (m->rb.n_local) CCP_HIP(hipMemcpyAsync(x_out, m->tmp.p + m->rb.n_lo, sizeof(double) * (size_t)m->rb.n_local, hipMemcpyDeviceToHost, s));
     }
     CCP_HIP(hipMemcpyAsync(&host, m->state.p, sizeof(host), hipMemcpyDeviceToHost, s));
     CCP_HIP(hipStreamSynchronize(s));
@@ -2041,6 +2455,7 @@ int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, 
 try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
+    if (m->rb.on) return CCP_ERR_UNSUPPORTED;      // (row blocks: the Gauss-Seidel sweep, b := A x and the residual)
     CCP_TRY(flush_edits(m));
     if (!b || !x_out) return CCP_ERR_BAD_ARG;
     if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;
@@ -2103,6 +2518,7 @@ int ccp_csr_conjugate_gradient_jacobi(ccp_csr *m, const double *b, double *x_out
 try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
+    if (m->rb.on) return CCP_ERR_UNSUPPORTED;      // (row blocks: the Gauss-Seidel sweep, b := A x and the residual)
     CCP_TRY(flush_edits(m));
     if (!b || !x_out) return CCP_ERR_BAD_ARG;
     if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;
@@ -2156,17 +2572,24 @@ try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
     CCP_TRY(flush_edits(m));
-    if ((m->n_cols && !in) || (m->n_rows && !out)) return CCP_ERR_BAD_ARG;
+    if (m->rb.on ? (m->rb.n_local && (!in || !out)) : ((m->n_cols && !in) || (m->n_rows && !out))) return CCP_ERR_BAD_ARG;
     CCP_TRY(ensure_natural(m));
     hipStream_t s = m->stream;
-    if (m->n_cols) CCP_HIP(hipMemcpyAsync(m->x.p, in, sizeof(double) * m->n_cols, hipMemcpyHostToDevice, s));
+    const bool rowblock = m->rb.on;        // in / out: the block's own rows; the ghosts of `in` come from their owners
+    if (rowblock) {
+        CCP_TRY(rb_stage(m, m->x.p, in));
+        CCP_TRY(rb_exchange_natural(m, m->x.p));
+    } else if (m->n_cols) {
+        CCP_HIP(hipMemcpyAsync(m->x.p, in, sizeof(double) * m->n_cols, hipMemcpyHostToDevice, s));
+    }
     if (m->n_rows) {
         const unsigned blocks = (unsigned)((m->natural.n_slices + kBlock / kWave - 1) / (kBlock / kWave));
         CCP_TRY(ensure_partial(m, blocks));
         hipLaunchKernelGGL((k_sell_apply<0>), dim3(blocks), dim3(kBlock), 0, s, m->natural.view(), m->natural.n_slices,
                            m->x.p, m->tmp.p, m->b.p, m->partial.p);
         CCP_HIP(hipGetLastError());
-        CCP_HIP(hipMemcpyAsync(out, m->tmp.p, sizeof(double) * m->n_rows, hipMemcpyDeviceToHost, s));
+        if (!rowblock) CCP_HIP(hipMemcpyAsync(out, m->tmp.p, sizeof(double) * m->n_rows, hipMemcpyDeviceToHost, s));
+        else if (m->rb.n_local) CCP_HIP(hipMemcpyAsync(out, m->tmp.p + m->rb.n_lo, sizeof(double) * (size_t)m->rb.n_local, hipMemcpyDeviceToHost, s));
     }
     CCP_HIP(hipStreamSynchronize(s));
     return CCP_OK;
@@ -2177,22 +2600,35 @@ try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
     CCP_TRY(flush_edits(m));
-    if (!b || !x || !rr || !bb) return CCP_ERR_BAD_ARG;
+    if (!rr || !bb || ((!b || !x) && !(m->rb.on && m->rb.n_local == 0))) return CCP_ERR_BAD_ARG;
     CCP_TRY(ensure_natural(m));
     hipStream_t s = m->stream;
     *rr = 0.0;
     *bb = 0.0;
-    if (!m->n_rows) return CCP_OK;
-    CCP_HIP(hipMemcpyAsync(m->x.p, x, sizeof(double) * m->n_cols, hipMemcpyHostToDevice, s));
-    CCP_HIP(hipMemcpyAsync(m->b.p, b, sizeof(double) * m->n_rows, hipMemcpyHostToDevice, s));
+    const bool rowblock = m->rb.on;        // b, x: the block's own rows; rr, bb: sums over the whole matrix, on every rank
+    if (!m->n_rows && !rowblock) return CCP_OK;
+    if (rowblock) {
+        CCP_TRY(rb_stage(m, m->x.p, x));
+        CCP_TRY(rb_exchange_natural(m, m->x.p));
+        CCP_TRY(rb_stage(m, m->b.p, b));
+    } else {
+        CCP_HIP(hipMemcpyAsync(m->x.p, x, sizeof(double) * m->n_cols, hipMemcpyHostToDevice, s));
+        CCP_HIP(hipMemcpyAsync(m->b.p, b, sizeof(double) * m->n_rows, hipMemcpyHostToDevice, s));
+    }
     const unsigned blocks = (unsigned)((m->natural.n_slices + kBlock / kWave - 1) / (kBlock / kWave));
-    CCP_TRY(ensure_partial(m, blocks));
-    hipLaunchKernelGGL((k_sell_apply<1>), dim3(blocks), dim3(kBlock), 0, s, m->natural.view(), m->natural.n_slices, m->x.p,
-                       m->tmp.p, m->b.p, m->partial.p);
+    CCP_TRY(ensure_partial(m, std::max(blocks, 1u)));
+    if (blocks)
+        hipLaunchKernelGGL((k_sell_apply<1>), dim3(blocks), dim3(kBlock), 0, s, m->natural.view(), m->natural.n_slices, m->x.p,
+                           m->tmp.p, m->b.p, m->partial.p);
     double *res = m->tmp.p;   // two doubles of scratch for the result
     hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, m->partial.p, (long)blocks, 2L, res, 0);
     hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, m->partial.p + 1, (long)blocks, 2L, res + 1, 0);
     CCP_HIP(hipGetLastError());
+    if (rowblock) {
+        const RcclApi *api = rccl_api();
+        if (!api) return CCP_ERR_RCCL;
+        CCP_RCCL(api->AllReduce(res, res, 2, ncclDouble, ncclSum, m->rb.comm->comm, s));
+    }
     double host[2];
     CCP_HIP(hipMemcpyAsync(host, res, sizeof(host), hipMemcpyDeviceToHost, s));
     CCP_HIP(hipStreamSynchronize(s));

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCP_GS_ABI_VERSION 3
+#define CCP_GS_ABI_VERSION 4
 
 typedef enum ccp_status {
     CCP_OK = 0,
@@ -157,6 +157,37 @@ int ccp_csr_apply_to_vector(ccp_csr *m, const double *in, double *out);
 
 /* sum (b - A x)^2 and sum b^2 (applyToVector + vecsub + veclen2, sparse-matrix.h:51-55,75-79). */
 int ccp_csr_residual_norm2(ccp_csr *m, const double *b, const double *x, double *rr, double *bb);
+
+/* ----------------------------------------------------------------------------------------
+ * Row block of a matrix distributed over the ranks of a communicator (section 4: ccp_comm) — SURVEY.md §8e,
+ * BASELINE configs[4] on several GPUs: "row-block by unknown index with a halo index list".  No reference
+ * counterpart (the reference is one process, sparse-matrix.h:350-380); the sweep each rank runs is the
+ * multi-colour ccp_csr_gauss_seidel above, and the iterates are the one-GPU iterates bit for bit.
+ *
+ * ccp_csr_upload_rows — COLLECTIVE over `comm`.  This rank owns rows [first_row, first_row + n_rows) of an
+ * n_global x n_global matrix; the blocks of ranks 0, 1, ... follow one another and cover it.  The five arrays
+ * are the reference's for those rows (row_begin / row_num_nze have n_rows entries), column indices are
+ * GLOBAL.  colour[i] in [0, n_colours) for the owned rows: a proper colouring of the whole matrix (two coupled
+ * rows never share a colour — checked on every rank against its own rows, CCP_ERR_UNSUPPORTED otherwise), the
+ * same n_colours everywhere.  The ranks exchange their halo index lists (the columns a block references outside
+ * itself) and the colours of those rows once, here.  If any rank refuses its arguments every rank returns an
+ * error (its own, or CCP_ERR_STATE for "a peer failed") and the handle holds no matrix.
+ * Afterwards, with b / x0 / x_out / in / out holding the block's OWN rows (n_rows entries):
+ *   ccp_csr_gauss_seidel(CCP_ORDER_MULTICOLOUR)  collective: after every colour the new values other blocks
+ *        reference travel to them (one ncclSend/ncclRecv pair per neighbouring block, all in one group); the
+ *        stop rule (:376) uses the all-reduced step sum, so every rank stops at the same sweep;
+ *   ccp_csr_apply_to_vector, ccp_csr_residual_norm2   collective (rr, bb: sums over the whole matrix);
+ *   ccp_csr_get_colouring   the block's own rows.
+ * The reference-order sweep, conjugate gradient, ccp_csr_insert and ccp_csr_set_colouring return
+ * CCP_ERR_UNSUPPORTED on a row block.  ccp_csr_upload returns the handle to the one-GPU form.
+ * ccp_csr_rows_info: the block, its ghosts (columns owned by peers), the peers it exchanges with, and the
+ * values sent / grouped exchanges issued since the upload (outputs may be NULL). */
+typedef struct ccp_comm ccp_comm;
+int ccp_csr_upload_rows(ccp_csr *m, ccp_comm *comm, int32_t first_row, int32_t n_rows, int32_t n_global, int64_t n_values,
+                        const double *values, const int32_t *col_offset, const int32_t *row_begin, const int32_t *row_num_nze,
+                        const int32_t *colour, int32_t n_colours);
+int ccp_csr_rows_info(ccp_csr *m, int32_t *first_row, int32_t *n_rows, int32_t *n_ghost, int32_t *n_peers,
+                      int64_t *values_sent, int64_t *exchanges);
 
 /* ========================================================================================
  * 2. Structured Poisson grid  —  matrix-free form of the system SolveChannel assembles

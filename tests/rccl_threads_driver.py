@@ -227,7 +227,170 @@ def case_late_flag(c):
     return {"ok": True, "ranks": verdict}
 
 
-CASES = {"late_flag": case_late_flag, "sweep": case_sweep, "stop_rule": case_stop_rule, "bad_partition": case_bad_partition}
+# ---- row blocks of a general CSR matrix (ccp_csr_upload_rows; SURVEY §8e "row-block by unknown index with a halo index list")
+
+def csr_matrix(c):
+    """(values, col, row_offset, colour, n_colours) of the whole matrix of a case."""
+    if c["matrix"] == "mask":                      # BASELINE configs[4] in small: discs + brush trail, Dirichlet Laplacian
+        mask = synth.disc_mask(c["W"], c["H"], seed=c.get("seed", 4321), n_discs=c.get("discs", 24), rmin=300.0, rmax=c.get("rmax", 1400.0))
+        v, col, rowp, colour, _, _ = synth.masked_laplacian_csr(mask)
+        return v, col, rowp, colour, 2
+    # random symmetric pattern, diagonally dominant; couplings reach far across the blocks (every block talks to every other)
+    n, g = c["n"], synth.rng(c.get("seed", 7))
+    pairs = set()
+    for i in range(n):
+        for j in g.integers(0, n, c.get("deg", 3)):
+            j = int(j)
+            if j != i:
+                pairs.add((i, j))
+                pairs.add((j, i))
+    rows = [[] for _ in range(n)]
+    for i, j in pairs:
+        rows[i].append(j)
+    vals, cols, rowp = [], [], [0]
+    for i in range(n):
+        js = sorted(rows[i] + [i])
+        w = {j: -g.uniform(0.2, 1.0) for j in js if j != i}
+        w[i] = 0.0 if c.get("empty_rows") and i % 97 == 5 else 1.0 + sum(-t for t in w.values())
+        for j in js:
+            if w[j] != 0.0:
+                cols.append(j)
+                vals.append(w[j])
+        rowp.append(len(cols))
+    v, col, rowp = np.array(vals), np.array(cols, dtype=np.int32), np.array(rowp, dtype=np.int32)
+    whole = capi.CsrMatrix().upload_compressed(v, col, rowp)
+    colour, nc = whole.get_colouring()             # the library's greedy colouring of the whole matrix
+    whole.close()
+    return v, col, rowp, colour.copy(), nc
+
+
+def slack_rows(v, col, rowp, lo, hi, slack):
+    """The reference's five arrays for rows [lo, hi): `slack` unused entries after every row (sparse-matrix.h:670-676)."""
+    nnz = np.diff(rowp[lo:hi + 1]).astype(np.int32)
+    begin = np.zeros(hi - lo, dtype=np.int32)
+    if hi > lo:
+        begin[1:] = np.cumsum(nnz[:-1] + slack)
+    total = int(begin[-1] + nnz[-1] + slack) if hi > lo else 0
+    values = np.full(total, np.nan)                # slack is never read
+    cols = np.full(total, -7, dtype=np.int32)
+    for i in range(hi - lo):
+        a = rowp[lo + i]
+        values[begin[i]:begin[i] + nnz[i]] = v[a:a + nnz[i]]
+        cols[begin[i]:begin[i] + nnz[i]] = col[a:a + nnz[i]]
+    return values, cols, begin, nnz
+
+
+def case_csr_rows(c):
+    """Blocks of rows of one matrix on `world` ranks: the sweep's iterates, b := A x and the stop sweep are the one-GPU
+    handle's (and the CPU oracle's on P A P^T), bit for bit."""
+    import oracle
+    v, col, rowp, colour, nc = csr_matrix(c)
+    n = len(rowp) - 1
+    world, iters, eps = c["world"], c["iters"], c.get("eps", 0.0)
+    xt = synth.x_true(n, 1234)
+    b = synth.csr_apply(v, col, rowp, xt)
+    x0 = synth.x_true(n, 99) if c.get("x0") else None
+    os.environ["CCP_GS_MASKED"] = "0"              # the one-GPU comparison on the stored matrix too
+    whole = capi.CsrMatrix().upload_compressed(v, col, rowp).set_colouring(colour, nc)
+    want, rep_w = whole.gauss_seidel(b, eps, iters, x0, check_every=1 if eps > 0 else 0)
+    y_w = whole.apply_to_vector(xt)
+    rr_w, bb_w = whole.residual_norm2(b, want)
+    whole.close()
+    orc = oracle.Oracle()
+    want_o, it_o, _ = orc.multicolour_gauss_seidel(v, col, rowp, colour, b, eps, iters, x0=x0)
+    cuts = c.get("cuts") or [round(n * k / world) for k in range(world + 1)]
+    cuts = [int(round(t * n)) if isinstance(t, float) else t for t in cuts]
+    before = transport_stats()
+
+    def rank_fn(rank, comm):
+        assert comm.info()["rccl_version"] == 99901, "not the test transport"
+        lo, hi = cuts[rank], cuts[rank + 1]
+        values, cols, begin, nnz = slack_rows(v, col, rowp, lo, hi, c.get("slack", 0))
+        m = capi.CsrMatrix()
+        m.upload_rows(comm, lo, n, values, cols, begin, nnz, colour[lo:hi], nc)
+        x, rep = m.gauss_seidel(b[lo:hi], eps, iters, None if x0 is None else x0[lo:hi], check_every=1 if eps > 0 else 0)
+        y = m.apply_to_vector(xt[lo:hi])
+        rr, bb = m.residual_norm2(b[lo:hi], x)
+        own_colour, own_nc = m.get_colouring()
+        info = m.rows_info()
+        unsupported = []
+        for what, fn in (("lexicographic", lambda: m.gauss_seidel(b[lo:hi], 0.0, 1, ordering=capi.ORDER_LEXICOGRAPHIC)),
+                         ("cg", lambda: m.conjugate_gradient(b[lo:hi], 1e-9, 3)), ("insert", lambda: m.insert(1.0, 0, 0))):
+            try:
+                fn()
+                unsupported.append((what, 0))
+            except capi.CcpError as e:
+                unsupported.append((what, e.status))
+        path = m.last_path()
+        m.close()
+        return x, (rep.converged, rep.iterations, rep.last_l1_step), y, rr, bb, info, bool(np.array_equal(own_colour, colour[lo:hi]) and own_nc == nc), unsupported, path
+
+    out, err = run_ranks(world, rank_fn)
+    os.environ.pop("CCP_GS_MASKED", None)
+    if any(err):
+        return {"ok": False, "error": [repr(e) for e in err]}
+    after = transport_stats()
+    got = np.concatenate([o[0] for o in out])
+    y = np.concatenate([o[2] for o in out])
+    ghosts = [o[5]["n_ghost"] for o in out]
+    return {"ok": True, "n": n, "colours": nc, "cuts": cuts,
+            "bit_identical_to_one_gpu": bool(np.array_equal(got, want)),
+            "bit_identical_to_oracle": bool(np.array_equal(got, want_o)),
+            "spmv_bit_identical": bool(np.array_equal(y, y_w)),
+            "residual_close": bool(np.allclose([out[0][3], out[0][4]], [rr_w, bb_w], rtol=1e-12, atol=0.0)),
+            "residual_same_on_all_ranks": bool(all(o[3] == out[0][3] and o[4] == out[0][4] for o in out)),
+            "iterations_one_gpu": rep_w.iterations, "iterations_oracle": int(it_o), "iterations_ranks": [o[1][1] for o in out],
+            "converged_ranks": [o[1][0] for o in out], "converged_one_gpu": rep_w.converged,
+            "step_ranks": [o[1][2] for o in out], "step_one_gpu": rep_w.last_l1_step,
+            "ghosts": ghosts, "peers": [o[5]["n_peers"] for o in out], "values_sent": [o[5]["values_sent"] for o in out],
+            "exchanges": [o[5]["exchanges"] for o in out], "own_colours_ok": all(o[6] for o in out),
+            "unsupported": [o[7] for o in out], "path": [o[8] for o in out],
+            "sends": after["sends"] - before["sends"], "recvs": after["recvs"] - before["recvs"], "bytes": after["bytes"] - before["bytes"]}
+
+
+def case_csr_rows_refused(c):
+    """One rank's arguments are wrong (a colouring with two coupled rows of one colour; a block that leaves a gap; a
+    column outside the matrix): EVERY rank returns an error and nobody hangs."""
+    v, col, rowp, colour, nc = csr_matrix(c)
+    n = len(rowp) - 1
+    world, fault = c["world"], c["fault"]
+    cuts = [round(n * k / world) for k in range(world + 1)]
+
+    def rank_fn(rank, comm):
+        lo, hi = cuts[rank], cuts[rank + 1]
+        values, cols, begin, nnz = slack_rows(v, col, rowp, lo, hi, 0)
+        colr = colour[lo:hi].copy()
+        if rank == c["rank"]:
+            if fault == "colouring":
+                colr[:] = 0
+            elif fault == "gap":
+                lo += 1
+                values, cols, begin, nnz = slack_rows(v, col, rowp, lo, hi, 0)
+                colr = colour[lo:hi].copy()
+            elif fault == "column":
+                cols = cols.copy()
+                cols[len(cols) // 2] = n + 5
+        m = capi.CsrMatrix()
+        try:
+            m.upload_rows(comm, lo, n, values, cols, begin, nnz, colr, nc)
+            st = 0
+        except capi.CcpError as e:
+            st = e.status
+        after = None
+        try:
+            m.gauss_seidel(np.zeros(hi - lo), 0.0, 1)
+        except capi.CcpError as e:
+            after = e.status
+        m.close()
+        return st, after
+
+    out, err = run_ranks(world, rank_fn)
+    if any(err):
+        return {"ok": False, "error": [repr(e) for e in err]}
+    return {"ok": True, "status": [o[0] for o in out], "solve_after": [o[1] for o in out]}
+
+
+CASES = {"csr_rows": case_csr_rows, "csr_rows_refused": case_csr_rows_refused, "late_flag": case_late_flag, "sweep": case_sweep, "stop_rule": case_stop_rule, "bad_partition": case_bad_partition}
 
 
 def main():

@@ -136,3 +136,66 @@ def test_cpp_host_runs_every_rank_as_a_thread(fake_env, tmp_path, world):
     assert np.isclose(sum(float(v["abs"]) for v in vals), want_abs, rtol=1e-12, atol=0.0)
     for v in vals:
         assert np.isclose(float(v["rr"]), rr[0], rtol=1e-11, atol=0.0) and np.isclose(float(v["bb"]), bb[0], rtol=1e-12, atol=0.0)
+
+
+# ---- row blocks of a general CSR matrix: ccp_csr_upload_rows (BASELINE configs[4] on several GPUs) ----------
+CSR_ROWS = [
+    # the region matrix of configs[4] in small, unknowns in raster order: blocks talk to their neighbours only
+    {"matrix": "mask", "W": 320, "H": 240, "world": 2, "iters": 12},
+    {"matrix": "mask", "W": 400, "H": 300, "world": 3, "iters": 9, "x0": True, "slack": 3, "cuts": [0, 0.21, 0.77, 1.0]},
+    {"matrix": "mask", "W": 512, "H": 384, "world": 4, "iters": 7, "cuts": [0, 0.5, 0.5, 0.8, 1.0]},       # an EMPTY block
+    # random symmetric pattern, the library's greedy colouring (several colours), every block coupled to every other
+    {"matrix": "random", "n": 5000, "deg": 3, "world": 3, "iters": 6, "x0": True},
+    {"matrix": "random", "n": 3001, "deg": 2, "world": 4, "iters": 5, "empty_rows": True, "slack": 1},
+]
+
+
+def test_csr_row_blocks_sweep_the_one_gpu_iterates(fake_env):
+    res = drive(fake_env, [dict(c, kind="csr_rows") for c in CSR_ROWS])
+    for r in res:
+        c = r["case"]
+        assert r["ok"], r
+        assert r["bit_identical_to_one_gpu"] and r["bit_identical_to_oracle"], c
+        assert r["spmv_bit_identical"], c
+        assert r["residual_close"] and r["residual_same_on_all_ranks"], c
+        assert r["iterations_ranks"] == [c["iters"]] * c["world"], r
+        assert r["own_colours_ok"], c
+        assert all(p == "sliced ELL" for p in r["path"]), r["path"]
+        # the reference-order sweep, conjugate gradient and insert do not shard: CCP_ERR_UNSUPPORTED (6) on every rank
+        assert all(st == 6 for rank in r["unsupported"] for _, st in rank), r["unsupported"]
+        # the messages went through the transport: every value sent was received, 8 bytes each, plus the halo index
+        # lists and colours of the set-up (4 bytes each way per ghost)
+        assert r["sends"] == r["recvs"] > 0, r
+        sent = sum(r["values_sent"])
+        assert r["bytes"] == 8 * sent + 2 * 4 * sum(r["ghosts"]), r
+        if c["matrix"] == "mask":
+            assert max(r["peers"]) <= 2, r                    # raster order: a block touches the block before and after it
+        else:
+            assert max(r["peers"]) == c["world"] - 1, r
+
+
+def test_csr_row_blocks_stop_at_the_references_sweep(fake_env):
+    cases = [{"kind": "csr_rows", "matrix": "mask", "W": 200, "H": 150, "rmax": 700.0, "world": w, "iters": 500, "eps": 2.0} for w in (2, 3)]
+    cases.append({"kind": "csr_rows", "matrix": "random", "n": 2500, "deg": 3, "world": 4, "iters": 500, "eps": 1e-6})
+    for r in drive(fake_env, cases):
+        assert r["ok"], r
+        want = r["iterations_one_gpu"]
+        assert 1 < want < 500 and r["converged_one_gpu"] == 1, r
+        assert want == r["iterations_oracle"], r
+        assert r["iterations_ranks"] == [want] * r["case"]["world"] and all(v == 1 for v in r["converged_ranks"]), r
+        assert r["bit_identical_to_one_gpu"] and r["bit_identical_to_oracle"], r["case"]
+        assert all(s == r["step_ranks"][0] for s in r["step_ranks"])
+        assert np.isclose(r["step_ranks"][0], r["step_one_gpu"], rtol=1e-10, atol=0.0)
+
+
+def test_csr_row_blocks_refuse_together(fake_env):
+    base = {"kind": "csr_rows_refused", "matrix": "mask", "W": 160, "H": 120, "world": 3}
+    res = drive(fake_env, [dict(base, fault="colouring", rank=1), dict(base, fault="gap", rank=2), dict(base, fault="column", rank=0),
+                           dict(base, fault="none", rank=0)])
+    for r in res[:3]:
+        assert r["ok"], r
+        assert all(st != 0 for st in r["status"]), r          # nobody hangs, nobody is left believing it holds a block
+        assert all(st == 5 for st in r["solve_after"]), r     # CCP_ERR_STATE: the handle holds no matrix
+    assert res[1]["status"] == [1, 1, 1], res[1]              # the partition check is all-gathered: CCP_ERR_BAD_ARG everywhere
+    assert res[2]["status"][0] == 1, res[2]                   # the rank with the bad column reports its own error
+    assert res[3]["ok"] and res[3]["status"] == [0, 0, 0] and res[3]["solve_after"] == [None] * 3, res[3]
