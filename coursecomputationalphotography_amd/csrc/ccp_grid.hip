@@ -859,10 +859,8 @@ try {
     choose_tiling(g);
     g->masked = (d->flags & CCP_GRID_DIRICHLET_MASK) != 0;
     if (g->masked) {
-        if (g->ghost_top || g->ghost_bottom) {               // row blocks of a masked grid: not built
-            delete g;
-            return CCP_ERR_UNSUPPORTED;
-        }
+        // (a row block of a masked grid is a masked grid of its own rows plus ghosts: what lies beyond the ghosts is read
+        // as zero like everything outside the region, and is as stale as any ghost — the trapezoid argument covers it)
         g->fuse_tmax = std::min(g->fuse_tmax, kMaskedMaxT);
         if (!getenv("CCP_GS_CHUNK")) g->rows_per_chunk = 160;   // what the tuner picks on region canvases of 4-80 M pixels (untuned handles)
     }
@@ -1009,7 +1007,7 @@ try {
         for (int x = 0; x < geo.W; ++x) {
             if (!row[x]) continue;
             split[(size_t)(((long)l * 2 + ((x + y) & 1)) * geo.pitch + (x >> 1))] = 1;
-            ++count;
+            if (l >= geo.own_lo && l < geo.own_hi) ++count;
         }
     }
     CCP_HIP(hipMemcpyAsync(g->maskp.p, split.data(), split.size(), hipMemcpyHostToDevice, g->stream));
@@ -2002,7 +2000,8 @@ try {
     const RcclApi *api = rccl_api();
     if (!api) return CCP_ERR_RCCL;
     // every rank learns every block: the partition must be contiguous row blocks of one image, in rank order
-    const int me[4] = {g->desc.row_begin, g->desc.row_count, g->desc.ghost, g->desc.width ^ (g->desc.height << 1) ^ (g->desc.channels << 28)};
+    const int me[4] = {g->desc.row_begin, g->desc.row_count, g->desc.ghost,
+                       g->desc.width ^ (g->desc.height << 1) ^ (g->desc.channels << 28) ^ ((g->desc.flags & CCP_GRID_DIRICHLET_MASK) << 27)};
     int *dev = reinterpret_cast<int *>(c->scratch.p);
     std::vector<int> all((size_t)4 * c->world);
     CCP_HIP(hipMemcpyAsync(dev + 4 * c->rank, me, sizeof(me), hipMemcpyHostToDevice, g->stream));

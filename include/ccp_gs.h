@@ -214,9 +214,11 @@ typedef struct ccp_grid_desc {
  * nothing outside (zero Dirichlet values around it) — the matrix a gradient-domain blend restricted to a
  * brush / label region solves (BASELINE configs[4]).  The region is one byte per pixel (ccp_grid_set_mask_host);
  * pixels outside it are fixed at 0 in x and b.  Sweeps (red-black, fixed count or stop rule), b := A x, the
- * residual and conjugate gradient honour the mask; the SolveChannel-specific entry points (assembly,
- * reference-order sweep) and row blocks return CCP_ERR_UNSUPPORTED.  ccp_csr_gauss_seidel reaches this form by
- * itself when the uploaded matrix is such a Laplacian of a raster region (ccp_csr_last_path). */
+ * residual and conjugate gradient honour the mask, and so does the sweep in the reference's order (raster order of
+ * the region); SolveChannel's assembly entry points return CCP_ERR_UNSUPPORTED.  Row blocks work as for the plain
+ * grid (ghost rows, ccp_grid_attach_comm, ccp_grid_sweep_rowblocked, ...: the region of BASELINE configs[4] on
+ * several GPUs, every block handed the whole mask and keeping its own rows of it).  ccp_csr_gauss_seidel reaches
+ * this form by itself when the uploaded matrix is such a Laplacian of a raster region (ccp_csr_last_path). */
 #define CCP_GRID_DIRICHLET_MASK 1
 
 /* Device layout, for callers that move halos themselves (torch.distributed / RCCL).

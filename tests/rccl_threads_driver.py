@@ -56,6 +56,12 @@ def run_ranks(world, fn):
     return out, err
 
 
+def region_mask(c):
+    if not c.get("mask"):
+        return None
+    return synth.disc_mask(c["W"], c["H"], seed=c.get("seed", 4321), n_discs=c.get("discs", 40), rmin=300.0, rmax=1400.0).astype(np.uint8)
+
+
 def system(g, scale=None, base=None):
     if base is None:
         g.randomize_x(1234, 0.0, 255.0)      # x_true: a function of (seed, x, y) only, so every block sees the same image
@@ -70,7 +76,8 @@ def system(g, scale=None, base=None):
 def case_sweep(c):
     """Owned rows after `iters` sweeps == the one-block sweep, bit for bit; the global residual too."""
     W, H, C_, world, ghost, iters, overlap = c["W"], c["H"], c.get("C", 1), c["world"], c["ghost"], c["iters"], c["overlap"]
-    whole = capi.Grid(W, H, C_)
+    mask = region_mask(c)                                  # a Dirichlet-mask grid (the region of BASELINE configs[4]) or None
+    whole = capi.Grid(W, H, C_, mask=mask)
     system(whole)
     whole.sweep(iters)
     want = np.stack([whole.get_x(ch) for ch in range(C_)])
@@ -82,7 +89,7 @@ def case_sweep(c):
     def rank_fn(rank, comm):
         assert comm.info()["rccl_version"] == 99901, "not the test transport"
         rb, rc = parts[rank]
-        g = capi.Grid(W, H, C_, rb, rc, ghost, 0)
+        g = capi.Grid(W, H, C_, rb, rc, ghost, 0, mask=mask)
         system(g)
         g.attach_comm(comm)
         g.set_overlap(overlap)
@@ -121,7 +128,8 @@ def case_stop_rule(c):
     W, H, world, ghost, eps = c["W"], c["H"], c["world"], c["ghost"], c["eps"]
     scale = c.get("scale", [1e-3, 3e-4])
     base = synth.poisson_system(W, H, 1234)[0].reshape(H, W)
-    ref = capi.Grid(W, H, len(scale))
+    mask = region_mask(c)
+    ref = capi.Grid(W, H, len(scale), mask=mask)
     system(ref, scale, base)
     reps_w = ref.gauss_seidel(eps, 600, 1)
     want = [ref.get_x(ch) for ch in range(len(scale))]
@@ -130,7 +138,7 @@ def case_stop_rule(c):
 
     def rank_fn(rank, comm):
         rb, rc = parts[rank]
-        g = capi.Grid(W, H, len(scale), rb, rc, ghost, 0)
+        g = capi.Grid(W, H, len(scale), rb, rc, ghost, 0, mask=mask)
         system(g, scale, base)
         g.attach_comm(comm)
         g.exchange_halos()
@@ -149,10 +157,14 @@ def case_stop_rule(c):
     got_last = np.concatenate([o[0][last] for o in out])
     # the oracle's stop sweep of the same rule on the colour-ordered matrix (one channel at a time)
     import oracle
-    v, col, r = synth.poisson_csr(W, H)
-    colour = oracle.grid_colour(W, H)
     orc = oracle.Oracle()
-    its_o = [orc.multicolour_gauss_seidel(v, col, r, colour, (base * s).ravel(), eps, 600)[1] for s in scale]
+    if mask is None:
+        v, col, r = synth.poisson_csr(W, H)
+        colour = oracle.grid_colour(W, H)
+        its_o = [orc.multicolour_gauss_seidel(v, col, r, colour, (base * s).ravel(), eps, 600)[1] for s in scale]
+    else:                                                  # the region's own matrix, unknowns in raster order
+        v, col, r, colour, ys, xs = synth.masked_laplacian_csr(mask != 0)
+        its_o = [orc.multicolour_gauss_seidel(v, col, r, colour, (base * s)[ys, xs], eps, 600)[1] for s in scale]
     return {"ok": True, "iterations_one_block": its_w, "iterations_oracle": [int(k) for k in its_o],
             "iterations_ranks": [[t[1] for t in o[1]] for o in out], "converged": [[t[0] for t in o[1]] for o in out],
             "step_ranks": [[t[2] for t in o[1]] for o in out], "step_one_block": [r.last_l1_step for r in reps_w],

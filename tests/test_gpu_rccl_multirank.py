@@ -47,6 +47,12 @@ SWEEPS = [
     (3, 777, 411, 2, 16, 29, [5, 17, 7]),       # ragged block heights, intervals straddling calls, two channels
     (4, 2048, 1024, 1, 16, 37, [20, 17]),
 ]
+# Dirichlet-mask grids (the region of BASELINE configs[4]) in row blocks: world, W, H, C, ghost, iters, calls
+MASK_SWEEPS = [
+    (2, 1200, 700, 1, 12, 19, None),
+    (3, 2048, 1100, 2, 16, 27, [11, 16]),
+    (4, 1500, 1300, 1, 32, 40, None),
+]
 
 
 def test_owned_rows_equal_one_block_with_overlap_on_and_off(fake_env):
@@ -54,6 +60,12 @@ def test_owned_rows_equal_one_block_with_overlap_on_and_off(fake_env):
     for world, W, H, C, ghost, iters, calls in SWEEPS:
         for overlap in (True, False):
             c = {"kind": "sweep", "world": world, "W": W, "H": H, "C": C, "ghost": ghost, "iters": iters, "overlap": overlap}
+            if calls:
+                c["calls"] = calls
+            cases.append(c)
+    for world, W, H, C, ghost, iters, calls in MASK_SWEEPS:
+        for overlap in (True, False):
+            c = {"kind": "sweep", "mask": True, "world": world, "W": W, "H": H, "C": C, "ghost": ghost, "iters": iters, "overlap": overlap}
             if calls:
                 c["calls"] = calls
             cases.append(c)
@@ -76,6 +88,7 @@ def test_owned_rows_equal_one_block_with_overlap_on_and_off(fake_env):
 
 def test_all_reduced_stop_rule_stops_at_the_references_sweep(fake_env):
     cases = [{"kind": "stop_rule", "world": w, "W": 96, "H": 80, "ghost": g, "eps": 0.5} for w, g in ((2, 8), (3, 4), (4, 2))]
+    cases += [{"kind": "stop_rule", "mask": True, "discs": 12, "world": w, "W": 160, "H": 120, "ghost": g, "eps": 5.0} for w, g in ((2, 8), (3, 2))]
     for r in drive(fake_env, cases):
         assert r["ok"], r
         want = r["iterations_one_block"]
