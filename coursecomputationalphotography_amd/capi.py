@@ -145,7 +145,7 @@ def load() -> C.CDLL:
     L.ccp_csr_destroy.argtypes = [vp]
     L.ccp_csr_upload.argtypes = [vp, i32, i32, i64, vp, vp, vp, vp]
     L.ccp_csr_upload_rows.argtypes = [vp, vp, i32, i32, i32, i64, vp, vp, vp, vp, vp, i32]
-    L.ccp_csr_rows_info.argtypes = [vp] + [C.POINTER(i32)] * 4 + [C.POINTER(i64)] * 2
+    L.ccp_csr_rows_info.argtypes = [vp] + [C.POINTER(i32)] * 5 + [C.POINTER(i64)] * 2
     L.ccp_csr_set_colouring.argtypes = [vp, vp, i32]
     L.ccp_csr_get_colouring.argtypes = [vp, vp, C.POINTER(i32)]
     L.ccp_csr_insert.argtypes = [vp, i32, i32, dbl]
@@ -351,10 +351,10 @@ class CsrMatrix:
         return self
 
     def rows_info(self):
-        a = [C.c_int32() for _ in range(4)]
+        a = [C.c_int32() for _ in range(5)]
         b = [C.c_int64() for _ in range(2)]
         check(self.L.ccp_csr_rows_info(self.h, *[C.byref(t) for t in a + b]), "ccp_csr_rows_info")
-        return dict(zip(("first_row", "n_rows", "n_ghost", "n_peers", "values_sent", "exchanges"), (t.value for t in a + b)))
+        return dict(zip(("first_row", "n_rows", "n_ghost", "n_peers", "edge_slices", "values_sent", "exchanges"), (t.value for t in a + b)))
 
     def upload_compressed(self, values, col_offset, row_offset, n_cols=None):
         """Compressed CSR (n+1 offsets) -> the slack arrays with zero slack."""

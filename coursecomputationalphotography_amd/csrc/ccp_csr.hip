@@ -196,8 +196,25 @@ struct ccp_csr {
         DevBuf<double> sendbuf;
         long nat_total = 0;                                  // entries of nat_send_pos
         long exchanges = 0, values_sent = 0;
+        // Overlap: per colour the slices that hold a row some peer references ("edge") are swept first; their values
+        // travel on stream_comm while the other slices of the colour are swept.  Off when the edge slices are more
+        // than a quarter of the image (nothing left to hide behind) or CCP_GS_ROWS_OVERLAP=0.
+        bool overlap = false;
+        DevBuf<int> slice_list;                              // per colour: edge slices, then the others
+        std::vector<int> edge_off, edge_cnt, inner_off, inner_cnt;    // [n_colours] ranges of slice_list
+        std::vector<long> part_off;                          // [n_colours + 1] partial-sum blocks of a colour (edge launch, then inner)
+        hipStream_t stream_comm = nullptr;
+        hipEvent_t ev_edge = nullptr, ev_comm = nullptr;
         void reset()
         {
+            if (stream_comm) (void)hipStreamDestroy(stream_comm);
+            if (ev_edge) (void)hipEventDestroy(ev_edge);
+            if (ev_comm) (void)hipEventDestroy(ev_comm);
+            stream_comm = nullptr;
+            ev_edge = ev_comm = nullptr;
+            overlap = false;
+            slice_list.release();
+            edge_off.clear(); edge_cnt.clear(); inner_off.clear(); inner_cnt.clear(); part_off.clear();
             on = false;
             comm = nullptr;
             row_begin = n_local = n_global = n_lo = n_ghost = n_colours = peers = 0;
@@ -1561,7 +1578,7 @@ int rb_agree(ccp_comm *c, hipStream_t s, int status)
 
 // One grouped exchange on the handle's stream: `send_cnt[r]` doubles from sendbuf + send_off[r] to rank r, `recv_cnt[r]`
 // doubles from rank r into x + recv_pos[r].
-int rb_messages(ccp_csr *m, const int *send_cnt, const int *send_off, const int *recv_cnt, const int *recv_pos, double *x)
+int rb_messages(ccp_csr *m, const int *send_cnt, const int *send_off, const int *recv_cnt, const int *recv_pos, double *x, hipStream_t s)
 {
     ccp_csr::RowBlock &rb = m->rb;
     const RcclApi *api = rccl_api();
@@ -1574,11 +1591,11 @@ int rb_messages(ccp_csr *m, const int *send_cnt, const int *send_off, const int 
     ncclResult_t res = ncclSuccess;
     for (int r = 0; r < W && res == ncclSuccess; ++r) {
         if (send_cnt[r] > 0) {
-            res = api->Send(rb.sendbuf.p + send_off[r], (size_t)send_cnt[r], ncclDouble, r, rb.comm->comm, m->stream);
+            res = api->Send(rb.sendbuf.p + send_off[r], (size_t)send_cnt[r], ncclDouble, r, rb.comm->comm, s);
             rb.values_sent += send_cnt[r];
         }
         if (recv_cnt[r] > 0 && res == ncclSuccess)
-            res = api->Recv(x + recv_pos[r], (size_t)recv_cnt[r], ncclDouble, r, rb.comm->comm, m->stream);
+            res = api->Recv(x + recv_pos[r], (size_t)recv_cnt[r], ncclDouble, r, rb.comm->comm, s);
     }
     const ncclResult_t e = api->GroupEnd();
     if (res != ncclSuccess) return rccl_fail(res, "ncclSend/ncclRecv", __FILE__, __LINE__);
@@ -1589,18 +1606,18 @@ int rb_messages(ccp_csr *m, const int *send_cnt, const int *send_off, const int 
 
 // The rows of colour g this block owns have new values: hand the ones other blocks reference to their ghosts and
 // take ours (m->x in colour-major order).
-int rb_exchange_colour(ccp_csr *m, int g)
+int rb_exchange_colour(ccp_csr *m, int g, hipStream_t s)
 {
     ccp_csr::RowBlock &rb = m->rb;
     const int W = rb.comm->world;
     const long seg0 = rb.col_seg_off[(size_t)g], seg = rb.col_seg_off[(size_t)g + 1] - seg0;
     if (seg > 0) {
-        hipLaunchKernelGGL((k_permute<true>), dim3(blocks_for(seg)), dim3(kBlock), 0, m->stream, rb.sendbuf.p + seg0, m->x.p,
+        hipLaunchKernelGGL((k_permute<true>), dim3(blocks_for(seg)), dim3(kBlock), 0, s, rb.sendbuf.p + seg0, m->x.p,
                            rb.col_send_pos.p + seg0, seg);
         CCP_HIP(hipGetLastError());
     }
     const size_t at = (size_t)g * W;
-    return rb_messages(m, &rb.col_send_cnt[at], &rb.col_send_off[at], &rb.col_recv_cnt[at], &rb.col_recv_pos[at], m->x.p);
+    return rb_messages(m, &rb.col_send_cnt[at], &rb.col_send_off[at], &rb.col_recv_cnt[at], &rb.col_recv_pos[at], m->x.p, s);
 }
 
 // All ghosts of a vector in natural (extended) order.
@@ -1612,7 +1629,7 @@ int rb_exchange_natural(ccp_csr *m, double *x)
         hipLaunchKernelGGL((k_permute<true>), dim3(blocks_for(total)), dim3(kBlock), 0, m->stream, rb.sendbuf.p, x, rb.nat_send_pos.p, total);
         CCP_HIP(hipGetLastError());
     }
-    return rb_messages(m, rb.nat_send_cnt.data(), rb.nat_send_off.data(), rb.nat_recv_cnt.data(), rb.nat_recv_pos.data(), x);
+    return rb_messages(m, rb.nat_send_cnt.data(), rb.nat_send_off.data(), rb.nat_recv_cnt.data(), rb.nat_recv_pos.data(), x, m->stream);
 }
 
 // A vector of the block (n_local host values) into the extended natural order on the device: ghosts 0.
@@ -1654,6 +1671,7 @@ try {
     if (m->ev1) (void)hipEventDestroy(m->ev1);
     if (m->grid) ccp_grid_destroy(m->grid);
     if (m->region_grid) ccp_grid_destroy(m->region_grid);
+    m->rb.reset();
     delete m;
     return CCP_OK;
 } CCP_ABI_CATCH
@@ -2001,6 +2019,56 @@ try {
             CCP_HIP(hipStreamSynchronize(s));
         }
     }
+    // the slices of every colour that hold a row a peer references, and the others
+    if (status == CCP_OK && sc.n_slices > 0) {
+        std::vector<int> row0((size_t)sc.n_slices);
+        CCP_HIP(hipMemcpyAsync(row0.data(), sc.slice_row0.p, sizeof(int) * (size_t)sc.n_slices, hipMemcpyDeviceToHost, s));
+        CCP_HIP(hipStreamSynchronize(s));
+        std::vector<unsigned char> is_edge((size_t)sc.n_slices, 0);
+        long n_edge = 0;
+        for (int pos : col_pos) {
+            const int sl = (int)(std::upper_bound(row0.begin(), row0.end(), pos) - row0.begin()) - 1;
+            if (sl >= 0 && !is_edge[(size_t)sl]) {
+                is_edge[(size_t)sl] = 1;
+                ++n_edge;
+            }
+        }
+        bool want = n_edge > 0 && n_edge * 4 <= (long)sc.n_slices;
+        if (const char *e = getenv("CCP_GS_ROWS_OVERLAP")) want = want && atoi(e) != 0;
+        if (want) {
+            const int waves = kBlock / kWave;
+            std::vector<int> list;
+            list.reserve((size_t)sc.n_slices);
+            rb.edge_off.assign((size_t)n_colours, 0); rb.edge_cnt.assign((size_t)n_colours, 0);
+            rb.inner_off.assign((size_t)n_colours, 0); rb.inner_cnt.assign((size_t)n_colours, 0);
+            rb.part_off.assign((size_t)n_colours + 1, 0);
+            for (int g = 0; g < n_colours; ++g) {
+                const int s0 = g < sc.n_groups ? sc.group_slice_ptr[(size_t)g] : 0, s1 = g < sc.n_groups ? sc.group_slice_ptr[(size_t)g + 1] : 0;
+                rb.edge_off[(size_t)g] = (int)list.size();
+                for (int sl = s0; sl < s1; ++sl)
+                    if (is_edge[(size_t)sl]) list.push_back(sl);
+                rb.edge_cnt[(size_t)g] = (int)list.size() - rb.edge_off[(size_t)g];
+                rb.inner_off[(size_t)g] = (int)list.size();
+                for (int sl = s0; sl < s1; ++sl)
+                    if (!is_edge[(size_t)sl]) list.push_back(sl);
+                rb.inner_cnt[(size_t)g] = (int)list.size() - rb.inner_off[(size_t)g];
+                rb.part_off[(size_t)g + 1] = rb.part_off[(size_t)g] + (rb.edge_cnt[(size_t)g] + waves - 1) / waves + (rb.inner_cnt[(size_t)g] + waves - 1) / waves;
+            }
+            status = rb.slice_list.alloc(list.size());
+            if (status == CCP_OK) {
+                CCP_HIP(hipMemcpyAsync(rb.slice_list.p, list.data(), sizeof(int) * list.size(), hipMemcpyHostToDevice, s));
+                CCP_HIP(hipStreamSynchronize(s));
+                int lo_p = 0, hi_p = 0;                          // hi_p = greatest priority (numerically lowest)
+                (void)hipDeviceGetStreamPriorityRange(&lo_p, &hi_p);
+                if (hipStreamCreateWithPriority(&rb.stream_comm, hipStreamNonBlocking, hi_p) != hipSuccess ||
+                    hipEventCreateWithFlags(&rb.ev_edge, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&rb.ev_comm, hipEventDisableTiming) != hipSuccess)
+                    status = CCP_ERR_HIP;
+                else
+                    rb.overlap = true;
+            }
+        }
+    }
     status = rb_agree(c, s, status);
     if (status != CCP_OK) {
         m->uploaded = false;
@@ -2011,7 +2079,7 @@ try {
     return CCP_OK;
 } CCP_ABI_CATCH
 
-int ccp_csr_rows_info(ccp_csr *m, int32_t *first_row, int32_t *n_rows, int32_t *n_ghost, int32_t *n_peers,
+int ccp_csr_rows_info(ccp_csr *m, int32_t *first_row, int32_t *n_rows, int32_t *n_ghost, int32_t *n_peers, int32_t *edge_slices,
                       int64_t *values_sent, int64_t *exchanges)
 try {
     if (!m) return CCP_ERR_BAD_ARG;
@@ -2020,6 +2088,11 @@ try {
     if (n_rows) *n_rows = m->rb.n_local;
     if (n_ghost) *n_ghost = m->rb.n_ghost;
     if (n_peers) *n_peers = m->rb.peers;
+    if (edge_slices) {
+        *edge_slices = 0;
+        if (m->rb.overlap)
+            for (int v : m->rb.edge_cnt) *edge_slices += v;
+    }
     if (values_sent) *values_sent = m->rb.values_sent;
     if (exchanges) *exchanges = m->rb.exchanges;
     return CCP_OK;
@@ -2279,7 +2352,7 @@ try {
     CCP_TRY(ordering == CCP_ORDER_MULTICOLOUR ? ensure_multicolour(m) : ensure_lexicographic(m));
     const long n = m->n_rows;
     hipStream_t s = m->stream;
-    CCP_TRY(ensure_partial(m, sc.group_block_off[sc.n_groups]));
+    CCP_TRY(ensure_partial(m, std::max<long>(sc.group_block_off[sc.n_groups], (rowblock && m->rb.overlap) ? m->rb.part_off.back() : 0)));
     // stage b (and x0) in natural order, gather into schedule order (a row block: b, x0 and x_out hold the block's
     // own rows; the ghosts sit around them in the extended order and get their first values from their owners)
     if (n) {
@@ -2298,7 +2371,7 @@ try {
         CCP_HIP(hipGetLastError());
     }
     if (rowblock && x0)
-        for (int g = 0; g < m->rb.n_colours; ++g) CCP_TRY(rb_exchange_colour(m, g));
+        for (int g = 0; g < m->rb.n_colours; ++g) CCP_TRY(rb_exchange_colour(m, g, s));
     CsrSolveState host{};
     host.active = 1;
     host.last_eps = 10.0;                    // sparse-matrix.h:354
@@ -2397,6 +2470,28 @@ try {
             const bool check = check_every > 0 && (k % check_every == 0);
             for (int g = 0; g < (rowblock ? m->rb.n_colours : sc.n_groups); ++g) {
                 const int s0 = g < sc.n_groups ? sc.group_slice_ptr[g] : 0, s1 = g < sc.n_groups ? sc.group_slice_ptr[g + 1] : 0;
+                if (rowblock && m->rb.overlap) {
+                    // edge slices, then their values on the way while the rest of the colour is swept
+                    ccp_csr::RowBlock &rb = m->rb;
+                    const int waves = kBlock / kWave;
+                    const int ne = rb.edge_cnt[(size_t)g], ni = rb.inner_cnt[(size_t)g];
+                    const unsigned be = (unsigned)((ne + waves - 1) / waves), bi = (unsigned)((ni + waves - 1) / waves);
+                    double *part = m->partial.p + rb.part_off[(size_t)g];
+                    if (ne) {
+                        if (check) hipLaunchKernelGGL((k_sell_gs_list<true>), dim3(be), dim3(kBlock), 0, s, view, rb.slice_list.p + rb.edge_off[(size_t)g], ne, m->x.p, m->b.p, part, active);
+                        else hipLaunchKernelGGL((k_sell_gs_list<false>), dim3(be), dim3(kBlock), 0, s, view, rb.slice_list.p + rb.edge_off[(size_t)g], ne, m->x.p, m->b.p, part, active);
+                    }
+                    CCP_HIP(hipEventRecord(rb.ev_edge, s));
+                    CCP_HIP(hipStreamWaitEvent(rb.stream_comm, rb.ev_edge, 0));
+                    CCP_TRY(rb_exchange_colour(m, g, rb.stream_comm));
+                    CCP_HIP(hipEventRecord(rb.ev_comm, rb.stream_comm));
+                    if (ni) {
+                        if (check) hipLaunchKernelGGL((k_sell_gs_list<true>), dim3(bi), dim3(kBlock), 0, s, view, rb.slice_list.p + rb.inner_off[(size_t)g], ni, m->x.p, m->b.p, part + be, active);
+                        else hipLaunchKernelGGL((k_sell_gs_list<false>), dim3(bi), dim3(kBlock), 0, s, view, rb.slice_list.p + rb.inner_off[(size_t)g], ni, m->x.p, m->b.p, part + be, active);
+                    }
+                    CCP_HIP(hipStreamWaitEvent(s, rb.ev_comm, 0));       // the next colour reads the ghosts
+                    continue;
+                }
                 if (s1 > s0) {
                     const unsigned blocks = (unsigned)(sc.group_block_off[g + 1] - sc.group_block_off[g]);
                     if (check)
@@ -2407,11 +2502,12 @@ try {
                                            m->partial.p, active);
                 }
                 // a row block: the colour's new values reach the blocks that reference them before the next colour runs
-                if (rowblock) CCP_TRY(rb_exchange_colour(m, g));
+                if (rowblock) CCP_TRY(rb_exchange_colour(m, g, s));
             }
             CCP_HIP(hipGetLastError());
             if (check) {
-                hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, m->partial.p, sc.group_block_off[sc.n_groups], 1L, eps_accum, 0);
+                const long n_part = (rowblock && m->rb.overlap) ? m->rb.part_off.back() : sc.group_block_off[sc.n_groups];
+                hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, m->partial.p, n_part, 1L, eps_accum, 0);
                 if (rowblock) {
                     // sparse-matrix.h:376 over the whole matrix: the blocks' step sums added up, on every rank alike
                     const RcclApi *api = rccl_api();

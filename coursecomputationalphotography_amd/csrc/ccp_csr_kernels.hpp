@@ -38,17 +38,12 @@ struct SellView {
 // when 0; sigma accumulates values*x over col != i in storage order; x = (b - sigma) / a_ii.
 // L1: block partial of sum|x_new - x_old| to partial[blockIdx.x].  `active` (nullable) points at
 // the device-side solve state: a converged solve turns the remaining queued passes into no-ops.
+// The rows of slice s: lane per row.  Returns |x_new - x_old| of the lane's row (L1) or 0.
 template <bool L1>
-__global__ void __launch_bounds__(kBlock)
-k_sell_gs(SellView m, int s_first, int s_last, double *__restrict__ x, const double *__restrict__ b,
-          double *__restrict__ partial, const int *__restrict__ active)
+__device__ __forceinline__ double sell_gs_slice(const SellView &m, int s, int lane, double *__restrict__ x, const double *__restrict__ b)
 {
-    __shared__ double scratch[kBlock / kWave];
-    const int lane = threadIdx.x & (kWave - 1);
-    const int s = s_first + blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     double acc = 0.0;
-    const bool run = (active == nullptr) || (*active != 0);
-    if (run && s < s_last && lane < m.slice_rows[s]) {
+    if (lane < m.slice_rows[s]) {
         const int row = m.slice_row0[s] + lane;
         const long off = m.slice_off[s] + lane;
         const int width = m.slice_width[s];
@@ -66,6 +61,39 @@ k_sell_gs(SellView m, int s_first, int s_last, double *__restrict__ x, const dou
             x[row] = nv;
         }
     }
+    return acc;
+}
+
+template <bool L1>
+__global__ void __launch_bounds__(kBlock)
+k_sell_gs(SellView m, int s_first, int s_last, double *__restrict__ x, const double *__restrict__ b,
+          double *__restrict__ partial, const int *__restrict__ active)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int s = s_first + blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    double acc = 0.0;
+    const bool run = (active == nullptr) || (*active != 0);
+    if (run && s < s_last) acc = sell_gs_slice<L1>(m, s, lane, x, b);
+    if (L1) {
+        const double t = block_sum(acc, scratch);
+        if (threadIdx.x == 0) partial[blockIdx.x] = t;
+    }
+}
+
+// The same pass over the slices list[0 .. count): a row block sweeps the slices whose rows other blocks reference
+// first, so that their values travel while the rest of the colour is swept (ccp_csr.hip: RowBlock).
+template <bool L1>
+__global__ void __launch_bounds__(kBlock)
+k_sell_gs_list(SellView m, const int *__restrict__ list, int count, double *__restrict__ x, const double *__restrict__ b,
+               double *__restrict__ partial, const int *__restrict__ active)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int at = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
+    double acc = 0.0;
+    const bool run = (active == nullptr) || (*active != 0);
+    if (run && at < count) acc = sell_gs_slice<L1>(m, list[at], lane, x, b);
     if (L1) {
         const double t = block_sum(acc, scratch);
         if (threadIdx.x == 0) partial[blockIdx.x] = t;

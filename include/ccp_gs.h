@@ -180,13 +180,16 @@ int ccp_csr_residual_norm2(ccp_csr *m, const double *b, const double *x, double 
  *   ccp_csr_get_colouring   the block's own rows.
  * The reference-order sweep, conjugate gradient, ccp_csr_insert and ccp_csr_set_colouring return
  * CCP_ERR_UNSUPPORTED on a row block.  ccp_csr_upload returns the handle to the one-GPU form.
- * ccp_csr_rows_info: the block, its ghosts (columns owned by peers), the peers it exchanges with, and the
- * values sent / grouped exchanges issued since the upload (outputs may be NULL). */
+ * The sweep overlaps the messages with arithmetic: per colour the 64-row slices that hold a row some peer
+ * references are swept first and their values travel on a second stream while the other slices of the colour
+ * are swept (off when those slices are more than a quarter of the block, or with CCP_GS_ROWS_OVERLAP=0).
+ * ccp_csr_rows_info: the block, its ghosts (columns owned by peers), the peers it exchanges with, the slices swept
+ * first (0: no overlap), and the values sent / grouped exchanges issued since the upload (outputs may be NULL). */
 typedef struct ccp_comm ccp_comm;
 int ccp_csr_upload_rows(ccp_csr *m, ccp_comm *comm, int32_t first_row, int32_t n_rows, int32_t n_global, int64_t n_values,
                         const double *values, const int32_t *col_offset, const int32_t *row_begin, const int32_t *row_num_nze,
                         const int32_t *colour, int32_t n_colours);
-int ccp_csr_rows_info(ccp_csr *m, int32_t *first_row, int32_t *n_rows, int32_t *n_ghost, int32_t *n_peers,
+int ccp_csr_rows_info(ccp_csr *m, int32_t *first_row, int32_t *n_rows, int32_t *n_ghost, int32_t *n_peers, int32_t *edge_slices,
                       int64_t *values_sent, int64_t *exchanges);
 
 /* ========================================================================================

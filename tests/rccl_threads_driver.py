@@ -303,6 +303,7 @@ def case_csr_rows(c):
     b = synth.csr_apply(v, col, rowp, xt)
     x0 = synth.x_true(n, 99) if c.get("x0") else None
     os.environ["CCP_GS_MASKED"] = "0"              # the one-GPU comparison on the stored matrix too
+    os.environ["CCP_GS_ROWS_OVERLAP"] = "1" if c.get("overlap", True) else "0"
     whole = capi.CsrMatrix().upload_compressed(v, col, rowp).set_colouring(colour, nc)
     want, rep_w = whole.gauss_seidel(b, eps, iters, x0, check_every=1 if eps > 0 else 0)
     y_w = whole.apply_to_vector(xt)
@@ -339,6 +340,7 @@ def case_csr_rows(c):
 
     out, err = run_ranks(world, rank_fn)
     os.environ.pop("CCP_GS_MASKED", None)
+    os.environ.pop("CCP_GS_ROWS_OVERLAP", None)
     if any(err):
         return {"ok": False, "error": [repr(e) for e in err]}
     after = transport_stats()
@@ -354,7 +356,7 @@ def case_csr_rows(c):
             "iterations_one_gpu": rep_w.iterations, "iterations_oracle": int(it_o), "iterations_ranks": [o[1][1] for o in out],
             "converged_ranks": [o[1][0] for o in out], "converged_one_gpu": rep_w.converged,
             "step_ranks": [o[1][2] for o in out], "step_one_gpu": rep_w.last_l1_step,
-            "ghosts": ghosts, "peers": [o[5]["n_peers"] for o in out], "values_sent": [o[5]["values_sent"] for o in out],
+            "ghosts": ghosts, "peers": [o[5]["n_peers"] for o in out], "edge_slices": [o[5]["edge_slices"] for o in out], "values_sent": [o[5]["values_sent"] for o in out],
             "exchanges": [o[5]["exchanges"] for o in out], "own_colours_ok": all(o[6] for o in out),
             "unsupported": [o[7] for o in out], "path": [o[8] for o in out],
             "sends": after["sends"] - before["sends"], "recvs": after["recvs"] - before["recvs"], "bytes": after["bytes"] - before["bytes"]}

@@ -164,7 +164,7 @@ CSR_ROWS = [
 
 
 def test_csr_row_blocks_sweep_the_one_gpu_iterates(fake_env):
-    res = drive(fake_env, [dict(c, kind="csr_rows") for c in CSR_ROWS])
+    res = drive(fake_env, [dict(c, kind="csr_rows", overlap=ov) for c in CSR_ROWS for ov in (True, False)])
     for r in res:
         c = r["case"]
         assert r["ok"], r
@@ -183,12 +183,16 @@ def test_csr_row_blocks_sweep_the_one_gpu_iterates(fake_env):
         assert r["bytes"] == 8 * sent + 2 * 4 * sum(r["ghosts"]), r
         if c["matrix"] == "mask":
             assert max(r["peers"]) <= 2, r                    # raster order: a block touches the block before and after it
+            # ... through a few slices at its two ends: those are swept first and their values travel beside the rest
+            assert (max(r["edge_slices"]) > 0) == c["overlap"], r
         else:
             assert max(r["peers"]) == c["world"] - 1, r
+            assert max(r["edge_slices"]) == 0, r              # every slice holds a referenced row: nothing to hide behind
 
 
 def test_csr_row_blocks_stop_at_the_references_sweep(fake_env):
-    cases = [{"kind": "csr_rows", "matrix": "mask", "W": 200, "H": 150, "rmax": 700.0, "world": w, "iters": 500, "eps": 2.0} for w in (2, 3)]
+    cases = [{"kind": "csr_rows", "matrix": "mask", "W": 200, "H": 150, "rmax": 700.0, "world": w, "iters": 500, "eps": 2.0, "overlap": w == 2}
+             for w in (2, 3)]
     cases.append({"kind": "csr_rows", "matrix": "random", "n": 2500, "deg": 3, "world": 4, "iters": 500, "eps": 1e-6})
     for r in drive(fake_env, cases):
         assert r["ok"], r
