@@ -180,3 +180,43 @@ def test_edge_hand_off_inside_the_launch(capi, monkeypatch, env, W, H, parts, gh
     for blk in blocks:
         blk.close()
     assert np.array_equal(got, want)
+
+
+def test_world1_csr_row_block_and_mask_grid_through_real_rccl(capi, monkeypatch):
+    """ccp_csr_upload_rows with the process's real RCCL at world 1: the all-gathered partition, the (empty) halo lists,
+    the all-reduced stop rule and residual run through librccl itself; results are the one-GPU handle's."""
+    from coursecomputationalphotography_amd import synth
+    monkeypatch.setenv("CCP_GS_MASKED", "0")
+    comm = capi.Comm(capi.comm_unique_id(), 0, 1, 0)
+    mask = synth.disc_mask(300, 220, n_discs=20, rmin=300.0, rmax=700.0)
+    v, col, rowp, colour, ys, xs = synth.masked_laplacian_csr(mask)
+    n = len(rowp) - 1
+    xt = synth.x_true(n, 1234)
+    b = synth.csr_apply(v, col, rowp, xt)
+    one = capi.CsrMatrix().upload_compressed(v, col, rowp).set_colouring(colour, 2)
+    blk = capi.CsrMatrix().upload_rows(comm, 0, n, v, col, rowp[:-1], np.diff(rowp), colour, 2)
+    info = blk.rows_info()
+    assert (info["n_rows"], info["n_ghost"], info["n_peers"], info["edge_slices"]) == (n, 0, 0, 0)
+    want, _ = one.gauss_seidel(b, 0.0, 9, check_every=0)
+    got, rep = blk.gauss_seidel(b, 0.0, 9, check_every=0)
+    assert rep.iterations == 9 and np.array_equal(got, want)
+    want, rep_w = one.gauss_seidel(b * 1e-3, 2.0, 900)
+    got, rep = blk.gauss_seidel(b * 1e-3, 2.0, 900)
+    assert rep_w.converged == 1 and (rep.converged, rep.iterations) == (1, rep_w.iterations) and np.array_equal(got, want)
+    assert np.array_equal(blk.apply_to_vector(xt), one.apply_to_vector(xt))
+    assert np.allclose(blk.residual_norm2(b, got), one.residual_norm2(b, want), rtol=1e-13, atol=0.0)
+    blk.close()
+    one.close()
+    # a Dirichlet-mask grid as the one row block of a communicator
+    m8 = mask.astype(np.uint8)
+    ref = make(capi, 300, 220, 1, mask=m8)
+    g = make(capi, 300, 220, 1, mask=m8)
+    g.attach_comm(comm)
+    g.exchange_halos()
+    ref.sweep(17)
+    g.sweep_rowblocked(17)
+    assert np.array_equal(g.get_x(0), ref.get_x(0))
+    g.attach_comm(None)
+    g.close()
+    ref.close()
+    comm.close()
