@@ -44,6 +44,22 @@ constexpr int kFusedMaxCheckedT = 8;     // deepest pass that also reports the s
 #define CCP_FUSED_UNROLL 2
 #endif
 constexpr int kFusedUnroll = CCP_FUSED_UNROLL;          // march steps unrolled per loop trip (shifted window)
+#ifndef CCP_FUSED_LAND
+#define CCP_FUSED_LAND 2
+#endif
+// Trips of rows in flight from memory in the ordinary tiles of an unchecked, unmasked pass of depth 8: 2 (the checked and
+// the masked kernels, and the shallower passes at their higher occupancy, have no registers left for a second landing
+// pair and keep 1).  Measured (profiles/r03_window_forms.jsonl):
+// +2-3 % at 16384^2 and 4096^2 x 3 over one trip.
+constexpr int kFusedLand = CCP_FUSED_LAND;
+#ifndef CCP_FUSED_RING
+#define CCP_FUSED_RING 0
+#endif
+constexpr bool kFusedRing = CCP_FUSED_RING != 0;        // ordinary tiles of unchecked passes: the ring form of the window (FusedRing)
+#ifndef CCP_FUSED_RING_MASKED
+#define CCP_FUSED_RING_MASKED 0
+#endif
+constexpr bool kFusedRingMasked = CCP_FUSED_RING_MASKED != 0;
 constexpr int kStripLanes = kWave;       // half-columns per strip
 
 __host__ __device__ constexpr int fused_halo_px(int T) { return 2 * T; }               // per side
@@ -209,11 +225,34 @@ __host__ __device__ __forceinline__ void fused_chunk_rows(const FusedParams &P, 
 template <int T, int UNR>
 struct FusedWindow {
     static_assert(UNR > 0 && UNR % 2 == 0, "row parity must be a compile-time constant per unrolled step");
+    static constexpr bool kRing = false;
     static constexpr int HS = 2 * T;
     static constexpr int G = UNR;
     static constexpr int NT = HS + G + 1;
     // slot of the row at `dist` rows behind the newest row of unrolled step i (dist in [0, HS+1])
     __host__ __device__ static constexpr int slot(int i, int dist) { return HS + 1 + i - dist; }
+};
+
+// The RING form of the window (ordinary tiles, passes without the step norm): the row that is `dist` rows behind the
+// newest row of unrolled step i sits in slot (i - dist) mod P, and P march steps are unrolled per loop trip, so
+// every slot index is a compile-time constant and NOTHING is ever moved: a row stays in the registers its load put it
+// in until the row that comes P rows later overwrites it.  P = 2T + 2 rows in use (the newest row down to the row
+// above the one being stored) + kRingAhead rows in flight from memory, even (the colour of every unrolled update is
+// a compile-time constant).  Against the shifted form at T = 8 this removes the ~47 v_mov_b64 of a step's ~143 vector
+// instructions (the SQ counters of DESIGN 4.1 put the pass at the vector-issue limit wherever it is not at the HBM
+// limit); the loop body is P steps long (~17 KB at T = 8: it stays in the instruction cache).
+#ifndef CCP_RING_AHEAD
+#define CCP_RING_AHEAD 2
+#endif
+constexpr int kRingAhead = CCP_RING_AHEAD;          // even
+template <int T>
+struct FusedRing {
+    static constexpr bool kRing = true;
+    static constexpr int HS = 2 * T;
+    static constexpr int G = HS + 2 + kRingAhead;       // steps per loop trip = slots
+    static constexpr int NT = G;
+    static_assert(G % 2 == 0, "row parity must be a compile-time constant per unrolled step");
+    __host__ __device__ static constexpr int slot(int i, int dist) { return ((i - dist) % G + G) % G; }
 };
 
 // Memory goes through raw buffer instructions with one descriptor per image row: a row that does
@@ -266,6 +305,7 @@ struct FusedCtx {
     bool px_right[2];   // x < W-1
     bool px_first[2];   // x == 0
     bool has_first;     // wave-uniform: the strip holds pixel column 0 (the a_ii = 3 column)
+    double quarter;     // 0.25 in a scalar register pair the compiler cannot see through (fused_step, ring form)
 };
 
 // Row q of x (red, black) and b (red, black); rows outside [m0, m1) and lanes outside the image read 0.
@@ -311,12 +351,12 @@ constexpr int kStepFast = 0, kStepBorder = 2, kStepSide = 3;
 // MASKED (Dirichlet-mask grid): the update is fma(sum, q, b/4) with q = 1/4 for an unknown and 0 for a pixel
 // fixed at zero (whose b is 0): the same instruction count as the plain update, the mask costs registers (a
 // q window) instead of instructions.  The stencil is the uniform 5-point one — no degree logic anywhere.
-template <int T, int MODE, int L1, int UNR, int NT, int AN, bool MASKED = false, int NQ = 1, bool COH = false>
+template <int T, int MODE, int L1, int UNR, int NT, int AN, bool MASKED = false, int NQ = 1, bool COH = false, class Win = FusedWindow<T, UNR>>
 __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], double (&br)[NT], double (&bk)[NT],
                                            double (&acc)[AN], const FusedCtx &cx, const Geom &g, int f, int i,
                                            double (&qr)[NQ], double (&qk)[NQ])
 {
-    using Win = FusedWindow<T, UNR>;
+    static_assert(Win::NT == NT, "window policy and register arrays disagree");
     constexpr int HS = Win::HS;
 #pragma unroll
     for (int h = 1; h <= HS; ++h) {
@@ -338,7 +378,9 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
         double nv = old;
         if (MODE == kStepFast) {
             if (MASKED) nv = __builtin_fma(((up + left) + right) + dn, c ? qk[MASKED ? sr : 0] : qr[MASKED ? sr : 0], bq);
-            else nv = __builtin_fma(((up + left) + right) + dn, 0.25, bq);
+            // (ring form: 1/4 from a register — as a literal it forces the two-address v_fmac, whose destination is
+            // the b/4 the window must keep, i.e. a copy per update; the shifted form folds that copy into its shifts)
+            else nv = __builtin_fma(((up + left) + right) + dn, Win::kRing ? cx.quarter : 0.25, bq);
         } else if (MODE == kStepSide) {
             const double bv = bq * 4.0;
             // ordinary row y in [1, H-2]: cell(x,y-1), cell(x,y) exist iff x < W-1 (up, right,
@@ -400,21 +442,18 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
     __builtin_amdgcn_sched_barrier(0);
 }
 
-// One wave: strip `sx`, rows [ra, rb) of channel data at xin/xout/b (already channel-offset).
-// BORDERTILE = false: every pixel the wave can touch is ordinary: one straight-line loop of
-// kStepFast trips.  BORDERTILE = true: each trip picks among the three bodies (force_border:
-// debug, every trip takes kStepBorder).
-template <int T, bool BORDERTILE, int L1, int UNR, int AN, bool MASKED = false, bool COH = false>
-__device__ __forceinline__ void fused_wave(const double *__restrict__ xin, double *__restrict__ xout,
-                                           const double *__restrict__ bb, const Geom &g, int sx,
-                                           int ra, int rb, double (&acc)[AN], bool force_border = false,
-                                           const unsigned char *__restrict__ mask = nullptr)
+template <int T>
+__device__ __forceinline__ void fused_ctx_init(FusedCtx &cx, const double *__restrict__ xin, double *__restrict__ xout,
+                                               const double *__restrict__ bb, const Geom &g, int sx, int ra, int rb,
+                                               const unsigned char *__restrict__ mask)
 {
-    static_assert(!(MASKED && BORDERTILE), "a Dirichlet-mask grid has no border tiles: everything outside is zero");
-    using Win = FusedWindow<T, UNR>;
-    constexpr int HS = Win::HS, G = Win::G, NT = Win::NT;
-    FusedCtx cx;
+    constexpr int HS = 2 * T;
     cx.xin = xin; cx.xout = xout; cx.bb = bb;
+    {
+        double q = 0.25;
+        asm volatile("" : "+s"(q));
+        cx.quarter = q;
+    }
     const int lane = (int)(threadIdx.x & (kWave - 1));
     const int U = fused_useful_px(T);
     const int px0 = sx * U - fused_halo_px(T);          // first pixel column of the strip (even)
@@ -442,6 +481,119 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
     cx.ra = ra; cx.rb = rb;
     cx.m0 = max(ra - HS, 0);                            // rows this wave loads: [m0, m1)
     cx.m1 = min(rb + HS, g.local_rows);
+}
+
+// Row q of x and b straight into window slot S (ring form: no landing registers).
+template <int S, int NT, bool COH>
+__device__ __forceinline__ void fused_load_row_into(const FusedCtx &cx, const Geom &g, int q, double (&wr)[NT], double (&wk)[NT],
+                                                    double (&br)[NT], double (&bk)[NT])
+{
+    const bool exists = q >= cx.m0 && q < cx.m1;
+    const __amdgpu_buffer_rsrc_t rx = row_rsrc(cx.xin, g, q, exists), rbb = row_rsrc(cx.bb, g, q, exists);
+    wr[S] = buf_load<COH>(rx, cx.ld_r);
+    wk[S] = buf_load<COH>(rx, cx.ld_k);
+    br[S] = buf_load(rbb, cx.ld_r);
+    bk[S] = buf_load(rbb, cx.ld_k);
+}
+
+// One unrolled step of the ring march (I = its position in the loop body).
+template <int T, int I, int AN, bool MASKED, int NQ, bool COH>
+__device__ __forceinline__ void fused_ring_step(double (&wr)[FusedRing<T>::NT], double (&wk)[FusedRing<T>::NT], double (&br)[FusedRing<T>::NT],
+                                                double (&bk)[FusedRing<T>::NT], double (&qr)[NQ], double (&qk)[NQ],
+                                                int (&landm)[kRingAhead][2], double (&acc)[AN], const FusedCtx &cx, const Geom &g, int f)
+{
+    using Win = FusedRing<T>;
+    constexpr int NT = Win::NT;
+    // the row that becomes the newest row kRingAhead steps from now starts its way from memory
+    fused_load_row_into<Win::slot(I, -kRingAhead), NT, COH>(cx, g, f + kRingAhead, wr, wk, br, bk);
+    // the newest row enters: the window holds b/4 (fused_step), the mask bytes become the factor 1/4 or 0
+    constexpr int s0 = Win::slot(I, 0);
+    br[s0] = br[s0] * 0.25;
+    bk[s0] = bk[s0] * 0.25;
+    if (MASKED) {
+        qr[MASKED ? s0 : 0] = landm[I % kRingAhead][0] ? 0.25 : 0.0;
+        qk[MASKED ? s0 : 0] = landm[I % kRingAhead][1] ? 0.25 : 0.0;
+        fused_load_mask(cx, g, f + kRingAhead, landm[I % kRingAhead]);
+    }
+    fused_step<T, kStepFast, 0, 0, NT, AN, MASKED, NQ, COH, Win>(wr, wk, br, bk, acc, cx, g, f, I, qr, qk);
+}
+
+template <int T, int I, int AN, bool MASKED, int NQ, bool COH>
+struct FusedRingTrip {
+    // steps I .. P-1 of a loop trip; false: the march ended inside the trip
+    static __device__ __forceinline__ bool run(double (&wr)[FusedRing<T>::NT], double (&wk)[FusedRing<T>::NT], double (&br)[FusedRing<T>::NT],
+                                               double (&bk)[FusedRing<T>::NT], double (&qr)[NQ], double (&qk)[NQ], int (&landm)[kRingAhead][2],
+                                               double (&acc)[AN], const FusedCtx &cx, const Geom &g, int fb, int f_end)
+    {
+        if constexpr (I >= FusedRing<T>::G) {
+            return true;
+        } else {
+            if (fb + I > f_end) return false;               // (wave-uniform)
+            fused_ring_step<T, I, AN, MASKED, NQ, COH>(wr, wk, br, bk, qr, qk, landm, acc, cx, g, fb + I);
+            return FusedRingTrip<T, I + 1, AN, MASKED, NQ, COH>::run(wr, wk, br, bk, qr, qk, landm, acc, cx, g, fb, f_end);
+        }
+    }
+};
+
+template <int T, int J, bool MASKED, bool COH>
+struct FusedRingPrologue {
+    static __device__ __forceinline__ void run(double (&wr)[FusedRing<T>::NT], double (&wk)[FusedRing<T>::NT], double (&br)[FusedRing<T>::NT],
+                                               double (&bk)[FusedRing<T>::NT], int (&landm)[kRingAhead][2], const FusedCtx &cx, const Geom &g, int base)
+    {
+        if constexpr (J < kRingAhead) {
+            fused_load_row_into<FusedRing<T>::slot(J, 0), FusedRing<T>::NT, COH>(cx, g, base + J, wr, wk, br, bk);
+            if (MASKED) fused_load_mask(cx, g, base + J, landm[J]);
+            FusedRingPrologue<T, J + 1, MASKED, COH>::run(wr, wk, br, bk, landm, cx, g, base);
+        }
+    }
+};
+
+// One wave of an ordinary tile, ring form (see FusedRing): same rows, same arithmetic, same stores as fused_wave.
+template <int T, int AN, bool MASKED, bool COH>
+__device__ __forceinline__ void fused_wave_ring(const double *__restrict__ xin, double *__restrict__ xout,
+                                                const double *__restrict__ bb, const Geom &g, int sx, int ra, int rb,
+                                                double (&acc)[AN], const unsigned char *__restrict__ mask)
+{
+    using Win = FusedRing<T>;
+    constexpr int HS = Win::HS, P = Win::G, NT = Win::NT;
+    FusedCtx cx;
+    fused_ctx_init<T>(cx, xin, xout, bb, g, sx, ra, rb, mask);
+    const int base = cx.m0 - ((g.y0 + cx.m0) & 1);      // the march starts on an even image row
+    const int f_end = rb - 1 + HS;
+    double wr[NT], wk[NT], br[NT], bk[NT];
+    constexpr int NQ = MASKED ? NT : 1;
+    double qr[NQ], qk[NQ];
+    int landm[kRingAhead][2];
+#pragma unroll
+    for (int s = 0; s < NT; ++s) wr[s] = wk[s] = br[s] = bk[s] = 0.0;
+#pragma unroll
+    for (int s = 0; s < NQ; ++s) qr[s] = qk[s] = 0.0;
+#pragma unroll
+    for (int j = 0; j < kRingAhead; ++j) landm[j][0] = landm[j][1] = 0;
+    FusedRingPrologue<T, 0, MASKED, COH>::run(wr, wk, br, bk, landm, cx, g, base);
+    for (int fb = base; fb <= f_end; fb += P)
+        if (!FusedRingTrip<T, 0, AN, MASKED, NQ, COH>::run(wr, wk, br, bk, qr, qk, landm, acc, cx, g, fb, f_end)) break;
+}
+
+// One wave: strip `sx`, rows [ra, rb) of channel data at xin/xout/b (already channel-offset).
+// BORDERTILE = false: every pixel the wave can touch is ordinary: one straight-line loop of
+// kStepFast trips.  BORDERTILE = true: each trip picks among the three bodies (force_border:
+// debug, every trip takes kStepBorder).
+template <int T, bool BORDERTILE, int L1, int UNR, int AN, bool MASKED = false, bool COH = false>
+__device__ __forceinline__ void fused_wave(const double *__restrict__ xin, double *__restrict__ xout,
+                                           const double *__restrict__ bb, const Geom &g, int sx,
+                                           int ra, int rb, double (&acc)[AN], bool force_border = false,
+                                           const unsigned char *__restrict__ mask = nullptr)
+{
+    static_assert(!(MASKED && BORDERTILE), "a Dirichlet-mask grid has no border tiles: everything outside is zero");
+    if constexpr (kFusedRing && !BORDERTILE && L1 == 0 && (!MASKED || kFusedRingMasked)) {
+        fused_wave_ring<T, AN, MASKED, COH>(xin, xout, bb, g, sx, ra, rb, acc, mask);
+        return;
+    }
+    using Win = FusedWindow<T, UNR>;
+    constexpr int HS = Win::HS, G = Win::G, NT = Win::NT;
+    FusedCtx cx;
+    fused_ctx_init<T>(cx, xin, xout, bb, g, sx, ra, rb, mask);
     // the march starts on an even image row (y0 + base even) and advances G (even) rows per
     // trip, so the colour parity of every unrolled row update is a compile-time constant
     const int base = cx.m0 - ((g.y0 + cx.m0) & 1);
@@ -471,6 +623,43 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
         }
     }
 
+    if constexpr (kFusedLand == 2 && !BORDERTILE && L1 == 0 && !MASKED && T >= 8) {
+        // Two trips of rows in flight instead of one: a row has 2G march steps to arrive.  The landing registers of
+        // the two trips swap roles from trip to trip, so the trip loop is unrolled by two (PH = which pair lands now).
+        double land2[G][4];                             // the other landing pair (`land` is pair 0)
+        int landm2[G][2];
+#pragma unroll
+        for (int i = 0; i < G; ++i) {
+            fused_load_row<COH>(cx, g, base + G + i, land2[i]);
+            if (MASKED) fused_load_mask(cx, g, base + G + i, landm2[i]);
+        }
+#define CCP_FUSED_TRIP(LANDING, LANDINGM, ARRIVED, ARRIVEDM, FB)                                                              \
+        {                                                                                                                     \
+            _Pragma("unroll") for (int i = 0; i < G; ++i) {                                                                   \
+                fused_load_row<COH>(cx, g, (FB) + 2 * G + i, LANDING[i]);                                                     \
+                if (MASKED) fused_load_mask(cx, g, (FB) + 2 * G + i, LANDINGM[i]);                                            \
+            }                                                                                                                 \
+            __builtin_amdgcn_sched_barrier(0);                                                                                \
+            _Pragma("unroll") for (int i = 0; i < G; ++i)                                                                     \
+                fused_step<T, kStepFast, L1, UNR, NT, AN, MASKED, NQ, COH>(wr, wk, br, bk, acc, cx, g, (FB) + i, i, qr, qk);   \
+            _Pragma("unroll") for (int s = 0; s + G < NT; ++s) {                                                              \
+                wr[s] = wr[s + G]; wk[s] = wk[s + G]; br[s] = br[s + G]; bk[s] = bk[s + G];                                   \
+                if (MASKED) { qr[s] = qr[s + G]; qk[s] = qk[s + G]; }                                                         \
+            }                                                                                                                 \
+            _Pragma("unroll") for (int i = 0; i < G; ++i) {                                                                   \
+                const int s0 = Win::slot(i, 0);                                                                               \
+                wr[s0] = ARRIVED[i][0]; wk[s0] = ARRIVED[i][1]; br[s0] = ARRIVED[i][2] * 0.25; bk[s0] = ARRIVED[i][3] * 0.25;  \
+                if (MASKED) { qr[s0] = ARRIVEDM[i][0] ? 0.25 : 0.0; qk[s0] = ARRIVEDM[i][1] ? 0.25 : 0.0; }                    \
+            }                                                                                                                 \
+        }
+        for (int fb = base; fb <= f_end; fb += 2 * G) {
+            CCP_FUSED_TRIP(land, landm, land2, landm2, fb)
+            if (fb + G > f_end) break;
+            CCP_FUSED_TRIP(land2, landm2, land, landm, fb + G)
+        }
+#undef CCP_FUSED_TRIP
+        return;
+    }
     for (int fb = base; fb <= f_end; fb += G) {
 #pragma unroll
         for (int i = 0; i < G; ++i) {
