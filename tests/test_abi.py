@@ -74,3 +74,16 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "ccp_oracle" not in text and "orc_" not in text, f
+
+
+def test_header_is_plain_c_and_cxx(tmp_path):
+    """include/ccp_gs.h is the whole boundary: it must compile on its own as C11 and as C++17 (no torch, no HIP types)."""
+    import shutil
+    import subprocess
+    hdr = os.path.join(ROOT, "include", "ccp_gs.h")
+    for cc, std, lang in (("gcc", "-std=c11", "c"), ("g++", "-std=c++17", "c++")):
+        if shutil.which(cc) is None:
+            pytest.skip(f"no {cc}")
+        src = tmp_path / f"use_header.{ 'c' if lang == 'c' else 'cc'}"
+        src.write_text('#include "ccp_gs.h"\nint main(void) { return ccp_abi_version() == 0; }\n')
+        subprocess.check_call([cc, std, "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I", os.path.dirname(hdr), str(src)])
