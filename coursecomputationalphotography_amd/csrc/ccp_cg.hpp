@@ -233,10 +233,14 @@ int cg_solve_fused(Spmv &&spmv, Apply &&apply, const double *b, double *x, doubl
 // `spmv_dot(in, out)` does the same and leaves block partials of in'(A in) in `partial`,
 // returning how many (0 = not fused: a separate dot pass runs).
 // x: initial guess on entry, solution on exit.  r, p, ap: scratch vectors of n doubles.
-template <typename Spmv, typename SpmvDot>
+// `sums(partial, &count, &sum_at)` is called after every kernel that left `count` block partials of a dot product in
+// `partial` and before the kernel that adds them up: a row block of a distributed matrix adds its partials up itself,
+// all-reduces the one value over the ranks and returns where it is, with count = 1 (ccp_csr.hip); the one-GPU callers
+// pass nothing.
+template <typename Spmv, typename SpmvDot, typename Sums>
 int cg_solve(Spmv &&spmv, SpmvDot &&spmv_dot, const double *b, double *x, double *r, double *p, double *ap, long n, double epsilon,
              int max_iteration, CgState *st_dev, double *partial, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
-             ccp_gs_report *report)
+             ccp_gs_report *report, Sums &&sums, bool every_rank_iterates = false)
 {
     const int blocks = (int)std::max<long>(1, std::min<long>(2048, (n + kBlock - 1) / kBlock));
     CgState host{};
@@ -245,10 +249,13 @@ int cg_solve(Spmv &&spmv, SpmvDot &&spmv_dot, const double *b, double *x, double
     CCP_HIP(hipEventRecord(ev0, stream));
     CCP_TRY(spmv(x, r));                                                     // r = A x      (:406)
     hipLaunchKernelGGL(k_cg_init, dim3(blocks), dim3(kBlock), 0, stream, b, r, p, n, partial);   // r = b - r, p = r
-    hipLaunchKernelGGL(k_cg_set_rlen, dim3(1), dim3(kBlock), 0, stream, partial, blocks, st_dev);
+    int count = blocks;
+    const double *sum_at = partial;
+    CCP_TRY(sums(partial, &count, &sum_at));
+    hipLaunchKernelGGL(k_cg_set_rlen, dim3(1), dim3(kBlock), 0, stream, sum_at, count, st_dev);
     CCP_HIP(hipGetLastError());
     int issued = 0;
-    bool active = max_iteration > 0 && n > 0;
+    bool active = max_iteration > 0 && (n > 0 || every_rank_iterates);
     while (active && issued < max_iteration) {
         const int batch = std::min(16, max_iteration - issued);
         for (int k = 0; k < batch; ++k) {
@@ -258,9 +265,14 @@ int cg_solve(Spmv &&spmv, SpmvDot &&spmv_dot, const double *b, double *x, double
                 hipLaunchKernelGGL(k_cg_dot, dim3(blocks), dim3(kBlock), 0, stream, p, ap, n, partial, st_dev);
                 dot_blocks = blocks;
             }
-            hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kBlock), 0, stream, partial, dot_blocks, st_dev);
+            sum_at = partial;
+            CCP_TRY(sums(partial, &dot_blocks, &sum_at));
+            hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kBlock), 0, stream, sum_at, dot_blocks, st_dev);
             hipLaunchKernelGGL(k_cg_update, dim3(blocks), dim3(kBlock), 0, stream, x, p, r, ap, n, partial, st_dev);
-            hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(kBlock), 0, stream, partial, blocks, epsilon, st_dev);
+            count = blocks;
+            sum_at = partial;
+            CCP_TRY(sums(partial, &count, &sum_at));
+            hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(kBlock), 0, stream, sum_at, count, epsilon, st_dev);
             hipLaunchKernelGGL(k_cg_direction, dim3(blocks), dim3(kBlock), 0, stream, p, r, n, st_dev);
         }
         CCP_HIP(hipGetLastError());
@@ -281,6 +293,15 @@ int cg_solve(Spmv &&spmv, SpmvDot &&spmv_dot, const double *b, double *x, double
         report->seconds = ms * 1e-3;
     }
     return CCP_OK;
+}
+
+template <typename Spmv, typename SpmvDot>
+int cg_solve(Spmv &&spmv, SpmvDot &&spmv_dot, const double *b, double *x, double *r, double *p, double *ap, long n, double epsilon,
+             int max_iteration, CgState *st_dev, double *partial, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
+             ccp_gs_report *report)
+{
+    return cg_solve(spmv, spmv_dot, b, x, r, p, ap, n, epsilon, max_iteration, st_dev, partial, stream, ev0, ev1, report,
+                    [](double *, int *, const double **) { return (int)CCP_OK; });
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -2551,9 +2551,9 @@ int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, 
 try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
-    if (m->rb.on) return CCP_ERR_UNSUPPORTED;      // (row blocks: the Gauss-Seidel sweep, b := A x and the residual)
     CCP_TRY(flush_edits(m));
-    if (!b || !x_out) return CCP_ERR_BAD_ARG;
+    const bool rowblock = m->rb.on;
+    if ((!b || !x_out) && !(rowblock && m->rb.n_local == 0)) return CCP_ERR_BAD_ARG;
     if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;
     if (m->allow_structured) {
         // SolveChannel's matrix at the unchanged call site (PhotoMontage.cpp:613): matrix-free SpMV of the
@@ -2583,7 +2583,14 @@ try {
     }
     const unsigned spmv_blocks = (unsigned)((m->natural.n_slices + kBlock / kWave - 1) / (kBlock / kWave));
     CCP_TRY(ensure_partial(m, std::max<long>(2048, spmv_blocks)));
-    if (n) {
+    if (rowblock) {
+        // b, init, x_out: the block's own rows.  The loop runs on the extended system: a ghost is an empty row, so its
+        // entries of A p and r are zero and take no part in the dot products; its entry of the vector A is applied to
+        // comes from its owner before every product, and every dot product is added up over the ranks.
+        CCP_TRY(rb_stage(m, m->b.p, b));
+        if (init) CCP_TRY(rb_stage(m, m->x.p, init));
+        else CCP_HIP(hipMemsetAsync(m->x.p, 0, sizeof(double) * (size_t)std::max<long>(n, 1), s));
+    } else if (n) {
         CCP_HIP(hipMemcpyAsync(m->b.p, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
         if (init) CCP_HIP(hipMemcpyAsync(m->x.p, init, sizeof(double) * n, hipMemcpyHostToDevice, s));
         else CCP_HIP(hipMemsetAsync(m->x.p, 0, sizeof(double) * n, s));                 // sparse-matrix.h:397
@@ -2591,17 +2598,37 @@ try {
     const SellView view = m->natural.view();
     const int n_slices = m->natural.n_slices;
     auto spmv = [&](const double *in, double *out) -> int {
+        if (rowblock) CCP_TRY(rb_exchange_natural(m, const_cast<double *>(in)));
         if (n_slices == 0) return CCP_OK;
         hipLaunchKernelGGL((k_sell_apply<0>), dim3(spmv_blocks), dim3(kBlock), 0, s, view, n_slices, in, out, in, m->partial.p);
         return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
     };
     auto spmv_dot = [&](const double *in, double *out, int *n_partials) -> int {
         *n_partials = 0;
+        if (rowblock) CCP_TRY(rb_exchange_natural(m, const_cast<double *>(in)));
         if (n_slices == 0) return CCP_OK;
         hipLaunchKernelGGL((k_sell_apply<2>), dim3(spmv_blocks), dim3(kBlock), 0, s, view, n_slices, in, out, in, m->partial.p);
         *n_partials = (int)spmv_blocks;
         return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
     };
+    if (rowblock) {
+        const RcclApi *api = rccl_api();
+        if (!api) return CCP_ERR_RCCL;
+        double *total = reinterpret_cast<double *>(m->rb.comm->scratch.p);     // (the communicator's own scratch words)
+        auto sums = [&](double *partial, int *count, const double **sum_at) -> int {
+            hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, partial, (long)*count, 1L, total, 0);
+            CCP_HIP(hipGetLastError());
+            CCP_RCCL(api->AllReduce(total, total, 1, ncclDouble, ncclSum, m->rb.comm->comm, s));
+            *count = 1;
+            *sum_at = total;
+            return CCP_OK;
+        };
+        CCP_TRY(cg_solve(spmv, spmv_dot, m->b.p, m->x.p, m->tmp.p, m->cg_p.p, m->cg_ap.p, n, epsilon, max_iteration, m->cg_state.p,
+                         m->partial.p, s, m->ev0, m->ev1, report, sums, true));
+        if (m->rb.n_local) CCP_HIP(hipMemcpyAsync(x_out, m->x.p + m->rb.n_lo, sizeof(double) * (size_t)m->rb.n_local, hipMemcpyDeviceToHost, s));
+        CCP_HIP(hipStreamSynchronize(s));
+        return CCP_OK;
+    }
     CCP_TRY(cg_solve(spmv, spmv_dot, m->b.p, m->x.p, m->tmp.p, m->cg_p.p, m->cg_ap.p, n, epsilon, max_iteration, m->cg_state.p,
                      m->partial.p, s, m->ev0, m->ev1, report));
     if (n) CCP_HIP(hipMemcpyAsync(x_out, m->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));

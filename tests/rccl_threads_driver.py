@@ -308,6 +308,9 @@ def case_csr_rows(c):
     want, rep_w = whole.gauss_seidel(b, eps, iters, x0, check_every=1 if eps > 0 else 0)
     y_w = whole.apply_to_vector(xt)
     rr_w, bb_w = whole.residual_norm2(b, want)
+    cg = c.get("cg")                                  # [epsilon, max_iteration]: conjugateGradient (sparse-matrix.h:396-434) as well
+    if cg:
+        cg_w, cg_rep_w = whole.conjugate_gradient(b, cg[0], cg[1], init=x0)
     whole.close()
     orc = oracle.Oracle()
     want_o, it_o, _ = orc.multicolour_gauss_seidel(v, col, rowp, colour, b, eps, iters, x0=x0)
@@ -325,10 +328,14 @@ def case_csr_rows(c):
         y = m.apply_to_vector(xt[lo:hi])
         rr, bb = m.residual_norm2(b[lo:hi], x)
         own_colour, own_nc = m.get_colouring()
-        info = m.rows_info()
         unsupported = []
+        cg_out = None
+        if cg:
+            xc, rc = m.conjugate_gradient(b[lo:hi], cg[0], cg[1], init=None if x0 is None else x0[lo:hi])
+            cg_out = (xc, rc.converged, rc.iterations, rc.last_l1_step)
+        info = m.rows_info()
         for what, fn in (("lexicographic", lambda: m.gauss_seidel(b[lo:hi], 0.0, 1, ordering=capi.ORDER_LEXICOGRAPHIC)),
-                         ("cg", lambda: m.conjugate_gradient(b[lo:hi], 1e-9, 3)), ("insert", lambda: m.insert(1.0, 0, 0))):
+                         ("cg_jacobi", lambda: m.conjugate_gradient_jacobi(b[lo:hi], 1e-9, 3)), ("insert", lambda: m.insert(1.0, 0, 0))):
             try:
                 fn()
                 unsupported.append((what, 0))
@@ -336,7 +343,7 @@ def case_csr_rows(c):
                 unsupported.append((what, e.status))
         path = m.last_path()
         m.close()
-        return x, (rep.converged, rep.iterations, rep.last_l1_step), y, rr, bb, info, bool(np.array_equal(own_colour, colour[lo:hi]) and own_nc == nc), unsupported, path
+        return x, (rep.converged, rep.iterations, rep.last_l1_step), y, rr, bb, info, bool(np.array_equal(own_colour, colour[lo:hi]) and own_nc == nc), unsupported, path, cg_out
 
     out, err = run_ranks(world, rank_fn)
     os.environ.pop("CCP_GS_MASKED", None)
@@ -347,7 +354,13 @@ def case_csr_rows(c):
     got = np.concatenate([o[0] for o in out])
     y = np.concatenate([o[2] for o in out])
     ghosts = [o[5]["n_ghost"] for o in out]
-    return {"ok": True, "n": n, "colours": nc, "cuts": cuts,
+    cg_res = {}
+    if cg:
+        xc = np.concatenate([o[9][0] for o in out])
+        cg_res = {"cg_rel_diff": float(np.linalg.norm(xc - cg_w) / np.linalg.norm(cg_w)), "cg_iterations_one_gpu": cg_rep_w.iterations,
+                  "cg_converged_one_gpu": cg_rep_w.converged, "cg_iterations_ranks": [o[9][2] for o in out], "cg_converged_ranks": [o[9][1] for o in out],
+                  "cg_rnorm_ranks": [o[9][3] for o in out], "cg_rnorm_one_gpu": cg_rep_w.last_l1_step}
+    return {"ok": True, "n": n, "colours": nc, "cuts": cuts, **cg_res,
             "bit_identical_to_one_gpu": bool(np.array_equal(got, want)),
             "bit_identical_to_oracle": bool(np.array_equal(got, want_o)),
             "spmv_bit_identical": bool(np.array_equal(y, y_w)),

@@ -154,9 +154,9 @@ def test_cpp_host_runs_every_rank_as_a_thread(fake_env, tmp_path, world):
 # ---- row blocks of a general CSR matrix: ccp_csr_upload_rows (BASELINE configs[4] on several GPUs) ----------
 CSR_ROWS = [
     # the region matrix of configs[4] in small, unknowns in raster order: blocks talk to their neighbours only
-    {"matrix": "mask", "W": 320, "H": 240, "world": 2, "iters": 12},
-    {"matrix": "mask", "W": 400, "H": 300, "world": 3, "iters": 9, "x0": True, "slack": 3, "cuts": [0, 0.21, 0.77, 1.0]},
-    {"matrix": "mask", "W": 512, "H": 384, "world": 4, "iters": 7, "cuts": [0, 0.5, 0.5, 0.8, 1.0]},       # an EMPTY block
+    {"matrix": "mask", "W": 320, "H": 240, "world": 2, "iters": 12, "cg": [1e-30, 25]},
+    {"matrix": "mask", "W": 400, "H": 300, "world": 3, "iters": 9, "x0": True, "slack": 3, "cuts": [0, 0.21, 0.77, 1.0], "cg": [1e-3, 4000]},
+    {"matrix": "mask", "W": 512, "H": 384, "world": 4, "iters": 7, "cuts": [0, 0.5, 0.5, 0.8, 1.0], "cg": [1e-30, 30]},       # an EMPTY block
     # random symmetric pattern, the library's greedy colouring (several colours), every block coupled to every other
     {"matrix": "random", "n": 5000, "deg": 3, "world": 3, "iters": 6, "x0": True},
     {"matrix": "random", "n": 3001, "deg": 2, "world": 4, "iters": 5, "empty_rows": True, "slack": 1},
@@ -174,7 +174,14 @@ def test_csr_row_blocks_sweep_the_one_gpu_iterates(fake_env):
         assert r["iterations_ranks"] == [c["iters"]] * c["world"], r
         assert r["own_colours_ok"], c
         assert all(p == "sliced ELL" for p in r["path"]), r["path"]
-        # the reference-order sweep, conjugate gradient and insert do not shard: CCP_ERR_UNSUPPORTED (6) on every rank
+        if "cg" in c:
+            # conjugateGradient on the blocks: the dot products are added up over the ranks in another order than on one
+            # GPU, so the iterates agree to rounding; a solve that stops stops at the same iteration on every rank
+            assert r["cg_rel_diff"] < 1e-9, r
+            assert len(set(r["cg_iterations_ranks"])) == 1 and len(set(r["cg_rnorm_ranks"])) == 1, r
+            assert r["cg_converged_ranks"] == [r["cg_converged_one_gpu"]] * c["world"], r
+            assert abs(r["cg_iterations_ranks"][0] - r["cg_iterations_one_gpu"]) <= (1 if r["cg_converged_one_gpu"] else 0), r
+        # the reference-order sweep, the Jacobi-preconditioned loop and insert do not shard: CCP_ERR_UNSUPPORTED (6) on every rank
         assert all(st == 6 for rank in r["unsupported"] for _, st in rank), r["unsupported"]
         # the messages went through the transport: every value sent was received, 8 bytes each, plus the halo index
         # lists and colours of the set-up (4 bytes each way per ghost)
