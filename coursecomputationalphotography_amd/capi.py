@@ -37,7 +37,7 @@ ABI_SYMBOLS = (
     "ccp_grid_set_x_u8", "ccp_grid_last_timing", "ccp_grid_region_begin", "ccp_grid_region_end",
     "ccp_comm_probe", "ccp_comm_unique_id", "ccp_comm_create", "ccp_comm_destroy", "ccp_comm_info", "ccp_comm_all_reduce_sum", "ccp_comm_all_reduce_max",
     "ccp_grid_attach_comm", "ccp_grid_set_overlap", "ccp_grid_exchange_halos", "ccp_grid_sweep_rowblocked",
-    "ccp_grid_gauss_seidel_rowblocked", "ccp_grid_residual_norm2_global", "ccp_grid_comm_stats",
+    "ccp_grid_gauss_seidel_rowblocked", "ccp_grid_conjugate_gradient_rowblocked", "ccp_grid_residual_norm2_global", "ccp_grid_comm_stats",
 )
 
 
@@ -201,6 +201,7 @@ def load() -> C.CDLL:
     L.ccp_grid_exchange_halos.argtypes = [vp]
     L.ccp_grid_sweep_rowblocked.argtypes = [vp, i32]
     L.ccp_grid_gauss_seidel_rowblocked.argtypes = [vp, dbl, i32, i32, C.POINTER(Report)]
+    L.ccp_grid_conjugate_gradient_rowblocked.argtypes = [vp, dbl, i32, C.POINTER(Report)]
     L.ccp_grid_residual_norm2_global.argtypes = [vp, vp]
     L.ccp_grid_comm_stats.argtypes = [vp, C.POINTER(i64), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
     _lib = L
@@ -649,6 +650,11 @@ class Grid:
         reps = (Report * self.C)()
         check(self.L.ccp_grid_gauss_seidel_rowblocked(self.h, epsilon, max_iteration, check_every, reps),
               "ccp_grid_gauss_seidel_rowblocked")
+        return list(reps)
+
+    def conjugate_gradient_rowblocked(self, epsilon=1e-16, max_iteration=1000):
+        reps = (Report * self.C)()
+        check(self.L.ccp_grid_conjugate_gradient_rowblocked(self.h, epsilon, max_iteration, reps), "ccp_grid_conjugate_gradient_rowblocked")
         return list(reps)
 
     def residual_norm2_global(self):

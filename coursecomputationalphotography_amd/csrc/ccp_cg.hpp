@@ -66,6 +66,15 @@ __device__ __forceinline__ double reduce_partials(const double *__restrict__ par
     return block_sum(acc, scratch);
 }
 
+// out[0] = the partials added up in the fixed order (what a row block all-reduces over its communicator)
+static __global__ void __launch_bounds__(kBlock)
+k_reduce_to_one(const double *__restrict__ partial, long count, double *__restrict__ out)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const double t = reduce_partials(partial, (int)count, scratch);
+    if (threadIdx.x == 0) out[0] = t;
+}
+
 static __global__ void __launch_bounds__(kBlock)
 k_cg_set_rlen(const double *__restrict__ partial, int count, CgState *__restrict__ st)
 {

@@ -2143,6 +2143,84 @@ try {
     return CCP_OK;
 } CCP_ABI_CATCH
 
+// conjugateGradient (sparse-matrix.h:396-434) on a row block: the three-vector loop of ccp_cg.hpp on the OWNED rows (one
+// contiguous range of the planes), A applied to the owned rows with the direction's row above and below them fetched from
+// the neighbours before every product (one image row per neighbour), every dot product all-reduced.
+int ccp_grid_conjugate_gradient_rowblocked(ccp_grid *g, double epsilon, int32_t max_iteration, ccp_gs_report *report)
+try {
+    CCP_TRY(bind(g));
+    if (!g->comm) return CCP_ERR_STATE;
+    if (max_iteration < 0) return CCP_ERR_BAD_ARG;
+    const RcclApi *api = rccl_api();
+    if (!api) return CCP_ERR_RCCL;
+    const Geom &geo = g->geom;
+    if ((g->up_rank >= 0 && g->ghost_top < 1) || (g->down_rank >= 0 && g->ghost_bottom < 1)) return CCP_ERR_STATE;
+    const long n = geo.ch_stride;
+    const size_t row = (size_t)2 * geo.pitch;
+    const long off = (long)geo.own_lo * (long)row, n_own = (long)(geo.own_hi - geo.own_lo) * (long)row;
+    if (!g->cg_r.p) {
+        CCP_TRY(g->cg_r.alloc((size_t)n));
+        CCP_TRY(g->cg_p.alloc((size_t)n));
+        CCP_TRY(g->cg_p2.alloc((size_t)n));
+        CCP_TRY(g->cg_ap.alloc((size_t)n));
+        CCP_TRY(g->cg_state.alloc(1));
+    }
+    hipStream_t s = g->stream;
+    dim3 grid((unsigned)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)), (unsigned)(geo.own_hi - geo.own_lo), 2);
+    // one row of `plane` to each neighbour's ghost row next to its owned rows, theirs into ours
+    auto fetch_rows = [&](double *plane) -> int {
+        if (g->up_rank < 0 && g->down_rank < 0) return CCP_OK;
+        CCP_RCCL(api->GroupStart());
+        ncclResult_t r = ncclSuccess;
+        if (g->up_rank >= 0) {
+            r = api->Send(plane + (size_t)geo.own_lo * row, row, ncclDouble, g->up_rank, g->comm->comm, s);
+            if (r == ncclSuccess) r = api->Recv(plane + (size_t)(geo.own_lo - 1) * row, row, ncclDouble, g->up_rank, g->comm->comm, s);
+        }
+        if (g->down_rank >= 0 && r == ncclSuccess) {
+            r = api->Send(plane + (size_t)(geo.own_hi - 1) * row, row, ncclDouble, g->down_rank, g->comm->comm, s);
+            if (r == ncclSuccess) r = api->Recv(plane + (size_t)geo.own_hi * row, row, ncclDouble, g->down_rank, g->comm->comm, s);
+        }
+        const ncclResult_t e = api->GroupEnd();
+        if (r != ncclSuccess) return rccl_fail(r, "ncclSend/ncclRecv", __FILE__, __LINE__);
+        CCP_RCCL(e);
+        g->exchanges++;
+        return CCP_OK;
+    };
+    double *total = reinterpret_cast<double *>(g->comm->scratch.p);
+    auto sums = [&](double *partial, int *count, const double **sum_at) -> int {
+        hipLaunchKernelGGL(k_reduce_to_one, dim3(1), dim3(kBlock), 0, s, partial, (long)*count, total);
+        CCP_HIP(hipGetLastError());
+        CCP_RCCL(api->AllReduce(total, total, 1, ncclDouble, ncclSum, g->comm->comm, s));
+        *count = 1;
+        *sum_at = total;
+        return CCP_OK;
+    };
+    for (int ch = 0; ch < g->desc.channels; ++ch) {
+        CCP_HIP(hipMemsetAsync(g->cg_r.p, 0, sizeof(double) * n, s));
+        CCP_HIP(hipMemsetAsync(g->cg_p.p, 0, sizeof(double) * n, s));
+        CCP_HIP(hipMemsetAsync(g->cg_ap.p, 0, sizeof(double) * n, s));
+        // the loop sees the owned range of every vector; the product goes back to the planes' bases
+        auto spmv = [&](const double *in_own, double *out_own) -> int {
+            double *in = const_cast<double *>(in_own) - off;
+            double *out = out_own - off;
+            CCP_TRY(fetch_rows(in));
+            if (g->masked) hipLaunchKernelGGL((k_apply<2, 0, true>), grid, dim3(kBlock), 0, s, in, out, out, geo, geo.own_lo, g->partial.p, g->maskp.p);
+            else hipLaunchKernelGGL((k_apply<2, 0>), grid, dim3(kBlock), 0, s, in, out, out, geo, geo.own_lo, g->partial.p, static_cast<const unsigned char *>(nullptr));
+            return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
+        };
+        auto spmv_dot = [&](const double *in_own, double *out_own, int *n_partials) -> int {
+            *n_partials = 0;                             // (the loop runs its own dot pass over the owned range)
+            return spmv(in_own, out_own);
+        };
+        CCP_TRY(cg_solve(spmv, spmv_dot, g->b.p + (long)ch * n + off, g->x.p + (long)ch * n + off, g->cg_r.p + off, g->cg_p.p + off,
+                         g->cg_ap.p + off, n_own, epsilon, max_iteration, g->cg_state.p, g->partial.p, s, g->ev0, g->ev1,
+                         report ? report + ch : nullptr, sums, true));
+    }
+    // the ghost rows of x are stale now: the next sweep needs an exchange first
+    g->half_sweeps_since_refresh = g->desc.ghost;
+    return edge_timeout_status(g);
+} CCP_ABI_CATCH
+
 int ccp_grid_comm_stats(ccp_grid *g, int64_t *exchanges, int32_t *wait_mode, int32_t *send_up_rows, int32_t *send_down_rows)
 try {
     if (!g) return CCP_ERR_BAD_ARG;

@@ -378,6 +378,13 @@ int ccp_grid_sweep_rowblocked(ccp_grid *g, int32_t iterations);
  * report carries the sweep at which ITS rule fired first). */
 int ccp_grid_gauss_seidel_rowblocked(ccp_grid *g, double epsilon, int32_t max_iteration, int32_t check_every,
                                      ccp_gs_report *report);
+/* SparseMatrix::conjugateGradient (sparse-matrix.h:396-434; the solver the blend call sites use) on the partitioned
+ * system, from the x the blocks hold: every rank runs the loop on its owned rows; before every product with A the
+ * direction's rows next to the block come from the neighbours (one image row each way), every dot product is
+ * all-reduced.  Iterates equal the one-block loop's to rounding; a solve that stops stops at the same iteration on
+ * every rank.  Needs ghost >= 1; works for Dirichlet-mask grids too.  Afterwards the ghost rows of x are stale (the
+ * next rowblocked sweep refreshes them).  report: one per channel, as ccp_grid_conjugate_gradient.  Collective. */
+int ccp_grid_conjugate_gradient_rowblocked(ccp_grid *g, double epsilon, int32_t max_iteration, ccp_gs_report *report);
 /* ccp_grid_residual_norm2 summed over all blocks (refreshes stale ghost rows first).  Collective. */
 int ccp_grid_residual_norm2_global(ccp_grid *g, double *rr_bb);
 /* Statistics: exchanges issued; how the exchange waits for the edge rows (0 hipStreamWaitValue64, 1 polling

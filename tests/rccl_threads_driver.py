@@ -171,6 +171,57 @@ def case_stop_rule(c):
             "last_channel_bit_identical": bool(np.array_equal(got_last, want[last]))}
 
 
+def case_grid_cg(c):
+    """conjugateGradient on row blocks of the grid (plain or Dirichlet-mask): iterates equal the one-block loop's to rounding,
+    the same stop iteration on every rank."""
+    W, H, C_, world, ghost = c["W"], c["H"], c.get("C", 1), c["world"], c["ghost"]
+    eps, iters = c["eps"], c["iters"]
+    mask = region_mask(c)
+    os.environ["CCP_GS_CG_FUSED"] = "0"                    # the one-block comparison on the same three-vector loop
+    whole = capi.Grid(W, H, C_, mask=mask)
+    system(whole)
+    whole.fill_x(0.0)
+    reps_w = whole.conjugate_gradient(eps, iters)
+    want = np.stack([whole.get_x(ch) for ch in range(C_)])
+    whole.close()
+    os.environ.pop("CCP_GS_CG_FUSED", None)
+    parts = rowblock.partition_rows(H, world)
+
+    def rank_fn(rank, comm):
+        rb, rc = parts[rank]
+        g = capi.Grid(W, H, C_, rb, rc, ghost, 0, mask=mask)
+        system(g)
+        g.fill_x(0.0)
+        g.attach_comm(comm)
+        reps = g.conjugate_gradient_rowblocked(eps, iters)
+        owned = np.stack([g.get_x_owned(ch) for ch in range(C_)])
+        # a sweep after the solve must refresh the ghost rows by itself
+        g.sweep_rowblocked(2)
+        after = np.stack([g.get_x_owned(ch) for ch in range(C_)])
+        res = [(r.converged, r.iterations, r.last_l1_step) for r in reps]
+        g.attach_comm(None)
+        g.close()
+        return owned, res, after
+
+    out, err = run_ranks(world, rank_fn)
+    if any(err):
+        return {"ok": False, "error": [repr(e) for e in err]}
+    got = np.concatenate([o[0] for o in out], axis=1)
+    after = np.concatenate([o[2] for o in out], axis=1)
+    ref = capi.Grid(W, H, C_, mask=mask)
+    system(ref)
+    for ch in range(C_):
+        ref.set_x(got[ch], ch)
+    ref.sweep(2)
+    after_w = np.stack([ref.get_x(ch) for ch in range(C_)])
+    ref.close()
+    return {"ok": True, "rel_diff": float(np.linalg.norm(got - want) / np.linalg.norm(want)),
+            "iterations_one_block": [r.iterations for r in reps_w], "converged_one_block": [r.converged for r in reps_w],
+            "iterations_ranks": [[t[1] for t in o[1]] for o in out], "converged_ranks": [[t[0] for t in o[1]] for o in out],
+            "rnorm_ranks": [[t[2] for t in o[1]] for o in out], "rnorm_one_block": [r.last_l1_step for r in reps_w],
+            "sweep_after_solve_bit_identical": bool(np.array_equal(after, after_w))}
+
+
 def case_bad_partition(c):
     """A partition that is not the rank-ordered contiguous row blocks of one image is refused on EVERY rank."""
     W, H, world, ghost = c["W"], c["H"], c["world"], c["ghost"]
@@ -417,7 +468,7 @@ def case_csr_rows_refused(c):
     return {"ok": True, "status": [o[0] for o in out], "solve_after": [o[1] for o in out]}
 
 
-CASES = {"csr_rows": case_csr_rows, "csr_rows_refused": case_csr_rows_refused, "late_flag": case_late_flag, "sweep": case_sweep, "stop_rule": case_stop_rule, "bad_partition": case_bad_partition}
+CASES = {"grid_cg": case_grid_cg, "csr_rows": case_csr_rows, "csr_rows_refused": case_csr_rows_refused, "late_flag": case_late_flag, "sweep": case_sweep, "stop_rule": case_stop_rule, "bad_partition": case_bad_partition}
 
 
 def main():

@@ -223,3 +223,24 @@ def test_csr_row_blocks_refuse_together(fake_env):
     assert res[1]["status"] == [1, 1, 1], res[1]              # the partition check is all-gathered: CCP_ERR_BAD_ARG everywhere
     assert res[2]["status"][0] == 1, res[2]                   # the rank with the bad column reports its own error
     assert res[3]["ok"] and res[3]["status"] == [0, 0, 0] and res[3]["solve_after"] == [None] * 3, res[3]
+
+
+def test_grid_conjugate_gradient_on_row_blocks(fake_env):
+    """ccp_grid_conjugate_gradient_rowblocked — the solver the blend call sites use (PhotoMontage.cpp:613) — on 2-4 blocks,
+    plain and Dirichlet-mask grids: the one-block iterates to rounding, the same stop iteration everywhere, and a sweep
+    after the solve refreshes its ghost rows by itself."""
+    cases = [
+        {"kind": "grid_cg", "world": 2, "W": 300, "H": 200, "C": 1, "ghost": 8, "eps": 1e-30, "iters": 30},
+        {"kind": "grid_cg", "world": 3, "W": 513, "H": 300, "C": 2, "ghost": 2, "eps": 1e-30, "iters": 25},
+        {"kind": "grid_cg", "world": 4, "W": 640, "H": 480, "C": 1, "ghost": 4, "eps": 1e-3, "iters": 5000, "mask": True, "discs": 30},
+        {"kind": "grid_cg", "world": 2, "W": 400, "H": 300, "C": 1, "ghost": 16, "eps": 1e-30, "iters": 40, "mask": True},
+    ]
+    for r in drive(fake_env, cases):
+        c = r["case"]
+        assert r["ok"], r
+        assert r["rel_diff"] < 1e-9, r
+        for ranks_it, ranks_conv in zip(r["iterations_ranks"], r["converged_ranks"]):
+            assert ranks_it == r["iterations_ranks"][0] and ranks_conv == r["converged_ranks"][0], r
+        assert r["converged_ranks"][0] == r["converged_one_block"], r
+        assert all(abs(a - b) <= (1 if cv else 0) for a, b, cv in zip(r["iterations_ranks"][0], r["iterations_one_block"], r["converged_one_block"])), r
+        assert r["sweep_after_solve_bit_identical"], c
