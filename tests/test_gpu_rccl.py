@@ -216,6 +216,21 @@ def test_world1_csr_row_block_and_mask_grid_through_real_rccl(capi, monkeypatch)
     ref.sweep(17)
     g.sweep_rowblocked(17)
     assert np.array_equal(g.get_x(0), ref.get_x(0))
+    # conjugate gradient through the real all-reduce (one rank): the one-block three-vector loop's iterates
+    monkeypatch.setenv("CCP_GS_CG_FUSED", "0")
+    for h in (ref, g):
+        h.fill_x(0.0)
+    want_rep = ref.conjugate_gradient(1e-30, 20)[0]
+    got_rep = g.conjugate_gradient_rowblocked(1e-30, 20)[0]
+    assert (got_rep.iterations, got_rep.converged) == (want_rep.iterations, want_rep.converged) == (20, 0)
+    assert np.allclose(g.get_x(0), ref.get_x(0), rtol=1e-11, atol=1e-9)
+    blk2 = capi.CsrMatrix().upload_rows(comm, 0, n, v, col, rowp[:-1], np.diff(rowp), colour, 2)
+    one2 = capi.CsrMatrix().upload_compressed(v, col, rowp)
+    xa, ra = blk2.conjugate_gradient(b, 1e-30, 20)
+    xb, rb_ = one2.conjugate_gradient(b, 1e-30, 20)
+    assert ra.iterations == rb_.iterations == 20 and np.allclose(xa, xb, rtol=1e-11, atol=1e-9)
+    blk2.close()
+    one2.close()
     g.attach_comm(None)
     g.close()
     ref.close()
