@@ -182,6 +182,9 @@ int ccp_csr_residual_norm2(ccp_csr *m, const double *b, const double *x, double 
  *   ccp_csr_get_colouring   the block's own rows.
  * The reference-order sweep, ccp_csr_conjugate_gradient_jacobi, ccp_csr_insert and ccp_csr_set_colouring return
  * CCP_ERR_UNSUPPORTED on a row block.  ccp_csr_upload returns the handle to the one-GPU form.
+ * `comm` must stay alive for as long as the handle is used as a row block.  What the ranks agree on are refused
+ * ARGUMENTS; a HIP or RCCL failure in the middle of a collective call (CCP_ERR_HIP / CCP_ERR_RCCL) is local to the rank
+ * it happens on — treat it as fatal for the communicator, as with any RCCL error.
  * The sweep overlaps the messages with arithmetic: per colour the 64-row slices that hold a row some peer
  * references are swept first and their values travel on a second stream while the other slices of the colour
  * are swept (off when those slices are more than a quarter of the block, or with CCP_GS_ROWS_OVERLAP=0).
