@@ -242,10 +242,10 @@ int cg_solve_fused(Spmv &&spmv, Apply &&apply, const double *b, double *x, doubl
 // `spmv_dot(in, out)` does the same and leaves block partials of in'(A in) in `partial`,
 // returning how many (0 = not fused: a separate dot pass runs).
 // x: initial guess on entry, solution on exit.  r, p, ap: scratch vectors of n doubles.
-// `sums(partial, &count, &sum_at)` is called after every kernel that left `count` block partials of a dot product in
+// `sums(partial, &count, &sum_at, slot)` is called after every kernel that left `count` block partials of a dot product in
 // `partial` and before the kernel that adds them up: a row block of a distributed matrix adds its partials up itself,
-// all-reduces the one value over the ranks and returns where it is, with count = 1 (ccp_csr.hip); the one-GPU callers
-// pass nothing.
+// all-reduces the one value over the ranks and returns where it is (`slot`: 0 or 1, two sums may be alive at once), with
+// count = 1 (ccp_csr.hip); the one-GPU callers pass nothing.
 template <typename Spmv, typename SpmvDot, typename Sums>
 int cg_solve(Spmv &&spmv, SpmvDot &&spmv_dot, const double *b, double *x, double *r, double *p, double *ap, long n, double epsilon,
              int max_iteration, CgState *st_dev, double *partial, hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1,
@@ -260,7 +260,7 @@ int cg_solve(Spmv &&spmv, SpmvDot &&spmv_dot, const double *b, double *x, double
     hipLaunchKernelGGL(k_cg_init, dim3(blocks), dim3(kBlock), 0, stream, b, r, p, n, partial);   // r = b - r, p = r
     int count = blocks;
     const double *sum_at = partial;
-    CCP_TRY(sums(partial, &count, &sum_at));
+    CCP_TRY(sums(partial, &count, &sum_at, 0));
     hipLaunchKernelGGL(k_cg_set_rlen, dim3(1), dim3(kBlock), 0, stream, sum_at, count, st_dev);
     CCP_HIP(hipGetLastError());
     int issued = 0;
@@ -275,12 +275,12 @@ int cg_solve(Spmv &&spmv, SpmvDot &&spmv_dot, const double *b, double *x, double
                 dot_blocks = blocks;
             }
             sum_at = partial;
-            CCP_TRY(sums(partial, &dot_blocks, &sum_at));
+            CCP_TRY(sums(partial, &dot_blocks, &sum_at, 0));
             hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kBlock), 0, stream, sum_at, dot_blocks, st_dev);
             hipLaunchKernelGGL(k_cg_update, dim3(blocks), dim3(kBlock), 0, stream, x, p, r, ap, n, partial, st_dev);
             count = blocks;
             sum_at = partial;
-            CCP_TRY(sums(partial, &count, &sum_at));
+            CCP_TRY(sums(partial, &count, &sum_at, 0));
             hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(kBlock), 0, stream, sum_at, count, epsilon, st_dev);
             hipLaunchKernelGGL(k_cg_direction, dim3(blocks), dim3(kBlock), 0, stream, p, r, n, st_dev);
         }
@@ -310,7 +310,7 @@ int cg_solve(Spmv &&spmv, SpmvDot &&spmv_dot, const double *b, double *x, double
              ccp_gs_report *report)
 {
     return cg_solve(spmv, spmv_dot, b, x, r, p, ap, n, epsilon, max_iteration, st_dev, partial, stream, ev0, ev1, report,
-                    [](double *, int *, const double **) { return (int)CCP_OK; });
+                    [](double *, int *, const double **, int) { return (int)CCP_OK; });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -395,10 +395,10 @@ k_pcg_direction(double *__restrict__ p, const double *__restrict__ r, const doub
 }
 
 // x: zeroed by the caller; r: holds b on entry.  partial: 2 * 2048 doubles at least (beyond what spmv_dot uses).
-template <typename SpmvDot>
+template <typename SpmvDot, typename Sums>
 int pcg_solve(SpmvDot &&spmv_dot, double *x, double *r, double *p, double *ap, const double *inv, long n, double epsilon,
               int max_iteration, CgState *st_dev, double *partial, double *partial2, hipStream_t stream, hipEvent_t ev0,
-              hipEvent_t ev1, ccp_gs_report *report)
+              hipEvent_t ev1, ccp_gs_report *report, Sums &&sums, bool every_rank_iterates = false)
 {
     const int blocks = (int)std::max<long>(1, std::min<long>(2048, (n + kBlock - 1) / kBlock));
     CgState host{};
@@ -406,10 +406,13 @@ int pcg_solve(SpmvDot &&spmv_dot, double *x, double *r, double *p, double *ap, c
     CCP_HIP(hipMemcpyAsync(st_dev, &host, sizeof(host), hipMemcpyHostToDevice, stream));
     CCP_HIP(hipEventRecord(ev0, stream));
     hipLaunchKernelGGL(k_pcg_init, dim3(blocks), dim3(kBlock), 0, stream, r, inv, p, n, partial);
-    hipLaunchKernelGGL(k_cg_set_rlen, dim3(1), dim3(kBlock), 0, stream, partial, blocks, st_dev);      // olddist = p'r
+    int count = blocks;
+    const double *sum_at = partial, *sum2_at = partial2;
+    CCP_TRY(sums(partial, &count, &sum_at, 0));
+    hipLaunchKernelGGL(k_cg_set_rlen, dim3(1), dim3(kBlock), 0, stream, sum_at, count, st_dev);      // olddist = p'r
     CCP_HIP(hipGetLastError());
     int issued = 0;
-    bool active = max_iteration > 0 && n > 0;
+    bool active = max_iteration > 0 && (n > 0 || every_rank_iterates);
     while (active && issued < max_iteration) {
         const int batch = std::min(16, max_iteration - issued);
         for (int k = 0; k < batch; ++k) {
@@ -419,10 +422,18 @@ int pcg_solve(SpmvDot &&spmv_dot, double *x, double *r, double *p, double *ap, c
                 hipLaunchKernelGGL(k_cg_dot, dim3(blocks), dim3(kBlock), 0, stream, p, ap, n, partial, st_dev);
                 dot_blocks = blocks;
             }
-            hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kBlock), 0, stream, partial, dot_blocks, st_dev);   // olddist / p'Ap (:517)
+            sum_at = partial;
+            CCP_TRY(sums(partial, &dot_blocks, &sum_at, 0));
+            hipLaunchKernelGGL(k_cg_alpha, dim3(1), dim3(kBlock), 0, stream, sum_at, dot_blocks, st_dev);   // olddist / p'Ap (:517)
             hipLaunchKernelGGL(k_pcg_update, dim3(blocks), dim3(kBlock), 0, stream, x, p, r, ap, inv, n, partial2, partial2 + 2048,
                                st_dev);
-            hipLaunchKernelGGL(k_pcg_beta, dim3(1), dim3(kBlock), 0, stream, partial2, partial2 + 2048, blocks, epsilon, st_dev);
+            count = blocks;
+            int count2 = blocks;
+            sum_at = partial2;
+            sum2_at = partial2 + 2048;
+            CCP_TRY(sums(partial2, &count, &sum_at, 0));
+            CCP_TRY(sums(partial2 + 2048, &count2, &sum2_at, 1));
+            hipLaunchKernelGGL(k_pcg_beta, dim3(1), dim3(kBlock), 0, stream, sum_at, sum2_at, count, epsilon, st_dev);
             hipLaunchKernelGGL(k_pcg_direction, dim3(blocks), dim3(kBlock), 0, stream, p, r, inv, n, st_dev);
         }
         CCP_HIP(hipGetLastError());
@@ -443,6 +454,15 @@ int pcg_solve(SpmvDot &&spmv_dot, double *x, double *r, double *p, double *ap, c
         report->seconds = ms * 1e-3;
     }
     return CCP_OK;
+}
+
+template <typename SpmvDot>
+int pcg_solve(SpmvDot &&spmv_dot, double *x, double *r, double *p, double *ap, const double *inv, long n, double epsilon,
+              int max_iteration, CgState *st_dev, double *partial, double *partial2, hipStream_t stream, hipEvent_t ev0,
+              hipEvent_t ev1, ccp_gs_report *report)
+{
+    return pcg_solve(spmv_dot, x, r, p, ap, inv, n, epsilon, max_iteration, st_dev, partial, partial2, stream, ev0, ev1, report,
+                     [](double *, int *, const double **, int) { return (int)CCP_OK; });
 }
 
 }  // namespace ccp

@@ -2615,12 +2615,12 @@ try {
         const RcclApi *api = rccl_api();
         if (!api) return CCP_ERR_RCCL;
         double *total = reinterpret_cast<double *>(m->rb.comm->scratch.p);     // (the communicator's own scratch words)
-        auto sums = [&](double *partial, int *count, const double **sum_at) -> int {
-            hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, partial, (long)*count, 1L, total, 0);
+        auto sums = [&](double *partial, int *count, const double **sum_at, int slot) -> int {
+            hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, partial, (long)*count, 1L, total + slot, 0);
             CCP_HIP(hipGetLastError());
-            CCP_RCCL(api->AllReduce(total, total, 1, ncclDouble, ncclSum, m->rb.comm->comm, s));
+            CCP_RCCL(api->AllReduce(total + slot, total + slot, 1, ncclDouble, ncclSum, m->rb.comm->comm, s));
             *count = 1;
-            *sum_at = total;
+            *sum_at = total + slot;
             return CCP_OK;
         };
         CCP_TRY(cg_solve(spmv, spmv_dot, m->b.p, m->x.p, m->tmp.p, m->cg_p.p, m->cg_ap.p, n, epsilon, max_iteration, m->cg_state.p,
@@ -2641,9 +2641,9 @@ int ccp_csr_conjugate_gradient_jacobi(ccp_csr *m, const double *b, double *x_out
 try {
     CCP_TRY(bind(m));
     if (!m->uploaded) return CCP_ERR_STATE;
-    if (m->rb.on) return CCP_ERR_UNSUPPORTED;      // (row blocks: the Gauss-Seidel sweep, b := A x and the residual)
     CCP_TRY(flush_edits(m));
-    if (!b || !x_out) return CCP_ERR_BAD_ARG;
+    const bool rowblock = m->rb.on;        // b, x_out: the block's own rows (see ccp_csr_conjugate_gradient)
+    if ((!b || !x_out) && !(rowblock && m->rb.n_local == 0)) return CCP_ERR_BAD_ARG;
     if (m->n_rows != m->n_cols) return CCP_ERR_UNSUPPORTED;
     CCP_TRY(ensure_natural(m));
     const long n = m->n_rows;
@@ -2671,18 +2671,38 @@ try {
     if (m->cg_inv.n != inv.size()) CCP_TRY(m->cg_inv.alloc(inv.size()));
     if (n) {
         CCP_HIP(hipMemcpyAsync(m->cg_inv.p, inv.data(), sizeof(double) * n, hipMemcpyHostToDevice, s));
-        CCP_HIP(hipMemcpyAsync(m->tmp.p, b, sizeof(double) * n, hipMemcpyHostToDevice, s));     // r = b - A 0 = b (:500-501)
+        if (rowblock) CCP_TRY(rb_stage(m, m->tmp.p, b));                                         // (a ghost: empty row, inverse diagonal 1, r = 0)
+        else CCP_HIP(hipMemcpyAsync(m->tmp.p, b, sizeof(double) * n, hipMemcpyHostToDevice, s));     // r = b - A 0 = b (:500-501)
         CCP_HIP(hipMemsetAsync(m->x.p, 0, sizeof(double) * n, s));                               // :495
     }
     const SellView view = m->natural.view();
     const int n_slices = m->natural.n_slices;
     auto spmv_dot = [&](const double *in, double *out, int *n_partials) -> int {
         *n_partials = 0;
+        if (rowblock) CCP_TRY(rb_exchange_natural(m, const_cast<double *>(in)));
         if (n_slices == 0) return CCP_OK;
         hipLaunchKernelGGL((k_sell_apply<2>), dim3(spmv_blocks), dim3(kBlock), 0, s, view, n_slices, in, out, in, m->partial.p);
         *n_partials = (int)spmv_blocks;
         return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
     };
+    if (rowblock) {
+        const RcclApi *api = rccl_api();
+        if (!api) return CCP_ERR_RCCL;
+        double *total = reinterpret_cast<double *>(m->rb.comm->scratch.p);
+        auto sums = [&](double *partial, int *count, const double **sum_at, int slot) -> int {
+            hipLaunchKernelGGL(k_reduce_to, dim3(1), dim3(kBlock), 0, s, partial, (long)*count, 1L, total + slot, 0);
+            CCP_HIP(hipGetLastError());
+            CCP_RCCL(api->AllReduce(total + slot, total + slot, 1, ncclDouble, ncclSum, m->rb.comm->comm, s));
+            *count = 1;
+            *sum_at = total + slot;
+            return CCP_OK;
+        };
+        CCP_TRY(pcg_solve(spmv_dot, m->x.p, m->tmp.p, m->cg_p.p, m->cg_ap.p, m->cg_inv.p, n, epsilon, max_iteration, m->cg_state.p,
+                          m->partial.p, m->cg_partial2.p, s, m->ev0, m->ev1, report, sums, true));
+        if (m->rb.n_local) CCP_HIP(hipMemcpyAsync(x_out, m->x.p + m->rb.n_lo, sizeof(double) * (size_t)m->rb.n_local, hipMemcpyDeviceToHost, s));
+        CCP_HIP(hipStreamSynchronize(s));    // `inv` lives on this stack frame
+        return CCP_OK;
+    }
     CCP_TRY(pcg_solve(spmv_dot, m->x.p, m->tmp.p, m->cg_p.p, m->cg_ap.p, m->cg_inv.p, n, epsilon, max_iteration, m->cg_state.p,
                       m->partial.p, m->cg_partial2.p, s, m->ev0, m->ev1, report));
     if (n) CCP_HIP(hipMemcpyAsync(x_out, m->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));

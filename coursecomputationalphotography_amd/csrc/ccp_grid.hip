@@ -2187,12 +2187,12 @@ try {
         return CCP_OK;
     };
     double *total = reinterpret_cast<double *>(g->comm->scratch.p);
-    auto sums = [&](double *partial, int *count, const double **sum_at) -> int {
-        hipLaunchKernelGGL(k_reduce_to_one, dim3(1), dim3(kBlock), 0, s, partial, (long)*count, total);
+    auto sums = [&](double *partial, int *count, const double **sum_at, int slot) -> int {
+        hipLaunchKernelGGL(k_reduce_to_one, dim3(1), dim3(kBlock), 0, s, partial, (long)*count, total + slot);
         CCP_HIP(hipGetLastError());
-        CCP_RCCL(api->AllReduce(total, total, 1, ncclDouble, ncclSum, g->comm->comm, s));
+        CCP_RCCL(api->AllReduce(total + slot, total + slot, 1, ncclDouble, ncclSum, g->comm->comm, s));
         *count = 1;
-        *sum_at = total;
+        *sum_at = total + slot;
         return CCP_OK;
     };
     for (int ch = 0; ch < g->desc.channels; ++ch) {

@@ -177,11 +177,11 @@ int ccp_csr_residual_norm2(ccp_csr *m, const double *b, const double *x, double 
  *        reference travel to them (one ncclSend/ncclRecv pair per neighbouring block, all in one group); the
  *        stop rule (:376) uses the all-reduced step sum, so every rank stops at the same sweep;
  *   ccp_csr_apply_to_vector, ccp_csr_residual_norm2   collective (rr, bb: sums over the whole matrix);
- *   ccp_csr_conjugate_gradient   collective: the ghosts of the direction travel before every product, every dot
- *        product is all-reduced (iterates equal to the one-GPU loop's to rounding, the same stop iteration on every rank);
+ *   ccp_csr_conjugate_gradient, ccp_csr_conjugate_gradient_jacobi   collective: the ghosts of the direction travel
+ *        before every product, every dot product is all-reduced (iterates equal to the one-GPU loop's to rounding, the
+ *        same stop iteration on every rank);
  *   ccp_csr_get_colouring   the block's own rows.
- * The reference-order sweep, ccp_csr_conjugate_gradient_jacobi, ccp_csr_insert and ccp_csr_set_colouring return
- * CCP_ERR_UNSUPPORTED on a row block.  ccp_csr_upload returns the handle to the one-GPU form.
+ * The reference-order sweep, ccp_csr_insert and ccp_csr_set_colouring return CCP_ERR_UNSUPPORTED on a row block.  ccp_csr_upload returns the handle to the one-GPU form.
  * `comm` must stay alive for as long as the handle is used as a row block.  What the ranks agree on are refused
  * ARGUMENTS; a HIP or RCCL failure in the middle of a collective call (CCP_ERR_HIP / CCP_ERR_RCCL) is local to the rank
  * it happens on — treat it as fatal for the communicator, as with any RCCL error.

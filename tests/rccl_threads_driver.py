@@ -362,6 +362,7 @@ def case_csr_rows(c):
     cg = c.get("cg")                                  # [epsilon, max_iteration]: conjugateGradient (sparse-matrix.h:396-434) as well
     if cg:
         cg_w, cg_rep_w = whole.conjugate_gradient(b, cg[0], cg[1], init=x0)
+        pcg_w, pcg_rep_w = whole.conjugate_gradient_jacobi(b, cg[0], cg[1])       # conjugateGradientEigen (:494-535), from x0 = 0
     whole.close()
     orc = oracle.Oracle()
     want_o, it_o, _ = orc.multicolour_gauss_seidel(v, col, rowp, colour, b, eps, iters, x0=x0)
@@ -383,10 +384,11 @@ def case_csr_rows(c):
         cg_out = None
         if cg:
             xc, rc = m.conjugate_gradient(b[lo:hi], cg[0], cg[1], init=None if x0 is None else x0[lo:hi])
-            cg_out = (xc, rc.converged, rc.iterations, rc.last_l1_step)
+            xp, rp = m.conjugate_gradient_jacobi(b[lo:hi], cg[0], cg[1])
+            cg_out = (xc, rc.converged, rc.iterations, rc.last_l1_step, xp, rp.converged, rp.iterations)
         info = m.rows_info()
         for what, fn in (("lexicographic", lambda: m.gauss_seidel(b[lo:hi], 0.0, 1, ordering=capi.ORDER_LEXICOGRAPHIC)),
-                         ("cg_jacobi", lambda: m.conjugate_gradient_jacobi(b[lo:hi], 1e-9, 3)), ("insert", lambda: m.insert(1.0, 0, 0))):
+                         ("insert", lambda: m.insert(1.0, 0, 0))):
             try:
                 fn()
                 unsupported.append((what, 0))
@@ -410,7 +412,10 @@ def case_csr_rows(c):
         xc = np.concatenate([o[9][0] for o in out])
         cg_res = {"cg_rel_diff": float(np.linalg.norm(xc - cg_w) / np.linalg.norm(cg_w)), "cg_iterations_one_gpu": cg_rep_w.iterations,
                   "cg_converged_one_gpu": cg_rep_w.converged, "cg_iterations_ranks": [o[9][2] for o in out], "cg_converged_ranks": [o[9][1] for o in out],
-                  "cg_rnorm_ranks": [o[9][3] for o in out], "cg_rnorm_one_gpu": cg_rep_w.last_l1_step}
+                  "cg_rnorm_ranks": [o[9][3] for o in out], "cg_rnorm_one_gpu": cg_rep_w.last_l1_step,
+                  "pcg_rel_diff": float(np.linalg.norm(np.concatenate([o[9][4] for o in out]) - pcg_w) / np.linalg.norm(pcg_w)),
+                  "pcg_iterations_one_gpu": pcg_rep_w.iterations, "pcg_converged_one_gpu": pcg_rep_w.converged,
+                  "pcg_iterations_ranks": [o[9][6] for o in out], "pcg_converged_ranks": [o[9][5] for o in out]}
     return {"ok": True, "n": n, "colours": nc, "cuts": cuts, **cg_res,
             "bit_identical_to_one_gpu": bool(np.array_equal(got, want)),
             "bit_identical_to_oracle": bool(np.array_equal(got, want_o)),

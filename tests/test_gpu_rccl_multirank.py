@@ -181,7 +181,11 @@ def test_csr_row_blocks_sweep_the_one_gpu_iterates(fake_env):
             assert len(set(r["cg_iterations_ranks"])) == 1 and len(set(r["cg_rnorm_ranks"])) == 1, r
             assert r["cg_converged_ranks"] == [r["cg_converged_one_gpu"]] * c["world"], r
             assert abs(r["cg_iterations_ranks"][0] - r["cg_iterations_one_gpu"]) <= (1 if r["cg_converged_one_gpu"] else 0), r
-        # the reference-order sweep, the Jacobi-preconditioned loop and insert do not shard: CCP_ERR_UNSUPPORTED (6) on every rank
+            # ... and conjugateGradientEigen (Jacobi-preconditioned) likewise
+            assert r["pcg_rel_diff"] < 1e-9, r
+            assert len(set(r["pcg_iterations_ranks"])) == 1 and r["pcg_converged_ranks"] == [r["pcg_converged_one_gpu"]] * c["world"], r
+            assert abs(r["pcg_iterations_ranks"][0] - r["pcg_iterations_one_gpu"]) <= (1 if r["pcg_converged_one_gpu"] else 0), r
+        # the reference-order sweep and insert do not shard: CCP_ERR_UNSUPPORTED (6) on every rank
         assert all(st == 6 for rank in r["unsupported"] for _, st in rank), r["unsupported"]
         # the messages went through the transport: every value sent was received, 8 bytes each, plus the halo index
         # lists and colours of the set-up (4 bytes each way per ghost)
