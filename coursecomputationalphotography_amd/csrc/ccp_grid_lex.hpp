@@ -459,6 +459,10 @@ k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGe
 //   C  anything else (the first and last ~10 blocks of a strip): classify / gs_update at every step.
 // All three read their inputs from the rings: no wave but the loader loads, no wave but the storer stores.
 // grid = (G * S, channels), block = (T + 2) * 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
+#ifndef CCP_LEX_SHIFT_DOWN
+#define CCP_LEX_SHIFT_DOWN 1
+#endif
+constexpr bool kLexShiftDown = CCP_LEX_SHIFT_DOWN != 0;   // interior bodies of k_lex_wg: `down` from `right` by a lane shift
 constexpr int kLexRing = 4;                        // result rows kept per sweep: written at step d, read at step d+3, free at d+4
 constexpr int kLexBRows = 32;
 constexpr int kLexSlackRows = 320;                 // diagonal rows allocated beyond the last one (k_lex_wg / k_lex_wg2 prefetch past the image: up to ~160 rows at 128-column strips)
@@ -552,7 +556,7 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
                                                int db0, int db1, int xs0, bool lane_on, Stencil st_b)
 {
     const bool ghost = lane < 2;
-    const int lds2 = max(lane - 2, 0);
+    const int lds2 = max(lane - 2, 0), lds1 = max(lane - 1, 0);
     const int col = ghost ? LexWgShape<T>::kGhost + 2 * t + lane : lane - 2 - 2 * t + 2 * (T - 1);   // of a b row in LDS
     const bool c_off = !lane_on || st_b.diag == 0;           // (st_b: classify() of this lane's column at an interior y)
     const bool c_x0 = !c_off && !st_b.left, c_xl = !c_off && !st_b.right;
@@ -567,9 +571,11 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
         const int sb = (db - 4 * t) & (kLexBRows - 1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const double *in = &ring[t][(j + 1) & (kLexRing - 1)][lds2];                  // two adjacent doubles: one ds_read2_b64
-            const double down = in[0];
-            const double right = in[1];
+            // `right` is sweep t-1's value one lane to the left, `down` the one two lanes to the left: one LDS read and a
+            // lane shift instead of two adjacent doubles per lane (half the LDS bytes of the step's biggest read; the
+            // ghost lanes 0 and 1 never use either)
+            const double right = ring[t][(j + 1) & (kLexRing - 1)][lds1];
+            const double down = kLexShiftDown ? lane_prev(right) : ring[t][(j + 1) & (kLexRing - 1)][lds2];
             const double vv = brow[(sb + j) & (kLexBRows - 1)][col];
             const double up = h1;
             const double left = lane_prev(h1);
