@@ -347,14 +347,17 @@ __device__ __forceinline__ void fused_load_mask(const FusedCtx &cx, const Geom &
 // 2 = of EVERY iteration t = 1..T in acc[t-1] (old is the previous level of the same colour, which
 // the window still holds — the reference's per-sweep manhattonDist at no extra memory traffic).
 constexpr int kStepFast = 0, kStepBorder = 2, kStepSide = 3;
+typedef int QWord;
+constexpr int kQuarterHi = 0x3FD00000;                  // high word of 0.25
 
 // MASKED (Dirichlet-mask grid): the update is fma(sum, q, b/4) with q = 1/4 for an unknown and 0 for a pixel
-// fixed at zero (whose b is 0): the same instruction count as the plain update, the mask costs registers (a
-// q window) instead of instructions.  The stencil is the uniform 5-point one — no degree logic anywhere.
+// fixed at zero (whose b is 0).  The stencil is the uniform 5-point one — no degree logic anywhere.  Both values of q
+// have a zero low word, so the window keeps the HIGH word only (QWord: one VGPR per pixel instead of two — what lets
+// the masked pass go as deep as the plain one) and the factor is put together at its use (a register move or two).
 template <int T, int MODE, int L1, int UNR, int NT, int AN, bool MASKED = false, int NQ = 1, bool COH = false, class Win = FusedWindow<T, UNR>>
 __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], double (&br)[NT], double (&bk)[NT],
                                            double (&acc)[AN], const FusedCtx &cx, const Geom &g, int f, int i,
-                                           double (&qr)[NQ], double (&qk)[NQ])
+                                           QWord (&qr)[NQ], QWord (&qk)[NQ])
 {
     static_assert(Win::NT == NT, "window policy and register arrays disagree");
     constexpr int HS = Win::HS;
@@ -377,7 +380,7 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
         const double old = c ? wk[sr] : wr[sr];
         double nv = old;
         if (MODE == kStepFast) {
-            if (MASKED) nv = __builtin_fma(((up + left) + right) + dn, c ? qk[MASKED ? sr : 0] : qr[MASKED ? sr : 0], bq);
+            if (MASKED) nv = __builtin_fma(((up + left) + right) + dn, __hiloint2double(c ? qk[MASKED ? sr : 0] : qr[MASKED ? sr : 0], 0), bq);
             // (ring form: 1/4 from a register — as a literal it forces the two-address v_fmac, whose destination is
             // the b/4 the window must keep, i.e. a copy per update; the shifted form folds that copy into its shifts)
             else nv = __builtin_fma(((up + left) + right) + dn, Win::kRing ? cx.quarter : 0.25, bq);
@@ -499,7 +502,7 @@ __device__ __forceinline__ void fused_load_row_into(const FusedCtx &cx, const Ge
 // One unrolled step of the ring march (I = its position in the loop body).
 template <int T, int I, int AN, bool MASKED, int NQ, bool COH>
 __device__ __forceinline__ void fused_ring_step(double (&wr)[FusedRing<T>::NT], double (&wk)[FusedRing<T>::NT], double (&br)[FusedRing<T>::NT],
-                                                double (&bk)[FusedRing<T>::NT], double (&qr)[NQ], double (&qk)[NQ],
+                                                double (&bk)[FusedRing<T>::NT], QWord (&qr)[NQ], QWord (&qk)[NQ],
                                                 int (&landm)[kRingAhead][2], double (&acc)[AN], const FusedCtx &cx, const Geom &g, int f)
 {
     using Win = FusedRing<T>;
@@ -511,8 +514,8 @@ __device__ __forceinline__ void fused_ring_step(double (&wr)[FusedRing<T>::NT], 
     br[s0] = br[s0] * 0.25;
     bk[s0] = bk[s0] * 0.25;
     if (MASKED) {
-        qr[MASKED ? s0 : 0] = landm[I % kRingAhead][0] ? 0.25 : 0.0;
-        qk[MASKED ? s0 : 0] = landm[I % kRingAhead][1] ? 0.25 : 0.0;
+        qr[MASKED ? s0 : 0] = landm[I % kRingAhead][0] ? kQuarterHi : 0;
+        qk[MASKED ? s0 : 0] = landm[I % kRingAhead][1] ? kQuarterHi : 0;
         fused_load_mask(cx, g, f + kRingAhead, landm[I % kRingAhead]);
     }
     fused_step<T, kStepFast, 0, 0, NT, AN, MASKED, NQ, COH, Win>(wr, wk, br, bk, acc, cx, g, f, I, qr, qk);
@@ -522,7 +525,7 @@ template <int T, int I, int AN, bool MASKED, int NQ, bool COH>
 struct FusedRingTrip {
     // steps I .. P-1 of a loop trip; false: the march ended inside the trip
     static __device__ __forceinline__ bool run(double (&wr)[FusedRing<T>::NT], double (&wk)[FusedRing<T>::NT], double (&br)[FusedRing<T>::NT],
-                                               double (&bk)[FusedRing<T>::NT], double (&qr)[NQ], double (&qk)[NQ], int (&landm)[kRingAhead][2],
+                                               double (&bk)[FusedRing<T>::NT], QWord (&qr)[NQ], QWord (&qk)[NQ], int (&landm)[kRingAhead][2],
                                                double (&acc)[AN], const FusedCtx &cx, const Geom &g, int fb, int f_end)
     {
         if constexpr (I >= FusedRing<T>::G) {
@@ -562,12 +565,12 @@ __device__ __forceinline__ void fused_wave_ring(const double *__restrict__ xin, 
     const int f_end = rb - 1 + HS;
     double wr[NT], wk[NT], br[NT], bk[NT];
     constexpr int NQ = MASKED ? NT : 1;
-    double qr[NQ], qk[NQ];
+    QWord qr[NQ], qk[NQ];
     int landm[kRingAhead][2];
 #pragma unroll
     for (int s = 0; s < NT; ++s) wr[s] = wk[s] = br[s] = bk[s] = 0.0;
 #pragma unroll
-    for (int s = 0; s < NQ; ++s) qr[s] = qk[s] = 0.0;
+    for (int s = 0; s < NQ; ++s) qr[s] = qk[s] = 0;
 #pragma unroll
     for (int j = 0; j < kRingAhead; ++j) landm[j][0] = landm[j][1] = 0;
     FusedRingPrologue<T, 0, MASKED, COH>::run(wr, wk, br, bk, landm, cx, g, base);
@@ -601,13 +604,13 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
 
     double wr[NT], wk[NT], br[NT], bk[NT];              // x red/black, b red/black per window row
     constexpr int NQ = MASKED ? NT : 1;
-    double qr[NQ], qk[NQ];                              // MASKED: 1/4 for an unknown, 0 for a pixel fixed at zero
+    QWord qr[NQ], qk[NQ];                               // MASKED: the factor 1/4 (an unknown) or 0 (a pixel fixed at zero), high word
     double land[G][4];                                  // rows in flight
     int landm[G][2];
 #pragma unroll
     for (int s = 0; s < NT; ++s) wr[s] = wk[s] = br[s] = bk[s] = 0.0;
 #pragma unroll
-    for (int s = 0; s < NQ; ++s) qr[s] = qk[s] = 0.0;
+    for (int s = 0; s < NQ; ++s) qr[s] = qk[s] = 0;
 #pragma unroll
     for (int i = 0; i < G; ++i) {
         fused_load_row<COH>(cx, g, base + i, land[i]);
@@ -618,8 +621,8 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
         const int s0 = Win::slot(i, 0);
         wr[s0] = land[i][0]; wk[s0] = land[i][1]; br[s0] = land[i][2] * 0.25; bk[s0] = land[i][3] * 0.25;
         if (MASKED) {
-            qr[s0] = landm[i][0] ? 0.25 : 0.0;
-            qk[s0] = landm[i][1] ? 0.25 : 0.0;
+            qr[s0] = landm[i][0] ? kQuarterHi : 0;
+            qk[s0] = landm[i][1] ? kQuarterHi : 0;
         }
     }
 
@@ -649,7 +652,7 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
             _Pragma("unroll") for (int i = 0; i < G; ++i) {                                                                   \
                 const int s0 = Win::slot(i, 0);                                                                               \
                 wr[s0] = ARRIVED[i][0]; wk[s0] = ARRIVED[i][1]; br[s0] = ARRIVED[i][2] * 0.25; bk[s0] = ARRIVED[i][3] * 0.25;  \
-                if (MASKED) { qr[s0] = ARRIVEDM[i][0] ? 0.25 : 0.0; qk[s0] = ARRIVEDM[i][1] ? 0.25 : 0.0; }                    \
+                if (MASKED) { qr[s0] = ARRIVEDM[i][0] ? kQuarterHi : 0; qk[s0] = ARRIVEDM[i][1] ? kQuarterHi : 0; }                    \
             }                                                                                                                 \
         }
         for (int fb = base; fb <= f_end; fb += 2 * G) {
@@ -702,8 +705,8 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
             const int s0 = Win::slot(i, 0);
             wr[s0] = land[i][0]; wk[s0] = land[i][1]; br[s0] = land[i][2] * 0.25; bk[s0] = land[i][3] * 0.25;
             if (MASKED) {
-                qr[s0] = landm[i][0] ? 0.25 : 0.0;
-                qk[s0] = landm[i][1] ? 0.25 : 0.0;
+                qr[s0] = landm[i][0] ? kQuarterHi : 0;
+                qk[s0] = landm[i][1] ? kQuarterHi : 0;
             }
         }
     }
@@ -777,7 +780,10 @@ k_fused_sweep(FusedParams P)
 // through the buffer range check, and zero is what lies outside a Dirichlet region); a tile whose extended
 // region holds no unknown at all leaves at once (its pixels are zero in both ping-pong buffers and stay so).
 // tile_live: one byte per (chunk, strip), written by k_masked_tile_census for this tiling.
-constexpr int kMaskedMaxT = 7;           // the q window costs 2 VGPRs per pixel kept: depth 6 fits where depth 8 fits unmasked
+#ifndef CCP_MASKED_MAX_T
+#define CCP_MASKED_MAX_T 8
+#endif
+constexpr int kMaskedMaxT = CCP_MASKED_MAX_T;   // the q window costs one VGPR per pixel kept (its high word)
 constexpr int kMaskedMaxCheckedT = 4;    // deepest masked pass that also reports the step of each of its sweeps
 __host__ __device__ constexpr int masked_waves_per_simd(int T, int L1 = 0)
 {

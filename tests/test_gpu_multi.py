@@ -72,6 +72,7 @@ def test_multi_pass_launch_on_row_blocks(capi, monkeypatch, W, H, block, iters):
     (1500, 1100, [21], (7, 160)),         # 3 passes; remainder chunk of 140 rows
     (900, 700, [12, 12], (4, 64)),        # depth 4, 3 + 3 passes; 700 = 10 x 64 + 60
     (2000, 1303, [14], (7, 100)),         # remainder chunk of 3 rows: shorter than the halo
+    (1500, 1100, [32], (8, 128)),         # depth 8 (the high-word factor window): 4 passes
 ])
 def test_multi_pass_launch_on_dirichlet_mask_grids(capi, monkeypatch, W, H, iters, tiling):
     """Region grids (BASELINE configs[4]'s form): every tile ordinary, dead tiles complete without running."""

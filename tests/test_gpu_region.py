@@ -39,7 +39,7 @@ MASKS = {
 
 
 @pytest.mark.parametrize("name", list(MASKS))
-@pytest.mark.parametrize("tmax,iters", [(1, 5), (2, 4), (3, 9), (4, 8), (5, 11), (6, 13), (7, 15), (7, 30)])
+@pytest.mark.parametrize("tmax,iters", [(1, 5), (2, 4), (3, 9), (4, 8), (5, 11), (6, 13), (7, 15), (7, 30), (8, 16), (8, 35)])
 def test_mask_grid_sweeps_equal_oracle(capi, orc, monkeypatch, name, tmax, iters):
     """ccp_grid_sweep on a Dirichlet-mask grid, every depth of the temporally blocked pass (plus the in-place
     kernels for the odd iteration), against the oracle; pixels outside the region stay exactly 0."""

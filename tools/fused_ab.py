@@ -60,7 +60,7 @@ def main():
     if "region" in which:
         from coursecomputationalphotography_amd import synth
         mask = synth.disc_mask(8192, 8192, seed=4321)
-        for T in (7, 6):
+        for T in (8, 7, 6):
             g = capi.Grid(8192, 8192, 1, mask=mask)
             g.randomize_x(1, 0.0, 255.0)
             g.b_from_x()
