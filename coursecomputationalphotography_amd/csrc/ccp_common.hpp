@@ -80,6 +80,9 @@ namespace ccp {
 // Library-internal (not part of the C ABI): install the mask of a Dirichlet-mask grid from a DEVICE buffer that is
 // already in the grid's layout (one byte per element of a channel plane, colour half-rows of `pitch` bytes).
 int grid_set_mask_split_device(ccp_grid *g, const unsigned char *split_mask_dev, long unknowns);
+// Library-internal: the handle's owner asks for the layout (ccp_grid_get_layout) at every use, so x and its ping-pong
+// partner may swap roles after a run of passes (ccp_grid.hip: run_unchecked).
+int grid_set_allow_swap(ccp_grid *g, bool on);
 
 inline int select_device(int device)
 {

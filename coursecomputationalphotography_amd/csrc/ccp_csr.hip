@@ -1169,6 +1169,7 @@ bool embed_region_device(ccp_csr *m, const std::vector<int> &colour, int &W, int
     if (m->region_grid) ccp_grid_destroy(m->region_grid);
     m->region_grid = nullptr;
     if (ccp_grid_create(&d, &m->region_grid) != CCP_OK) return false;
+    (void)grid_set_allow_swap(m->region_grid, true);       // (the layout is asked for at every solve)
     ccp_grid_layout lay{};
     if (ccp_grid_get_layout(m->region_grid, &lay) != CCP_OK) return false;
     const size_t plane = (size_t)lay.local_rows * 2 * (size_t)lay.pitch;
@@ -1252,6 +1253,7 @@ int detect_region(ccp_csr *m, bool for_reference_order = false)
         if (m->region_grid) ccp_grid_destroy(m->region_grid);
         m->region_grid = nullptr;
         CCP_TRY(ccp_grid_create(&d, &m->region_grid));
+        (void)grid_set_allow_swap(m->region_grid, true);
         ccp_grid_layout lay{};
         CCP_TRY(ccp_grid_get_layout(m->region_grid, &lay));
         std::vector<unsigned char> mask((size_t)E.W * E.H, 0);
@@ -2260,6 +2262,7 @@ try {
             if (!m->grid) {
                 ccp_grid_desc d{m->poisson_w, m->poisson_h, 1, 0, m->poisson_h, 0, m->device, 0};
                 CCP_TRY(ccp_grid_create(&d, &m->grid));
+                (void)grid_set_allow_swap(m->grid, true);  // (results leave through ccp_grid_get_x_host)
             }
             CCP_TRY(ccp_grid_set_stream(m->grid, m->stream));
             CCP_TRY(ccp_grid_set_b_host(m->grid, 0, b, 0, m->poisson_h));
@@ -2319,6 +2322,8 @@ try {
                 m->last_launches = launches;
             }
             if (swept) {
+                CCP_TRY(ccp_grid_get_layout(g, &lay));             // (x and its ping-pong partner may have swapped roles)
+                gx = static_cast<double *>(lay.x_dev);
                 hipLaunchKernelGGL((k_canvas_move<1>), dim3(blocks_for(n)), dim3(kBlock), 0, s, gx, m->tmp.p, m->region_where.p, n, 0.0);
                 CCP_HIP(hipGetLastError());
                 CCP_HIP(hipMemcpyAsync(x_out, m->tmp.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
@@ -2337,6 +2342,7 @@ try {
             if (!m->grid) {
                 ccp_grid_desc d{m->poisson_w, m->poisson_h, 1, 0, m->poisson_h, 0, m->device, 0};
                 CCP_TRY(ccp_grid_create(&d, &m->grid));
+                (void)grid_set_allow_swap(m->grid, true);  // (results leave through ccp_grid_get_x_host)
             }
             CCP_TRY(ccp_grid_set_stream(m->grid, m->stream));
             CCP_TRY(ccp_grid_set_b_host(m->grid, 0, b, 0, m->poisson_h));
@@ -2564,6 +2570,7 @@ try {
             if (!m->grid) {
                 ccp_grid_desc d{m->poisson_w, m->poisson_h, 1, 0, m->poisson_h, 0, m->device, 0};
                 CCP_TRY(ccp_grid_create(&d, &m->grid));
+                (void)grid_set_allow_swap(m->grid, true);  // (results leave through ccp_grid_get_x_host)
             }
             CCP_TRY(ccp_grid_set_stream(m->grid, m->stream));
             CCP_TRY(ccp_grid_set_b_host(m->grid, 0, b, 0, m->poisson_h));

@@ -57,6 +57,10 @@ struct ccp_grid {
     DevBuf<double> cg_r, cg_p, cg_p2, cg_ap;   // conjugate-gradient work vectors, one channel each (p double-buffered: fused loop)
     DevBuf<CgState> cg_state;
     DevBuf<double> x_alt;        // ping-pong partner of x for the temporally blocked sweep
+    // The CSR entry point's grid twins (ccp_csr.hip) ask for their layout at every solve: for them a run of passes may
+    // end in either buffer — x and x_alt then swap roles — instead of being planned as an EVEN number of launches
+    // (50 iterations at depth 8: seven launches instead of eight).  Handles whose x_dev a caller may hold keep the parity.
+    bool allow_swap = false;
     // Dirichlet-mask grid (CCP_GRID_DIRICHLET_MASK): uniform 5-point stencil on the pixels whose mask byte
     // is 1, everything else fixed at zero.  maskp: one byte per pixel in the layout of x (one channel);
     // tile_live: which tiles of the current tiling hold any unknown (k_masked_tile_census), cached per tiling.
@@ -697,8 +701,10 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool
                     step[(size_t)i * 2 + p] = T;
                 }
             }
+    const bool free_parity = g->allow_swap && !g->ghost_top && !g->ghost_bottom && edge_rows == 0 &&
+                             f[(size_t)iterations * 2 + 1] < f[(size_t)iterations * 2];
     std::vector<int> plan;
-    for (int i = iterations, p = 0; i > 0;) {
+    for (int i = iterations, p = free_parity ? 1 : 0; i > 0;) {
         const int T = step[(size_t)i * 2 + p];
         if (T == 0) return CCP_ERR_STATE;
         plan.push_back(T);
@@ -738,6 +744,12 @@ int run_unchecked(ccp_grid *g, int iterations, const int *active = nullptr, bool
         CCP_TRY(launch_fused(g, plan[k], cur, alt, active, (l1_last && last) ? 1 : 0, l1_blocks, last ? edge_rows : 0));
         std::swap(cur, alt);
         ++k;
+    }
+    if (cur != g->x.p) {
+        // an odd number of passes (free_parity): the result is in the partner buffer, which becomes x
+        if (!free_parity) return CCP_ERR_STATE;
+        std::swap(g->x.p, g->x_alt.p);
+        std::swap(g->x.n, g->x_alt.n);
     }
     if (edge_rows > 0) CCP_TRY(edge_epoch_publish_after_pass(g));
     return CCP_OK;
@@ -1024,6 +1036,13 @@ try {
 
 // Library-internal twin of ccp_grid_set_mask_host for a mask that is already on the device in the grid's layout
 // (the region recognition builds it there: ccp_csr.hip).  Asynchronous on the handle's stream.
+int ccp::grid_set_allow_swap(ccp_grid *g, bool on)
+{
+    if (!g) return CCP_ERR_BAD_ARG;
+    g->allow_swap = on;
+    return CCP_OK;
+}
+
 int ccp::grid_set_mask_split_device(ccp_grid *g, const unsigned char *split_mask_dev, long unknowns)
 {
     CCP_TRY(bind(g));
