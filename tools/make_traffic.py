@@ -54,8 +54,8 @@ def main(d, out_path):
         "bench.py's timed passes, pinned tiling", {"iterations_per_launch": 8})
     put("4096x4096x3_T8_R140", "mid", ["k_fused_sweep<8, 0, 2, false>", "k_fused_border<8, 0, 2, false>"],
         "tools/profile_kernels.py mid: BASELINE configs[1], the tiling bench.py pins", {"iterations_per_launch": 8})
-    put("region_grid_mask_8192", "region", ["k_fused_sweep_masked<7, 0, 2>"],
-        "tools/profile_kernels.py region: BASELINE configs[4] recognised as a raster region, depth-7 passes", {"iterations_per_launch": 7})
+    put("region_grid_mask_8192", "region", ["k_fused_sweep_masked<8, 0, 2>"],
+        "tools/profile_kernels.py region: BASELINE configs[4] recognised as a raster region, depth-8 passes", {"iterations_per_launch": 8})
     put("sell_mask_8192", "sell", ["k_sell_gs<false>"],
         "tools/profile_kernels.py gs: BASELINE configs[4] on the sliced-ELL images, one launch per colour")
     put("lex_wg_16384", "lex", ["k_lex_wg<8, false>"],

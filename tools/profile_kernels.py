@@ -36,8 +36,8 @@ if what & {"apply", "gs", "pipe", "region"}:
         m = capi.CsrMatrix().upload_compressed(v, c, r)
         m.set_colouring(colour, 2)
         bb = np.ones(n)
-        m.gauss_seidel(bb, 0.0, 14, check_every=0)
-        m.gauss_seidel(bb, 0.0, 70, check_every=0)
+        m.gauss_seidel(bb, 0.0, 16, check_every=0)           # (the second solve tunes the tiling: passes of depth 8)
+        m.gauss_seidel(bb, 0.0, 64, check_every=0)
         print(f"region: {m.last_path()}", flush=True)
         m.close()
     os.environ["CCP_GS_MASKED"] = "0"                      # the kernels below are the stored-matrix ones
