@@ -17,6 +17,10 @@ if [ "$what" = kt ] || [ "$what" = all ]; then
     rocprofv3 --output-format csv --kernel-trace --stats -d "$out/kt_bench" -o bench -- python3 bench.py --no-cpu-baseline > "$out/bench_under_kt.json" 2> "$out/kt_bench.log" || exit 1
     cp "$(find "$out/kt_bench" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats_bench.csv"
     echo "kt bench done"
+    # the timed passes alone (no configs, no convergence run): the dominant kernel's average is the 16384^2 pass
+    rocprofv3 --output-format csv --kernel-trace --stats -d "$out/kt_lean" -o bench -- python3 bench.py $lean > "$out/bench_lean_under_kt.json" 2> "$out/kt_lean.log" || exit 1
+    cp "$(find "$out/kt_lean" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats_bench_timed_passes_only.csv"
+    echo "kt lean done"
     [ "$what" = kt ] && { find "$out" -name '*kernel_trace.csv' -size +5M -delete; exit 0; }
 fi
 pass() {  # tag, command...
