@@ -248,3 +248,27 @@ def test_grid_conjugate_gradient_on_row_blocks(fake_env):
         assert r["converged_ranks"][0] == r["converged_one_block"], r
         assert all(abs(a - b) <= (1 if cv else 0) for a, b, cv in zip(r["iterations_ranks"][0], r["iterations_one_block"], r["converged_one_block"])), r
         assert r["sweep_after_solve_bit_identical"], c
+
+
+def test_csr_row_blocks_random_partitions(fake_env):
+    """Random sparse matrices, random cuts (empty blocks, one-row blocks, everything on one rank), worlds 2-4: the blocks'
+    iterates, products and norms are the one-GPU handle's."""
+    rng = np.random.Generator(np.random.MT19937(20261004))
+    cases = []
+    for k in range(14):
+        world = int(rng.integers(2, 5))
+        n = int(rng.integers(40, 2500))
+        inner = sorted(int(v) for v in rng.integers(0, n + 1, world - 1))
+        if k == 3:
+            inner = [0] * (world - 1)                        # every row on the last rank
+        if k == 7:
+            inner = [1] + [n] * (world - 2) if world > 2 else [1]
+        cases.append({"kind": "csr_rows", "matrix": "random", "n": n, "deg": int(rng.integers(1, 5)), "seed": int(rng.integers(1, 10**6)),
+                      "world": world, "iters": int(rng.integers(1, 6)), "x0": bool(rng.integers(0, 2)), "slack": int(rng.integers(0, 3)),
+                      "cuts": [0] + inner + [n], "overlap": bool(rng.integers(0, 2)), "empty_rows": bool(rng.integers(0, 2))})
+    for r in drive(fake_env, cases):
+        c = r["case"]
+        assert r["ok"], r
+        assert r["bit_identical_to_one_gpu"] and r["bit_identical_to_oracle"] and r["spmv_bit_identical"], c
+        assert r["residual_close"] and r["residual_same_on_all_ranks"], c
+        assert r["iterations_ranks"] == [c["iters"]] * c["world"] and r["own_colours_ok"], r
