@@ -118,8 +118,10 @@ def cpu_baseline(sample: int, iters: int):
     """Reference gaussSeidel (lexicographic, single thread by construction) on a sample of the workload: the same
     closed-form system (the oracle's generator, orc_poisson_csr) with b = A x_true as everywhere else.  The default
     sample is 4096^2 x 96 sweeps (~15 s inside gaussSeidel): the 16384^2 system itself (--cpu-sample 16384, 3 sweeps)
-    costs ~5 minutes of one host core just to build (1.34e9 entries, 16 GB) against the ~1 minute of the whole run, and
-    the serial sweep's rate per update does not change beyond the last-level cache (4096^2 is 1.3 GB of CSR)."""
+    costs more than 19 minutes of one host core before its first sweep on the GPU box (1.34e9 entries, 16 GB, built,
+    multiplied and ingested serially: a run of round 3 was stopped by the 20-minute limit of a call while still
+    building) against the ~1 minute of the whole run, and the serial sweep's rate per update does not change beyond the
+    last-level cache (4096^2 is 1.3 GB of CSR; 512^2: 1.36e8, 4096^2: 1.23-1.27e8)."""
     import oracle
     from coursecomputationalphotography_amd import synth
     note = ""
