@@ -120,8 +120,8 @@ def cpu_baseline(sample: int, iters: int):
     sample is 4096^2 x 96 sweeps (~15 s inside gaussSeidel): the 16384^2 system itself (--cpu-sample 16384, 3 sweeps)
     costs more than 19 minutes of one host core before its first sweep on the GPU box (1.34e9 entries, 16 GB, built,
     multiplied and ingested serially: a run of round 3 was stopped by the 20-minute limit of a call while still
-    building) against the ~1 minute of the whole run, and the serial sweep's rate per update does not change beyond the
-    last-level cache (4096^2 is 1.3 GB of CSR; 512^2: 1.36e8, 4096^2: 1.23-1.27e8)."""
+    building) against the ~1 minute of the whole run.  The sample flatters the CPU if anything: 512^2 runs at 1.36e8, 4096^2
+    (1.3 GB of CSR) at 1.23-1.27e8, and 8192^2 at 2.0e7 in the build container (3 sweeps, 10.3 s inside gaussSeidel)."""
     import oracle
     from coursecomputationalphotography_amd import synth
     note = ""
