@@ -608,16 +608,15 @@ __device__ __forceinline__ void lex_wg_compute_masked(double &h1, double &acc, d
                                                       const double (*brow)[LexWgShape<T>::kRowW], int t, int lane, int db0, int db1)
 {
     const bool ghost = lane < 2;
-    const int lds2 = max(lane - 2, 0);
+    const int lds2 = max(lane - 2, 0), lds1 = max(lane - 1, 0);
     const int col = ghost ? LexWgShape<T>::kGhost + 2 * t + lane : lane - 2 - 2 * t + 2 * (T - 1);
     double old = 0.0;
     for (int db = db0; db <= db1; db += 8) {
         const int sb = (db - 4 * t) & (kLexBRows - 1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const double *in = &ring[t][(j + 1) & (kLexRing - 1)][lds2];
-            const double down = in[0];
-            const double right = in[1];
+            const double right = ring[t][(j + 1) & (kLexRing - 1)][lds1];                  // (one LDS read and a lane shift: lex_wg_compute)
+            const double down = kLexShiftDown ? lane_prev(right) : ring[t][(j + 1) & (kLexRing - 1)][lds2];
             const double vv = brow[(sb + j) & (kLexBRows - 1)][col];
             const double up = h1;
             const double left = lane_prev(h1);
