@@ -461,7 +461,16 @@ def case_csr_rows_refused(c):
             st = e.status
         after = None
         try:
-            m.gauss_seidel(np.zeros(hi - lo), 0.0, 1)
+            x1, _ = m.gauss_seidel(np.zeros(hi - lo), 0.0, 1)
+            if fault == "none":
+                # the handle takes another block set-up (same arguments) and gives the same iterate; its counters start again
+                sent1 = m.rows_info()["values_sent"]
+                m.upload_rows(comm, lo, n, values, cols, begin, nnz, colr, nc)
+                if m.rows_info()["values_sent"] != 0:
+                    after = -1
+                x2, _ = m.gauss_seidel(np.zeros(hi - lo), 0.0, 1)
+                if not np.array_equal(x1, x2) or m.rows_info()["values_sent"] != sent1:
+                    after = -2
         except capi.CcpError as e:
             after = e.status
         m.close()
