@@ -784,7 +784,10 @@ k_fused_sweep(FusedParams P)
 #define CCP_MASKED_MAX_T 8
 #endif
 constexpr int kMaskedMaxT = CCP_MASKED_MAX_T;   // the q window costs one VGPR per pixel kept (its high word)
-constexpr int kMaskedMaxCheckedT = 4;    // deepest masked pass that also reports the step of each of its sweeps
+#ifndef CCP_MASKED_MAX_CHECKED_T
+#define CCP_MASKED_MAX_CHECKED_T 7
+#endif
+constexpr int kMaskedMaxCheckedT = CCP_MASKED_MAX_CHECKED_T;    // deepest masked pass that also reports the step of each of its sweeps
 __host__ __device__ constexpr int masked_waves_per_simd(int T, int L1 = 0)
 {
     return L1 == 0 ? (T <= 1 ? 6 : T <= 2 ? 5 : T <= 3 ? 3 : 2) : (T <= 1 ? 4 : T <= 2 ? 3 : 2);
