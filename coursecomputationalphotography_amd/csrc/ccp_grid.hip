@@ -87,6 +87,7 @@ struct ccp_grid {
     DevBuf<double> partial;      // per-block partial sums (L1 step / residual / checksums)
     long partial_region = 0;     // doubles per colour region of `partial` (L1 step)
     DevBuf<double> small;        // 4*kMaxChannels doubles of reduced results
+    DevBuf<double> sweep_sums;   // row blocks: step sums of every sweep of a checked pass (kFusedMaxCheckedT * kMaxChannels)
     DevBuf<SolveState> state;
     DevBuf<int> redo_mask;       // per-channel flags for re-running one channel of a checked pass
     // lexicographic (reference-order) path: diagonal-major copies of x and b, snapshot, step sums
@@ -1931,16 +1932,17 @@ bool has_neighbours(const ccp_grid *g) { return g->up_rank >= 0 || g->down_rank 
 // The messages of one exchange, all in one RCCL group on `s`: the outermost owned rows go to the
 // neighbours' ghost rows, theirs arrive in ours.  One image row of one channel is 2*pitch contiguous
 // doubles, so a block of rows is one message per channel and direction.
-int issue_exchange(ccp_grid *g, hipStream_t s)
+int issue_exchange(ccp_grid *g, hipStream_t s, double *base = nullptr)
 {
     const RcclApi *api = rccl_api();
     if (!api || !g->comm) return CCP_ERR_STATE;
     const Geom &geo = g->geom;
     const size_t row = (size_t)2 * geo.pitch;
+    if (!base) base = g->x.p;                        // (a checked solve exchanges the buffer its iterate is in)
     CCP_RCCL(api->GroupStart());
     ncclResult_t r = ncclSuccess;
     for (int ch = 0; ch < g->desc.channels && r == ncclSuccess; ++ch) {
-        double *x = g->x.p + (size_t)ch * geo.ch_stride;
+        double *x = base + (size_t)ch * geo.ch_stride;
         if (g->up_rank >= 0) {
             r = api->Send(x + (size_t)geo.own_lo * row, (size_t)g->send_up * row, ncclDouble, g->up_rank, g->comm->comm, s);
             if (r == ncclSuccess) r = api->Recv(x, (size_t)g->ghost_top * row, ncclDouble, g->up_rank, g->comm->comm, s);
@@ -1960,7 +1962,7 @@ int issue_exchange(ccp_grid *g, hipStream_t s)
 
 // Refresh the ghost rows.  after_edges: the sweeps were issued with an edge epoch — the messages wait for
 // the edge flag only and travel beside the rest of the pass; otherwise they wait for everything queued.
-int exchange(ccp_grid *g, bool after_edges)
+int exchange(ccp_grid *g, bool after_edges, double *base = nullptr)
 {
     if (!g->comm) return CCP_ERR_STATE;
     if (has_neighbours(g)) {
@@ -1970,7 +1972,7 @@ int exchange(ccp_grid *g, bool after_edges)
             CCP_HIP(hipEventRecord(g->ev_ready, g->stream));
             CCP_HIP(hipStreamWaitEvent(g->stream_comm, g->ev_ready, 0));
         }
-        CCP_TRY(issue_exchange(g, g->stream_comm));
+        CCP_TRY(issue_exchange(g, g->stream_comm, base));
         CCP_HIP(hipEventRecord(g->ev_comm, g->stream_comm));
         CCP_HIP(hipStreamWaitEvent(g->stream, g->ev_comm, 0));
         g->exchanges++;
@@ -2116,6 +2118,88 @@ try {
         if (10.0 > epsilon) {
             CCP_TRY(sweep_rowblocked(g, max_iteration));
             cnt = max_iteration;
+        }
+    } else if (g->fuse && !(getenv("CCP_GS_ROWBLOCK_CHECKED_FUSED") && atoi(getenv("CCP_GS_ROWBLOCK_CHECKED_FUSED")) == 0)) {
+        // The rule after every check_every-th sweep at the speed of the temporally blocked pass: a checked pass reports the
+        // step of each of its sweeps (as ccp_grid_gauss_seidel does on one block); the blocks' sums are all-reduced and
+        // every rank takes the same decisions.  A channel freezes at the sweep its rule fired at (re-run from the pass's
+        // input for the missing sweeps when that sweep lies inside a pass), exactly as on one block.
+        SolveState host{};
+        for (int ch = 0; ch < C; ++ch) {
+            host.active[ch] = 1;
+            host.last_eps[ch] = 10.0;
+        }
+        CCP_HIP(hipMemcpyAsync(g->state.p, &host, sizeof(host), hipMemcpyHostToDevice, g->stream));
+        const size_t elems = (size_t)g->geom.ch_stride * C;
+        if (!g->x_alt.p) {
+            CCP_TRY(g->x_alt.alloc(elems));
+            CCP_HIP(hipMemsetAsync(g->x_alt.p, 0, elems * sizeof(double), g->stream));
+        }
+        if (!g->redo_mask.p) CCP_TRY(g->redo_mask.alloc(kMaxChannels));
+        if (!g->sweep_sums.p) CCP_TRY(g->sweep_sums.alloc((size_t)kFusedMaxCheckedT * kMaxChannels));
+        const int *active = reinterpret_cast<const int *>(g->state.p);
+        const size_t plane = (size_t)g->geom.ch_stride * sizeof(double);
+        const bool shrinking = g->shrink_top || g->shrink_bottom;
+        const int max_checked = g->masked ? kMaskedMaxCheckedT : kFusedMaxCheckedT;
+        double *cur = g->x.p, *alt = g->x_alt.p;
+        int was_active[kMaxChannels];
+        for (int ch = 0; ch < C; ++ch) was_active[ch] = 1;
+        bool any_active = (10.0 > epsilon) && max_iteration > 0;
+        int k0 = 0;
+        while (any_active && k0 < max_iteration) {
+            // the ghost rows left decide how deep the pass may be; none left: refresh them in the buffer the iterate is in
+            if (nb && shrinking && g->half_sweeps_since_refresh + 2 > g->desc.ghost) CCP_TRY(exchange(g, false, cur));
+            int T = std::min(max_checked, max_iteration - k0);
+            if (shrinking) T = std::min(T, (g->desc.ghost - g->half_sweeps_since_refresh) / 2);
+            if (T < 1) return CCP_ERR_STATE;
+            const int since0 = g->half_sweeps_since_refresh;
+            long blocks[2] = {0, 0};
+            CCP_TRY(launch_fused(g, T, cur, alt, active, 2, blocks));
+            hipLaunchKernelGGL(k_sweep_sums, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
+                               g->partial.p + g->partial_region, blocks[1], T, g->sweep_sums.p);
+            CCP_HIP(hipGetLastError());
+            CCP_RCCL(api->AllReduce(g->sweep_sums.p, g->sweep_sums.p, (size_t)T * C, ncclDouble, ncclSum, g->comm->comm, g->stream));
+            hipLaunchKernelGGL(k_decide_sums, dim3(1), dim3(64), 0, g->stream, g->sweep_sums.p, C, T, k0 + 1, check_every, epsilon, g->state.p);
+            CCP_HIP(hipGetLastError());
+            CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));
+            CCP_HIP(hipStreamSynchronize(g->stream));
+            const int since1 = g->half_sweeps_since_refresh;
+            any_active = false;
+            for (int ch = 0; ch < C; ++ch) {
+                any_active |= host.active[ch] != 0;
+                if (!was_active[ch] || host.active[ch]) continue;
+                was_active[ch] = 0;                                   // stopped inside this pass
+                const int m = host.iterations[ch] - k0;               // sweeps of the pass it wanted: 1..T
+                double *have = alt;
+                if (m < T) {
+                    int mask[kMaxChannels] = {0};
+                    mask[ch] = 1;
+                    CCP_HIP(hipMemcpyAsync(g->redo_mask.p, mask, sizeof(mask), hipMemcpyHostToDevice, g->stream));
+                    g->half_sweeps_since_refresh = since0;           // the re-run starts where the pass started
+                    double *p = cur, *q = alt;
+                    for (int left = m; left > 0;) {
+                        const int t = std::min(left, g->masked ? kMaskedMaxT : kFusedMaxT);
+                        CCP_TRY(launch_fused(g, t, p, q, g->redo_mask.p));
+                        std::swap(p, q);
+                        left -= t;
+                    }
+                    CCP_HIP(hipStreamSynchronize(g->stream));          // `mask` lives on this stack frame
+                    g->half_sweeps_since_refresh = since1;
+                    have = p;
+                }
+                // a frozen channel is never touched again: keep its result in BOTH buffers
+                double *other = (have == cur) ? alt : cur;
+                CCP_HIP(hipMemcpyAsync(other + (size_t)ch * g->geom.ch_stride, have + (size_t)ch * g->geom.ch_stride, plane,
+                                       hipMemcpyDeviceToDevice, g->stream));
+            }
+            k0 += T;
+            std::swap(cur, alt);
+        }
+        if (cur != g->x.p) CCP_HIP(hipMemcpyAsync(g->x.p, cur, elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+        cnt = k0;
+        for (int ch = 0; ch < C; ++ch) {
+            eps[ch] = host.last_eps[ch];
+            stop_at[ch] = host.converged[ch] ? host.iterations[ch] : 0;
         }
     } else {
         // `while (eps > epsilon && cnt < max_iteration)` (sparse-matrix.h:356) with the step summed over all blocks

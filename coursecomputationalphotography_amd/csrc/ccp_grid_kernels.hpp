@@ -302,6 +302,45 @@ k_check_multi(const double *__restrict__ partial0, long blocks0, const double *_
     }
 }
 
+// The two halves of k_check_multi for a row block: the block's step sums of every sweep of a checked pass
+// (sums[t*channels + ch], all-reduced over the ranks by the caller), then the rule on the summed values.
+__global__ void __launch_bounds__(kBlock)
+k_sweep_sums(const double *__restrict__ partial0, long blocks0, const double *__restrict__ partial1, long blocks1, int T,
+             double *__restrict__ sums)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int ch = blockIdx.x;
+    const int channels = gridDim.x;
+    for (int t = 0; t < T; ++t) {
+        double acc = 0.0;
+        const double *__restrict__ p = partial0 + ((long)t * channels + ch) * blocks0;
+        for (long i = threadIdx.x; i < blocks0; i += kBlock) acc += p[i];
+        const double *__restrict__ q = partial1 + ((long)t * channels + ch) * blocks1;
+        for (long i = threadIdx.x; i < blocks1; i += kBlock) acc += q[i];
+        const double eps = block_sum(acc, scratch);
+        if (threadIdx.x == 0) sums[t * channels + ch] = eps;
+        __syncthreads();
+    }
+}
+
+__global__ void k_decide_sums(const double *__restrict__ sums, int channels, int T, int first_sweep_index, int every, double epsilon,
+                              SolveState *__restrict__ st)
+{
+    const int ch = threadIdx.x;
+    if (ch >= channels) return;
+    for (int t = 0; t < T; ++t) {
+        if ((first_sweep_index + t) % every != 0) continue;
+        if (!st->active[ch]) break;
+        const double eps = sums[t * channels + ch];
+        st->last_eps[ch] = eps;
+        if (!(eps > epsilon)) {
+            st->active[ch] = 0;
+            st->converged[ch] = 1;
+            st->iterations[ch] = first_sweep_index + t;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // SpMV-shaped kernels on the same layout.  One thread per CPT half-columns of one (row, colour).
 // MODE 0: b := A x (applyToVector).  MODE 1: partial sums of (b - A x)^2 and b^2 (residual).

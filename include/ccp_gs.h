@@ -377,8 +377,10 @@ int ccp_grid_exchange_halos(ccp_grid *g);
 int ccp_grid_sweep_rowblocked(ccp_grid *g, int32_t iterations);
 /* SparseMatrix::gaussSeidel's loop (sparse-matrix.h:350-380) on the partitioned system: the L1 step of a
  * checked sweep is all-reduced, so every rank takes the same decision.  check_every as for
- * ccp_grid_gauss_seidel.  With several channels all of them run until the last one has met the rule (each
- * report carries the sweep at which ITS rule fired first). */
+ * ccp_grid_gauss_seidel, and at its speed: checked temporally blocked passes report the step of each of their
+ * sweeps, the blocks' sums are all-reduced once per pass, and a channel freezes at the sweep ITS rule fired at
+ * (every channel's result equals the one-block solve's).  CCP_GS_ROWBLOCK_CHECKED_FUSED=0: the round-2 loop (one
+ * in-place sweep per check; all channels run until the last one has met the rule). */
 int ccp_grid_gauss_seidel_rowblocked(ccp_grid *g, double epsilon, int32_t max_iteration, int32_t check_every,
                                      ccp_gs_report *report);
 /* SparseMatrix::conjugateGradient (sparse-matrix.h:396-434; the solver the blend call sites use) on the partitioned

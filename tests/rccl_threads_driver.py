@@ -168,7 +168,8 @@ def case_stop_rule(c):
     return {"ok": True, "iterations_one_block": its_w, "iterations_oracle": [int(k) for k in its_o],
             "iterations_ranks": [[t[1] for t in o[1]] for o in out], "converged": [[t[0] for t in o[1]] for o in out],
             "step_ranks": [[t[2] for t in o[1]] for o in out], "step_one_block": [r.last_l1_step for r in reps_w],
-            "last_channel_bit_identical": bool(np.array_equal(got_last, want[last]))}
+            "last_channel_bit_identical": bool(np.array_equal(got_last, want[last])),
+            "all_channels_bit_identical": bool(all(np.array_equal(np.concatenate([o[0][ch] for o in out]), want[ch]) for ch in range(len(scale))))}
 
 
 def case_grid_cg(c):

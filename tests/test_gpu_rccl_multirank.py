@@ -89,6 +89,9 @@ def test_owned_rows_equal_one_block_with_overlap_on_and_off(fake_env):
 def test_all_reduced_stop_rule_stops_at_the_references_sweep(fake_env):
     cases = [{"kind": "stop_rule", "world": w, "W": 96, "H": 80, "ghost": g, "eps": 0.5} for w, g in ((2, 8), (3, 4), (4, 2))]
     cases += [{"kind": "stop_rule", "mask": True, "discs": 12, "world": w, "W": 160, "H": 120, "ghost": g, "eps": 5.0} for w, g in ((2, 8), (3, 2))]
+    # deep checked passes (ghost 16-32: depth 8), three channels that stop at different sweeps inside different passes
+    cases += [{"kind": "stop_rule", "world": w, "W": 200, "H": 144, "ghost": g, "eps": 0.5, "scale": [1e-3, 3e-4, 2e-5]} for w, g in ((2, 32), (3, 16), (4, 20))]
+    cases += [{"kind": "stop_rule", "mask": True, "discs": 12, "world": 2, "W": 200, "H": 160, "ghost": 24, "eps": 5.0, "scale": [1e-3, 1e-4]}]
     for r in drive(fake_env, cases):
         assert r["ok"], r
         want = r["iterations_one_block"]
@@ -96,6 +99,7 @@ def test_all_reduced_stop_rule_stops_at_the_references_sweep(fake_env):
         for its, conv in zip(r["iterations_ranks"], r["converged"]):
             assert its == want and all(c == 1 for c in conv), r
         assert r["last_channel_bit_identical"], r["case"]
+        assert r["all_channels_bit_identical"], r["case"]     # (a channel freezes at its own stop sweep, as on one block)
         for steps in r["step_ranks"]:                         # the all-reduced step: equal on every rank, equal up to summation order
             assert steps == r["step_ranks"][0]
             assert np.allclose(steps, r["step_one_block"], rtol=1e-10, atol=0.0)
