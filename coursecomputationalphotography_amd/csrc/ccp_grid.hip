@@ -2146,6 +2146,9 @@ try {
         for (int ch = 0; ch < C; ++ch) was_active[ch] = 1;
         bool any_active = (10.0 > epsilon) && max_iteration > 0;
         int k0 = 0;
+        // every rank enters with fresh ghost rows: the depth of a pass follows from the ghost rows left, and the ranks must
+        // agree on it (the all-reduce below carries T * C values)
+        if (any_active && nb) CCP_TRY(exchange(g, false, cur));
         while (any_active && k0 < max_iteration) {
             // the ghost rows left decide how deep the pass may be; none left: refresh them in the buffer the iterate is in
             if (nb && shrinking && g->half_sweeps_since_refresh + 2 > g->desc.ghost) CCP_TRY(exchange(g, false, cur));
