@@ -276,3 +276,28 @@ def test_csr_row_blocks_random_partitions(fake_env):
         assert r["bit_identical_to_one_gpu"] and r["bit_identical_to_oracle"] and r["spmv_bit_identical"], c
         assert r["residual_close"] and r["residual_same_on_all_ranks"], c
         assert r["iterations_ranks"] == [c["iters"]] * c["world"] and r["own_colours_ok"], r
+
+
+def test_row_blocked_stop_rule_random_shapes(fake_env):
+    """The checked blocked passes of the row-blocked solve on random shapes, ghost depths, channel counts and scales: every
+    channel stops where the one-block solve (and the oracle) stops and holds its iterate."""
+    rng = np.random.Generator(np.random.MT19937(777))
+    cases = []
+    for k in range(14):
+        world = int(rng.integers(2, 5))
+        ghost = int(rng.choice([2, 4, 6, 8, 12, 16, 24, 32]))
+        H = int(rng.integers(world * max(ghost, 8), world * max(ghost, 8) + 120))
+        W = int(rng.integers(40, 300))
+        nch = int(rng.integers(1, 4))
+        scale = [float(10.0 ** rng.uniform(-5.0, -2.7)) for _ in range(nch)]
+        cases.append({"kind": "stop_rule", "world": world, "W": W, "H": H, "ghost": ghost, "eps": float(rng.choice([0.5, 0.05, 2.0])),
+                      "scale": scale, "mask": bool(k % 3 == 2), "discs": 10})
+    for r in drive(fake_env, cases):
+        c = r["case"]
+        assert r["ok"], r
+        want = r["iterations_one_block"]
+        if not c["mask"]:
+            assert want == r["iterations_oracle"], r
+        for its, conv in zip(r["iterations_ranks"], r["converged"]):
+            assert its == want, r
+        assert r["all_channels_bit_identical"], c
