@@ -190,10 +190,10 @@ k_cg_axpy_final(double *__restrict__ x, const double *__restrict__ p0, const dou
 }
 
 // `apply(x, r, p_in, p_out, ap, &n_partials)` enqueues A(k); n is even (whole colour half-rows).
-template <typename Spmv, typename Apply>
+template <typename Spmv, typename Apply, typename Sums>
 int cg_solve_fused(Spmv &&spmv, Apply &&apply, const double *b, double *x, double *r, double *p0, double *p1, double *ap, long n,
                    double epsilon, int max_iteration, CgState *st_dev, double *partial, hipStream_t stream, hipEvent_t ev0,
-                   hipEvent_t ev1, ccp_gs_report *report)
+                   hipEvent_t ev1, ccp_gs_report *report, Sums &&sums, bool every_rank_iterates = false)
 {
     const int blocks = (int)std::max<long>(1, std::min<long>(2048, (n + kBlock - 1) / kBlock));
     CgState host{};
@@ -202,19 +202,27 @@ int cg_solve_fused(Spmv &&spmv, Apply &&apply, const double *b, double *x, doubl
     CCP_HIP(hipEventRecord(ev0, stream));
     CCP_TRY(spmv(x, r));                                                     // r = A x      (:406)
     hipLaunchKernelGGL(k_cg_init, dim3(blocks), dim3(kBlock), 0, stream, b, r, p0, n, partial);   // r = b - r, p = r
-    hipLaunchKernelGGL(k_cg_set_rlen, dim3(1), dim3(kBlock), 0, stream, partial, blocks, st_dev);
+    int count = blocks;
+    const double *sum_at = partial;
+    CCP_TRY(sums(partial, &count, &sum_at, 0));
+    hipLaunchKernelGGL(k_cg_set_rlen, dim3(1), dim3(kBlock), 0, stream, sum_at, count, st_dev);
     CCP_HIP(hipGetLastError());
     int issued = 0;
-    bool active = max_iteration > 0 && n > 0;
+    bool active = max_iteration > 0 && (n > 0 || every_rank_iterates);
     while (active && issued < max_iteration) {
         const int batch = std::min(16, max_iteration - issued);
         for (int k = issued + 1; k <= issued + batch; ++k) {
             int dot_blocks = 0;
             double *p_in = (k & 1) ? p0 : p1, *p_out = (k & 1) ? p1 : p0;    // iteration k reads buffer (k-1)&1, writes k&1
             CCP_TRY(apply(x, r, p_in, p_out, ap, &dot_blocks));
-            hipLaunchKernelGGL(k_cg_alpha_fused, dim3(1), dim3(kBlock), 0, stream, partial, dot_blocks, k, st_dev);
+            sum_at = partial;
+            CCP_TRY(sums(partial, &dot_blocks, &sum_at, 0));
+            hipLaunchKernelGGL(k_cg_alpha_fused, dim3(1), dim3(kBlock), 0, stream, sum_at, dot_blocks, k, st_dev);
             hipLaunchKernelGGL(k_cg_residual, dim3(blocks), dim3(kBlock), 0, stream, r, ap, n, partial, st_dev);
-            hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(kBlock), 0, stream, partial, blocks, epsilon, st_dev);
+            count = blocks;
+            sum_at = partial;
+            CCP_TRY(sums(partial, &count, &sum_at, 0));
+            hipLaunchKernelGGL(k_cg_beta, dim3(1), dim3(kBlock), 0, stream, sum_at, count, epsilon, st_dev);
         }
         CCP_HIP(hipGetLastError());
         issued += batch;
@@ -236,6 +244,15 @@ int cg_solve_fused(Spmv &&spmv, Apply &&apply, const double *b, double *x, doubl
         report->seconds = ms * 1e-3;
     }
     return CCP_OK;
+}
+
+template <typename Spmv, typename Apply>
+int cg_solve_fused(Spmv &&spmv, Apply &&apply, const double *b, double *x, double *r, double *p0, double *p1, double *ap, long n,
+                   double epsilon, int max_iteration, CgState *st_dev, double *partial, hipStream_t stream, hipEvent_t ev0,
+                   hipEvent_t ev1, ccp_gs_report *report)
+{
+    return cg_solve_fused(spmv, apply, b, x, r, p0, p1, ap, n, epsilon, max_iteration, st_dev, partial, stream, ev0, ev1, report,
+                          [](double *, int *, const double **, int) { return (int)CCP_OK; });
 }
 
 // The loop.  `spmv(in, out)` enqueues out := A in on `stream` (all device pointers);

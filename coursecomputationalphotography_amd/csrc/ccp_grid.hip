@@ -1741,10 +1741,11 @@ try {
         auto apply = [&](double *xv, const double *rv, const double *p_in, double *p_out, double *apv, int *n_partials) -> int {
             if (fused_mode != 2) {
                 if (g->masked)
-                    hipLaunchKernelGGL((k_cg_apply_march<true>), mgrid, dim3(kBlock), 0, s, xv, rv, p_in, p_out, apv, geo, march_rows, g->partial.p, g->maskp.p, g->cg_state.p);
+                    hipLaunchKernelGGL((k_cg_apply_march<true>), mgrid, dim3(kBlock), 0, s, xv, rv, p_in, p_out, apv, geo, march_rows, g->partial.p, g->maskp.p, g->cg_state.p,
+                                       0, geo.local_rows);
                 else
                     hipLaunchKernelGGL((k_cg_apply_march<false>), mgrid, dim3(kBlock), 0, s, xv, rv, p_in, p_out, apv, geo, march_rows, g->partial.p,
-                                       static_cast<const unsigned char *>(nullptr), g->cg_state.p);
+                                       static_cast<const unsigned char *>(nullptr), g->cg_state.p, 0, geo.local_rows);
                 *n_partials = (int)(mgrid.x * mgrid.y);
                 return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
             }
@@ -2318,9 +2319,35 @@ try {
             *n_partials = 0;                             // (the loop runs its own dot pass over the owned range)
             return spmv(in_own, out_own);
         };
-        CCP_TRY(cg_solve(spmv, spmv_dot, g->b.p + (long)ch * n + off, g->x.p + (long)ch * n + off, g->cg_r.p + off, g->cg_p.p + off,
-                         g->cg_ap.p + off, n_own, epsilon, max_iteration, g->cg_state.p, g->partial.p, s, g->ev0, g->ev1,
-                         report ? report + ch : nullptr, sums, true));
+        const int fused_mode = getenv("CCP_GS_CG_FUSED") ? atoi(getenv("CCP_GS_CG_FUSED")) : 1;
+        if (fused_mode == 0) {
+            CCP_TRY(cg_solve(spmv, spmv_dot, g->b.p + (long)ch * n + off, g->x.p + (long)ch * n + off, g->cg_r.p + off, g->cg_p.p + off,
+                             g->cg_ap.p + off, n_own, epsilon, max_iteration, g->cg_state.p, g->partial.p, s, g->ev0, g->ev1,
+                             report ? report + ch : nullptr, sums, true));
+            continue;
+        }
+        // the fused loop (72 B per unknown and iteration, ccp_cg.hpp): pass A recomputes the direction of a row's
+        // neighbours from r and the previous direction, so BOTH travel — one row of each per neighbour and iteration
+        CCP_HIP(hipMemsetAsync(g->cg_p2.p, 0, sizeof(double) * n, s));
+        const int march_rows = 32;
+        const int own_rows = geo.own_hi - geo.own_lo;
+        const dim3 mgrid((unsigned)((geo.pitch + 2L * kBlock - 1) / (2L * kBlock)), (unsigned)((own_rows + march_rows - 1) / march_rows));
+        auto apply = [&](double *xv_own, const double *rv_own, const double *p_in_own, double *p_out_own, double *apv_own, int *n_partials) -> int {
+            double *rv = const_cast<double *>(rv_own) - off, *p_in = const_cast<double *>(p_in_own) - off;
+            CCP_TRY(fetch_rows(rv));
+            CCP_TRY(fetch_rows(p_in));
+            if (g->masked)
+                hipLaunchKernelGGL((k_cg_apply_march<true>), mgrid, dim3(kBlock), 0, s, xv_own - off, rv, p_in, p_out_own - off, apv_own - off, geo, march_rows,
+                                   g->partial.p, g->maskp.p, g->cg_state.p, geo.own_lo, geo.own_hi);
+            else
+                hipLaunchKernelGGL((k_cg_apply_march<false>), mgrid, dim3(kBlock), 0, s, xv_own - off, rv, p_in, p_out_own - off, apv_own - off, geo, march_rows,
+                                   g->partial.p, static_cast<const unsigned char *>(nullptr), g->cg_state.p, geo.own_lo, geo.own_hi);
+            *n_partials = (int)(mgrid.x * mgrid.y);
+            return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
+        };
+        CCP_TRY(cg_solve_fused(spmv, apply, g->b.p + (long)ch * n + off, g->x.p + (long)ch * n + off, g->cg_r.p + off, g->cg_p.p + off,
+                               g->cg_p2.p + off, g->cg_ap.p + off, n_own, epsilon, max_iteration, g->cg_state.p, g->partial.p, s, g->ev0,
+                               g->ev1, report ? report + ch : nullptr, sums, true));
     }
     // the ghost rows of x are stale now: the next sweep needs an exchange first
     g->half_sweeps_since_refresh = g->desc.ghost;

@@ -104,18 +104,20 @@ k_cg_apply_fused(double *__restrict__ x, const double *__restrict__ r, const dou
 // half-columns comes from the adjacent lane (one shuffle per side and row); the two edge lanes of a wave compute it
 // from r and p_old themselves.  Same arithmetic per element; the partial sums of p'Ap are grouped differently, so
 // alpha may differ from the row-per-block kernel's in the last bit.
-// grid = (ceil(pitch / (kBlock*2)), ceil(local_rows / rows_per_block)); one channel (the caller offsets the pointers).
+// grid = (ceil(pitch / (kBlock*2)), ceil((row_end - row_first) / rows_per_block)); one channel (the caller offsets the pointers).
 template <bool MASKED>
 __global__ void __launch_bounds__(kBlock)
 k_cg_apply_march(double *__restrict__ x, const double *__restrict__ r, const double *__restrict__ p_old, double *__restrict__ p_new,
                  double *__restrict__ ap, Geom g, int rows_per_block, double *__restrict__ partial, const unsigned char *__restrict__ mask,
-                 const CgState *__restrict__ st)
+                 const CgState *__restrict__ st, int row_first, int row_end)
 {
+    // rows [row_first, row_end) are updated (a row block: its owned rows; the rows next to them are read from the ghost
+    // rows, which the caller has fetched from the neighbours for r and p_old)
     constexpr int CPT = 2;
     __shared__ double scratch[kBlock / kWave];
     const int j0 = (blockIdx.x * kBlock + threadIdx.x) * CPT;
     const int lane = (int)(threadIdx.x & (kWave - 1));
-    const int l_lo = blockIdx.y * rows_per_block, l_hi = min(l_lo + rows_per_block, g.local_rows);
+    const int l_lo = row_first + blockIdx.y * rows_per_block, l_hi = min(l_lo + rows_per_block, row_end);
     double dot = 0.0;
     if (st->active) {                                             // (uniform)
         const double alpha = st->alpha, beta = st->beta;

@@ -385,8 +385,8 @@ int ccp_grid_gauss_seidel_rowblocked(ccp_grid *g, double epsilon, int32_t max_it
                                      ccp_gs_report *report);
 /* SparseMatrix::conjugateGradient (sparse-matrix.h:396-434; the solver the blend call sites use) on the partitioned
  * system, from the x the blocks hold: every rank runs the loop on its owned rows; before every product with A the
- * direction's rows next to the block come from the neighbours (one image row each way), every dot product is
- * all-reduced.  Iterates equal the one-block loop's to rounding; a solve that stops stops at the same iteration on
+ * direction's rows next to the block come from the neighbours (one image row each way; in the default fused loop one row
+ * of the residual as well), every dot product is all-reduced.  Iterates equal the one-block loop's to rounding; a solve that stops stops at the same iteration on
  * every rank.  Needs ghost >= 1; works for Dirichlet-mask grids too.  Afterwards the ghost rows of x are stale (the
  * next rowblocked sweep refreshes them).  report: one per channel, as ccp_grid_conjugate_gradient.  Collective. */
 int ccp_grid_conjugate_gradient_rowblocked(ccp_grid *g, double epsilon, int32_t max_iteration, ccp_gs_report *report);

@@ -224,6 +224,14 @@ def test_world1_csr_row_block_and_mask_grid_through_real_rccl(capi, monkeypatch)
     got_rep = g.conjugate_gradient_rowblocked(1e-30, 20)[0]
     assert (got_rep.iterations, got_rep.converged) == (want_rep.iterations, want_rep.converged) == (20, 0)
     assert np.allclose(g.get_x(0), ref.get_x(0), rtol=1e-11, atol=1e-9)
+    # ... and the fused 72-byte loop (default) on the one-rank communicator against the one-block fused loop
+    monkeypatch.delenv("CCP_GS_CG_FUSED")
+    for h in (ref, g):
+        h.fill_x(0.0)
+    want_rep = ref.conjugate_gradient(1e-30, 20)[0]
+    got_rep = g.conjugate_gradient_rowblocked(1e-30, 20)[0]
+    assert got_rep.iterations == want_rep.iterations == 20
+    assert np.allclose(g.get_x(0), ref.get_x(0), rtol=1e-11, atol=1e-9)
     blk2 = capi.CsrMatrix().upload_rows(comm, 0, n, v, col, rowp[:-1], np.diff(rowp), colour, 2)
     one2 = capi.CsrMatrix().upload_compressed(v, col, rowp)
     xa, ra = blk2.conjugate_gradient(b, 1e-30, 20)
