@@ -2723,6 +2723,22 @@ try {
     if (!m->uploaded) return CCP_ERR_STATE;
     CCP_TRY(flush_edits(m));
     if (m->rb.on ? (m->rb.n_local && (!in || !out)) : ((m->n_cols && !in) || (m->n_rows && !out))) return CCP_ERR_BAD_ARG;
+    if (!m->rb.on && m->allow_structured && m->n_rows == m->n_cols) {
+        // SolveChannel's matrix: b := A x matrix-free on the grid twin (the row's products in the stored order: same bits)
+        // instead of a sliced-ELL image of the whole matrix (16 GB at 16384^2) that only this call would need
+        detect_poisson(m);
+        if (m->poisson_w > 1 && m->poisson_h > 1) {
+            if (!m->grid) {
+                ccp_grid_desc d{m->poisson_w, m->poisson_h, 1, 0, m->poisson_h, 0, m->device, 0};
+                CCP_TRY(ccp_grid_create(&d, &m->grid));
+                (void)grid_set_allow_swap(m->grid, true);
+            }
+            CCP_TRY(ccp_grid_set_stream(m->grid, m->stream));
+            CCP_TRY(ccp_grid_set_x_host(m->grid, 0, in, 0, m->poisson_h));
+            CCP_TRY(ccp_grid_b_from_x(m->grid));
+            return ccp_grid_get_b_host(m->grid, 0, out, 0, m->poisson_h);
+        }
+    }
     CCP_TRY(ensure_natural(m));
     hipStream_t s = m->stream;
     const bool rowblock = m->rb.on;        // in / out: the block's own rows; the ghosts of `in` come from their owners
@@ -2751,6 +2767,24 @@ try {
     if (!m->uploaded) return CCP_ERR_STATE;
     CCP_TRY(flush_edits(m));
     if (!rr || !bb || ((!b || !x) && !(m->rb.on && m->rb.n_local == 0))) return CCP_ERR_BAD_ARG;
+    if (!m->rb.on && m->allow_structured && m->n_rows == m->n_cols && m->n_rows > 0) {
+        detect_poisson(m);                   // (as ccp_csr_apply_to_vector: matrix-free on the grid twin)
+        if (m->poisson_w > 1 && m->poisson_h > 1) {
+            if (!m->grid) {
+                ccp_grid_desc d{m->poisson_w, m->poisson_h, 1, 0, m->poisson_h, 0, m->device, 0};
+                CCP_TRY(ccp_grid_create(&d, &m->grid));
+                (void)grid_set_allow_swap(m->grid, true);
+            }
+            CCP_TRY(ccp_grid_set_stream(m->grid, m->stream));
+            CCP_TRY(ccp_grid_set_b_host(m->grid, 0, b, 0, m->poisson_h));
+            CCP_TRY(ccp_grid_set_x_host(m->grid, 0, x, 0, m->poisson_h));
+            double both[2] = {0.0, 0.0};
+            CCP_TRY(ccp_grid_residual_norm2(m->grid, both));
+            *rr = both[0];
+            *bb = both[1];
+            return CCP_OK;
+        }
+    }
     CCP_TRY(ensure_natural(m));
     hipStream_t s = m->stream;
     *rr = 0.0;

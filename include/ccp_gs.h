@@ -152,7 +152,9 @@ int ccp_csr_conjugate_gradient(ccp_csr *m, const double *b, const double *init, 
 int ccp_csr_conjugate_gradient_jacobi(ccp_csr *m, const double *b, double *x_out, double epsilon,
                                       int32_t max_iteration, ccp_gs_report *report);
 
-/* SparseMatrix::applyToVector(in, out) (sparse-matrix.h:382-393). in: n_cols, out: n_rows. */
+/* SparseMatrix::applyToVector(in, out) (sparse-matrix.h:382-393). in: n_cols, out: n_rows.  SolveChannel's matrix is
+ * applied matrix-free on the grid kernels (the row's products in the stored order: same bits; no image of the matrix is
+ * built for it); so is its residual below. */
 int ccp_csr_apply_to_vector(ccp_csr *m, const double *in, double *out);
 
 /* sum (b - A x)^2 and sum b^2 (applyToVector + vecsub + veclen2, sparse-matrix.h:51-55,75-79). */

@@ -349,3 +349,27 @@ def test_multicolour_iterates_equal_oracle_with_the_exported_colouring(capi, orc
         assert e.status == 6
     m2.close()
     m.close()
+
+
+def test_apply_and_residual_of_the_poisson_matrix_need_no_image(capi, orc, monkeypatch):
+    """applyToVector / the residual on SolveChannel's matrix run matrix-free on the grid twin: the stored-order products
+    (bit-identical to the oracle's applyToVector and to the sliced-ELL kernel), and no image of the matrix is built."""
+    from coursecomputationalphotography_amd import synth
+    W, H = 301, 187
+    v, c, r = synth.poisson_csr(W, H)
+    xv = synth.x_true(W * H, 5)
+    om = orc.from_csr(v, c, r)
+    want = om.apply_to_vector(xv)
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    got = m.apply_to_vector(xv)
+    assert np.array_equal(got, want)
+    b = want + 0.25
+    rr, bb = m.residual_norm2(b, xv)
+    assert np.isclose(rr, 0.0625 * W * H, rtol=1e-6, atol=0.0) and np.isclose(bb, float(np.dot(b, b)), rtol=1e-12, atol=0.0)
+    assert m.edit_stats()["image_uploads"] == 0
+    m.close()
+    monkeypatch.setenv("CCP_GS_STRUCTURED", "0")                     # the stored-matrix kernel: same bits
+    m2 = capi.CsrMatrix().upload_compressed(v, c, r)
+    assert np.array_equal(m2.apply_to_vector(xv), want)
+    assert m2.edit_stats()["image_uploads"] >= 1
+    m2.close()
