@@ -2738,6 +2738,24 @@ try {
             CCP_TRY(ccp_grid_b_from_x(m->grid));
             return ccp_grid_get_b_host(m->grid, 0, out, 0, m->poisson_h);
         }
+        if (m->allow_region && m->region_state > 0 && m->region_grid && !m->edited) {
+            // a raster-region Laplacian a solve has already recognised: b := A x on its canvas (Dirichlet-mask grid)
+            const long n = m->n_rows;
+            hipStream_t s = m->stream;
+            ccp_grid *g = m->region_grid;
+            CCP_TRY(ccp_grid_set_stream(g, s));
+            ccp_grid_layout lay{};
+            CCP_TRY(ccp_grid_get_layout(g, &lay));
+            CCP_HIP(hipMemcpyAsync(m->tmp.p, in, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL((k_canvas_move<0>), dim3(blocks_for(n)), dim3(kBlock), 0, s, static_cast<double *>(lay.x_dev), m->tmp.p, m->region_where.p, n, 0.0);
+            CCP_HIP(hipGetLastError());
+            CCP_TRY(ccp_grid_b_from_x(g));
+            hipLaunchKernelGGL((k_canvas_move<1>), dim3(blocks_for(n)), dim3(kBlock), 0, s, static_cast<double *>(lay.b_dev), m->tmp.p, m->region_where.p, n, 0.0);
+            CCP_HIP(hipGetLastError());
+            CCP_HIP(hipMemcpyAsync(out, m->tmp.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
+            CCP_HIP(hipStreamSynchronize(s));
+            return CCP_OK;
+        }
     }
     CCP_TRY(ensure_natural(m));
     hipStream_t s = m->stream;
@@ -2780,6 +2798,26 @@ try {
             CCP_TRY(ccp_grid_set_x_host(m->grid, 0, x, 0, m->poisson_h));
             double both[2] = {0.0, 0.0};
             CCP_TRY(ccp_grid_residual_norm2(m->grid, both));
+            *rr = both[0];
+            *bb = both[1];
+            return CCP_OK;
+        }
+        if (m->allow_region && m->region_state > 0 && m->region_grid && !m->edited) {
+            const long n = m->n_rows;
+            hipStream_t s = m->stream;
+            ccp_grid *g = m->region_grid;
+            CCP_TRY(ccp_grid_set_stream(g, s));
+            ccp_grid_layout lay{};
+            CCP_TRY(ccp_grid_get_layout(g, &lay));
+            CCP_HIP(hipMemcpyAsync(m->tmp.p, b, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL((k_canvas_move<0>), dim3(blocks_for(n)), dim3(kBlock), 0, s, static_cast<double *>(lay.b_dev), m->tmp.p, m->region_where.p, n, 0.0);
+            CCP_HIP(hipGetLastError());
+            CCP_HIP(hipStreamSynchronize(s));            // (tmp is staged twice)
+            CCP_HIP(hipMemcpyAsync(m->tmp.p, x, sizeof(double) * n, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL((k_canvas_move<0>), dim3(blocks_for(n)), dim3(kBlock), 0, s, static_cast<double *>(lay.x_dev), m->tmp.p, m->region_where.p, n, 0.0);
+            CCP_HIP(hipGetLastError());
+            double both[2] = {0.0, 0.0};
+            CCP_TRY(ccp_grid_residual_norm2(g, both));
             *rr = both[0];
             *bb = both[1];
             return CCP_OK;

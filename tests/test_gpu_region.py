@@ -215,4 +215,9 @@ def test_chained_solves_of_any_pass_parity_on_one_handle(capi, orc):
     got2, _ = m.gauss_seidel(b, 0.0, 11, x0=got, check_every=0)                       # back to the colour order: 2 passes
     want2, _, _ = orc.multicolour_gauss_seidel(v, c, r, colour, b, 0.0, 11, x0=got)
     assert np.array_equal(got2, want2)
+    # b := A x and the residual of a recognised region run on its canvas too: the stored-order products, no image of the matrix
+    assert np.array_equal(m.apply_to_vector(got2), om.apply_to_vector(got2))
+    rr, bb = m.residual_norm2(b, got2)
+    assert abs(np.sqrt(rr / bb) - om.rel_residual(b, got2)) <= 1e-12
+    assert m.edit_stats()["image_uploads"] == 0
     m.close()
