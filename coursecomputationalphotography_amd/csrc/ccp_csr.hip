@@ -163,6 +163,8 @@ struct ccp_csr {
     ccp_grid *region_grid = nullptr;
     DevBuf<long> region_where;
     std::vector<int> region_colour;        // (x + y) & 1 of the embedding: the colouring the grid sweep realises
+    std::vector<int> auto_colour;          // no colouring from the caller and the matrix is a raster region: the canvas parity IS the
+                                           // library's colouring (kept for the stored-matrix path too, as long as it stays proper)
     int region_w = 0, region_h = 0;
     bool allow_region = true;              // CCP_GS_MASKED=0 keeps such matrices on the sliced-ELL path
     int region_values_ok = -1;             // every stored value is 4 (diagonal) or -1: -1 unknown, 0 no, 1 yes (compact host copy)
@@ -1088,7 +1090,7 @@ bool region_values_fit(ccp_csr *m)
 // The recognition with everything that is per unknown on the device (ccp_csr_region.hpp).  On success the region grid
 // exists with its mask set, m->region_where holds every unknown's element of the canvas planes and W, H the canvas.
 // false: not a region matrix (or a HIP failure: the caller then simply does not take the fast path).
-bool embed_region_device(ccp_csr *m, const std::vector<int> &colour, int &W, int &H)
+bool embed_region_device(ccp_csr *m, std::vector<int> &colour, int &W, int &H, bool free_parity = false)
 {
     const int n = m->n_rows;
     if (n < 1 || m->n_cols != n || !m->overlay.empty()) return false;
@@ -1114,7 +1116,10 @@ bool embed_region_device(ccp_csr *m, const std::vector<int> &colour, int &W, int
         d_run_id.alloc((size_t)n) != CCP_OK || d_left.alloc((size_t)n) != CCP_OK || d_bad.alloc(4) != CCP_OK)
         return false;
     auto hip_ok = [](hipError_t e) { return e == hipSuccess; };
-    if (!hip_ok(hipMemcpyAsync(d_colour.p, colour.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s)) ||
+    // free_parity: no colouring to honour — every piece is laid out with its first pixel on even parity and the canvas
+    // parity becomes the colouring (k_region_place writes it, it comes back below)
+    if (!hip_ok(free_parity ? hipMemsetAsync(d_colour.p, 0, sizeof(int) * (size_t)n, s)
+                            : hipMemcpyAsync(d_colour.p, colour.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, s)) ||
         !hip_ok(hipMemsetAsync(d_bad.p, 0, sizeof(int) * 4, s)))
         return false;
     lap("matrix (if not resident yet) and colours to the device");
@@ -1181,7 +1186,7 @@ bool embed_region_device(ccp_csr *m, const std::vector<int> &colour, int &W, int
     hipLaunchKernelGGL(k_fill_int, dim3(4096), dim3(kBlock), 0, s, d_ident.p, (long)W * H, -1);
     if (!hip_ok(hipMemsetAsync(d_mask.p, 0, plane, s))) return false;
     hipLaunchKernelGGL(k_region_place, dim3(blocks), dim3(kBlock), 0, s, d_run_id.p, d_run_start.p, d_x0.p, d_y0.p, d_colour.p, n, W, H, (long)lay.pitch,
-                       d_ident.p, m->region_where.p, d_mask.p, d_bad.p + 2);
+                       d_ident.p, m->region_where.p, d_mask.p, d_bad.p + 2, free_parity ? 1 : 0);
     int bad = 0;
     if (!hip_ok(hipMemcpyAsync(&bad, d_bad.p + 2, sizeof(int), hipMemcpyDeviceToHost, s)) || !hip_ok(hipStreamSynchronize(s))) return false;   // (x0, y0 die below)
     if (bad) return false;
@@ -1190,6 +1195,11 @@ bool embed_region_device(ccp_csr *m, const std::vector<int> &colour, int &W, int
     if (!hip_ok(hipMemcpyAsync(&bad, d_bad.p + 3, sizeof(int), hipMemcpyDeviceToHost, s)) || !hip_ok(hipStreamSynchronize(s))) return false;
     lap("placement, verification");
     if (bad || hipGetLastError() != hipSuccess) return false;
+    if (free_parity) {
+        colour.resize((size_t)n);
+        if (!hip_ok(hipMemcpyAsync(colour.data(), d_colour.p, sizeof(int) * (size_t)n, hipMemcpyDeviceToHost, s)) || !hip_ok(hipStreamSynchronize(s)))
+            return false;
+    }
     if (ccp_grid_set_stream(m->region_grid, s) != CCP_OK) return false;
     if (grid_set_mask_split_device(m->region_grid, d_mask.p, (long)n) != CCP_OK) return false;
     lap("mask into the grid");
@@ -1217,6 +1227,30 @@ int detect_region(ccp_csr *m, bool for_reference_order = false)
     }
     std::vector<int> colour;
     int nc = 0;
+    static const bool host_recognition = getenv("CCP_GS_REGION_HOST") && atoi(getenv("CCP_GS_REGION_HOST")) != 0;
+    if (m->user_colour.empty() && m->auto_colour.empty() && !host_recognition && m->used_colour.empty() && !m->multicolour.built) {
+        // No colouring came with the matrix (the facade's case).  A greedy colouring in row order needs a third colour
+        // on most masks whose pieces merge further down (1.1 s at 41.75 M unknowns, and the sweep then stays on the stored
+        // matrix): lay the region out first and let the canvas parity be the colouring.
+        int cw0 = 0, ch0 = 0;
+        if (embed_region_device(m, colour, cw0, ch0, true)) {
+            m->region_tuned = false;
+            m->region_solves = 0;
+            m->auto_colour = colour;
+            m->region_colour.swap(colour);
+            m->region_w = cw0;
+            m->region_h = ch0;
+            m->region_state = 1;
+            m->multicolour.reset();                      // (an image built with another colouring is not this sweep's)
+            if (getenv("CCP_GS_DEBUG"))
+                fprintf(stderr, "[ccp_gs] raster-region Laplacian without a colouring: %d unknowns on a %d x %d canvas, canvas parity taken as the colouring, %.3f s\n",
+                        m->n_rows, cw0, ch0, now_s() - t0);
+            return CCP_OK;
+        }
+        if (m->region_grid) ccp_grid_destroy(m->region_grid);
+        m->region_grid = nullptr;
+        colour.clear();
+    }
     CCP_TRY(resolve_colouring(m, colour, nc));
     bool order_only = false;
     if (nc != 2) {
@@ -1313,9 +1347,12 @@ int ensure_natural(ccp_csr *m)
 int resolve_colouring(ccp_csr *m, std::vector<int> &colour, int &nc)
 {
     const double t0 = now_s();
-    if (!m->user_colour.empty()) {
-        colour = m->user_colour;
-        nc = m->user_n_colours;
+    // (the canvas parity of a recognised region stands in for a colouring only while the matrix IS that region: once an
+    // edit has taken the region form away the library colours the rows as it would after a fresh upload of the edited matrix)
+    const bool automatic = m->user_colour.empty() && !m->auto_colour.empty() && (int)m->auto_colour.size() == m->n_rows && !m->edited;
+    if (!m->user_colour.empty() || automatic) {
+        colour = automatic ? m->auto_colour : m->user_colour;
+        nc = automatic ? 2 : m->user_n_colours;
         // a proper colouring: no stored off-diagonal entry couples two rows of one colour.  Rows edited since the
         // upload are checked in their current form (the overlay), the others in the compact host copy.
         std::atomic<int> bad{0};
@@ -1342,7 +1379,12 @@ int resolve_colouring(ccp_csr *m, std::vector<int> &colour, int &nc)
                 }
             }
         });
-        if (bad.load()) return CCP_ERR_UNSUPPORTED;
+        if (bad.load() && !automatic) return CCP_ERR_UNSUPPORTED;
+        if (bad.load()) {
+            // an edit coupled two rows of one parity: the library's own colouring starts again (greedy)
+            m->auto_colour.clear();
+            return resolve_colouring(m, colour, nc);
+        }
     } else {
         CCP_TRY(materialise(m));
         std::vector<long> lptr;
@@ -1752,6 +1794,7 @@ try {
     m->lexicographic.reset();
     m->user_colour.clear();
     m->user_n_colours = 0;
+    m->auto_colour.clear();
     m->used_colour.clear();
     m->used_n_colours = 0;
     m->overlay.clear();
@@ -2108,6 +2151,7 @@ try {
     m->multicolour.reset();
     m->user_colour.clear();
     m->user_n_colours = 0;
+    m->auto_colour.clear();
     m->used_colour.clear();
     m->used_n_colours = 0;
     m->region_state = m->edited ? 0 : -1;          // the embedding's parity follows the colouring
@@ -2225,6 +2269,9 @@ try {
     if (!m->uploaded) return CCP_ERR_STATE;
     CCP_TRY(flush_edits(m));
     if (!n_colours) return CCP_ERR_BAD_ARG;
+    // (no colouring from the caller, nothing resolved yet: a raster region takes its canvas parity — detect_region)
+    if (m->user_colour.empty() && m->allow_structured && m->allow_region && m->region_state < 0 && !m->multicolour.built && !m->rb.on)
+        CCP_TRY(detect_region(m));
     if (m->region_state == 1 && !m->multicolour.built) {          // the raster-region twin sweeps (x + y) & 1 = the resolved colouring
         *n_colours = 2;
         if (colour && m->n_rows) std::memcpy(colour, m->region_colour.data(), sizeof(int32_t) * (size_t)m->n_rows);

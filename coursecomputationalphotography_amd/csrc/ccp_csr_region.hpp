@@ -94,15 +94,17 @@ k_region_links(const int *__restrict__ up, const unsigned char *__restrict__ has
 
 // Canvas position of every unknown from its run's origin (x0, y0): identity canvas, index into the grid's colour-split
 // planes, mask byte.  Off the canvas interior or of the wrong colour parity: *bad.
+// free_parity: no colouring came with the matrix — the canvas parity BECOMES the colouring (written to colour[i]).
 __global__ void __launch_bounds__(kBlock)
 k_region_place(const int *__restrict__ run_id, const int *__restrict__ run_start, const int *__restrict__ x0, const int *__restrict__ y0,
-               const int *__restrict__ colour, int n, int W, int H, long pitch, int *__restrict__ ident, long *__restrict__ where,
-               unsigned char *__restrict__ mask_split, int *__restrict__ bad)
+               int *__restrict__ colour, int n, int W, int H, long pitch, int *__restrict__ ident, long *__restrict__ where,
+               unsigned char *__restrict__ mask_split, int *__restrict__ bad, int free_parity)
 {
     const long i = (long)blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     const int r = run_id[i] - 1;
     const int x = x0[r] + ((int)i - run_start[r]), y = y0[r];
+    if (free_parity) colour[i] = (x + y) & 1;
     if (x < 1 || y < 1 || x >= W - 1 || y >= H - 1 || ((x + y) & 1) != (colour[i] & 1)) {
         atomicOr(bad, 1);
         where[i] = 0;

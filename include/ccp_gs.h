@@ -85,8 +85,10 @@ int ccp_csr_upload(ccp_csr *m, int32_t n_rows, int32_t n_cols, int64_t n_values,
 
 /* Optional colouring for CCP_ORDER_MULTICOLOUR: colour[i] in [0,n_colours), rows of one
  * colour must not reference each other (checked: CCP_ERR_UNSUPPORTED otherwise).
- * Without it the library colours the rows itself (greedy, in row order; a 4-connected
- * raster mask gets its checkerboard). */
+ * Without it the library colours the rows itself: a matrix recognised as the Laplacian of a raster region takes
+ * the parity of its reconstructed pixel coordinates (a proper 2-colouring however the pieces of the region merge, and
+ * the sweep runs on the region grid); any other matrix is coloured greedily in row order.  ccp_csr_get_colouring
+ * exports whichever it is. */
 int ccp_csr_set_colouring(ccp_csr *m, const int32_t *colour, int32_t n_colours);
 
 /* Which kernels the last ccp_csr_gauss_seidel ran on.  The general path stores the matrix (sliced ELL);
