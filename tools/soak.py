@@ -375,6 +375,20 @@ def run_round2(n, rng, orc):
             except Exception as e:
                 bad += 1
                 print("ERROR region reference order", with_colouring, W, H, iters, repr(e), flush=True)
+        # the colour order with NO colouring from the caller (the facade's case): the canvas parity becomes the colouring
+        try:
+            m = capi.CsrMatrix().upload_compressed(v, c, r)
+            got, _ = m.gauss_seidel(b, 0.0, iters, x0=x0, check_every=0)
+            colx, ncx = m.get_colouring()
+            path = m.last_path()
+            m.close()
+            wantx, _, _ = orc.multicolour_gauss_seidel(v, c, r, colx, b, 0.0, iters, x0=x0)
+            if not np.array_equal(got, wantx) or (nn >= 4 and not path.startswith("region grid")):
+                bad += 1
+                print("MISMATCH region without a colouring", path, ncx, W, H, iters, float(np.abs(got - wantx).max()), flush=True)
+        except Exception as e:
+            bad += 1
+            print("ERROR region without a colouring", W, H, iters, repr(e), flush=True)
         if colour[0] == ((xs[0] + ys[0]) & 1):                            # the mask grid directly (its colour 0 is (x+y) even)
             os.environ["CCP_GS_TMAX"] = str(int(rng.integers(1, 8)))
             os.environ["CCP_GS_CHUNK"] = str(int(rng.integers(8, 200)))
