@@ -163,6 +163,8 @@ struct ccp_csr {
     ccp_grid *region_grid = nullptr;
     DevBuf<long> region_where;
     std::vector<int> region_colour;        // (x + y) & 1 of the embedding: the colouring the grid sweep realises
+    std::vector<int> greedy_colour;        // the library's greedy colouring of the matrix as it is now (computed once: the recognition
+    int greedy_n_colours = 0;              //    and the schedule both ask for it); cleared by every upload, colouring and edit
     std::vector<int> auto_colour;          // no colouring from the caller and the matrix is a raster region: the canvas parity IS the
                                            // library's colouring (kept for the stored-matrix path too, as long as it stays proper)
     int region_w = 0, region_h = 0;
@@ -1385,12 +1387,18 @@ int resolve_colouring(ccp_csr *m, std::vector<int> &colour, int &nc)
             m->auto_colour.clear();
             return resolve_colouring(m, colour, nc);
         }
+    } else if (!m->greedy_colour.empty() && (int)m->greedy_colour.size() == m->n_rows) {
+        colour = m->greedy_colour;
+        nc = m->greedy_n_colours;
+        return CCP_OK;
     } else {
         CCP_TRY(materialise(m));
         std::vector<long> lptr;
         std::vector<int> lidx;
         build_lower(m, lptr, lidx);
         nc = greedy_colouring(lptr, lidx, m->n_rows, colour);
+        m->greedy_colour = colour;
+        m->greedy_n_colours = nc;
     }
     if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] colouring (%d colours) in %.3f s\n", nc, now_s() - t0);
     return CCP_OK;
@@ -1795,6 +1803,7 @@ try {
     m->user_colour.clear();
     m->user_n_colours = 0;
     m->auto_colour.clear();
+    m->greedy_colour.clear();
     m->used_colour.clear();
     m->used_n_colours = 0;
     m->overlay.clear();
@@ -2152,6 +2161,7 @@ try {
     m->user_colour.clear();
     m->user_n_colours = 0;
     m->auto_colour.clear();
+    m->greedy_colour.clear();
     m->used_colour.clear();
     m->used_n_colours = 0;
     m->region_state = m->edited ? 0 : -1;          // the embedding's parity follows the colouring
@@ -2204,6 +2214,7 @@ try {
         m->touched.push_back(row);
         m->poisson_w = -1;                                           // the structured twin must be recognised again
         m->region_state = 0;                                         // an edited matrix stays on the general path
+        m->greedy_colour.clear();                                    // (a new coupling may make a cached colouring improper)
         m->edited = true;
     }
     return CCP_OK;
