@@ -65,7 +65,9 @@ def parse():
     ap.add_argument("--height", type=int, default=16384)
     ap.add_argument("--channels", type=int, default=1)
     ap.add_argument("--iters-per-step", type=int, default=32)
-    ap.add_argument("--ghost", type=int, default=64, help="ghost rows per side (N>1); exchange every ghost/2 iterations")
+    ap.add_argument("--ghost", type=int, default=0,
+                    help="ghost rows per side (N>1); exchange every ghost/2 iterations.  0 (default): timed on this node at set-up, "
+                         "the fastest of 32 / 64 / 128 (rowblock_abi.choose_ghost)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (default); gloo stages halos through the host (several ranks on one GPU, testing only)")
     ap.add_argument("--halo", default="abi", choices=["abi", "torch"],
@@ -83,11 +85,15 @@ def parse():
     ap.add_argument("--no-configs", action="store_true", help="skip BASELINE configs[0], [1], [4] (N=1)")
     ap.add_argument("--reference-order-iters", type=int, default=128)
     ap.add_argument("--converge-cap", type=int, default=6000)
-    ap.add_argument("--cpu-sample", type=int, default=4096,
-                    help="edge of the CPU baseline grid.  16384 times the headline system itself (BASELINE.md section 3: 3 sweeps): "
-                         "~45 GB of host memory and ~5 minutes, almost all of it building the 1.34e9-entry system on one host core, "
-                         "which is why the default run times a 4096^2 sample instead")
-    ap.add_argument("--cpu-iters", type=int, default=0, help="CPU baseline sweeps (default: 96 at the sample, 3 at 16384^2)")
+    ap.add_argument("--cpu-sample", type=int, default=16384,
+                    help="edge of the CPU baseline grid: 16384 (default) is the headline system itself (BASELINE.md section 3), timed in a "
+                         "child process beside the untimed part of the run after a 4096^2 sample that serves as the fallback")
+    ap.add_argument("--cpu-iters", type=int, default=0, help="CPU baseline sweeps (default: 96 at 4096^2, 24 at 8192^2, 5 at 16384^2)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="host threads that BUILD the CPU baseline's system (the timed gaussSeidel is the "
+                                                               "reference's serial sweep whatever this says); default min(32, cores)")
+    ap.add_argument("--cpu-deadline", type=float, default=420.0, help="seconds the CPU baseline child may take before the largest finished sample is reported")
+    ap.add_argument("--cpu-baseline-child", default="", help=argparse.SUPPRESS)     # internal: sizes, e.g. 4096,16384
+    ap.add_argument("--cpu-log", default="", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
@@ -114,32 +120,141 @@ def mem_available_gb():
     return 0.0
 
 
-def cpu_baseline(sample: int, iters: int):
-    """Reference gaussSeidel (lexicographic, single thread by construction) on a sample of the workload: the same
-    closed-form system (the oracle's generator, orc_poisson_csr) with b = A x_true as everywhere else.  The default
-    sample is 4096^2 x 96 sweeps (~15 s inside gaussSeidel): the 16384^2 system itself (--cpu-sample 16384, 3 sweeps)
-    costs more than 19 minutes of one host core before its first sweep on the GPU box (1.34e9 entries, 16 GB, built,
-    multiplied and ingested serially: a run of round 3 was stopped by the 20-minute limit of a call while still
-    building) against the ~1 minute of the whole run.  The sample flatters the CPU if anything: 512^2 runs at 1.36e8, 4096^2
-    (1.3 GB of CSR) at 1.23-1.27e8, and 8192^2 at 2.0e7 in the build container (3 sweeps, 10.3 s inside gaussSeidel)."""
+def cpu_system_gb(sample: int) -> float:
+    """Host memory of the CPU baseline at sample^2: CSR (12 B per entry, ~5 entries per row) twice (ours and the reference's
+    ingest copy), its three row arrays, x_true, b and the reference's b copy, x and prev."""
+    n = float(sample) * sample
+    return (2 * 5 * 12 * n + 3 * 4 * n + 5 * 8 * n) / 2**30
+
+
+def cpu_baseline_child(sizes, iters_arg: int, threads: int, log_path: str) -> None:
+    """Runs in a process of its own (no torch, no GPU): for every size in turn, build the system, time the compiled
+    reference's gaussSeidel on it and print ONE JSON line; every phase writes a wall-clock line to `log_path` as it ends,
+    so a run that is cut short still says where the time went.
+
+    Why phases matter (round 3 lost a 20-minute call here): on these virtual machines the FIRST touch of host memory the
+    guest has never used costs 3-7 s per GB (the host backs guest pages lazily; measured in the build container: 1 GB in
+    7.4 s on one thread, 16 GB in 49 s on eight, the same 16 GB in 4.9 s once the guest has had them before) — 45 GB of
+    fresh pages for the 16384^2 system, and every numpy temporary on top.  So: (1) `warm` touches the memory the run
+    will need on `threads` threads and frees it again, (2) the system is built band-wise by the C oracle's generator on
+    those threads without temporaries, (3) the reference ingests it (its own serial copy, sparse-matrix.h:537-620, not
+    timed) and (4) gaussSeidel (sparse-matrix.h:350-380, unmodified, serial by construction) is timed alone."""
+    import numpy as np
     import oracle
+    from concurrent.futures import ThreadPoolExecutor
     from coursecomputationalphotography_amd import synth
-    note = ""
-    if sample > 8192 and mem_available_gb() < 80.0:
-        note = f" (a {sample}^2 system needs ~45 GB of host memory, {mem_available_gb():.0f} GB available: sample instead)"
-        sample = 4096
-    if iters <= 0:
-        iters = 3 if sample > 8192 else 96
-    t0 = time.perf_counter()
-    v, c, r = oracle.Oracle().poisson_csr(sample, sample)
-    b = synth.poisson_apply(sample, sample, synth.x_true(sample * sample, 1234))
-    setup = time.perf_counter() - t0
-    kind, secs = cpu_gs_timed(v, c, r, b, iters)
-    return {"value": float(sample) * sample * iters / secs, "unit": "pixel-updates/s", "cores": 1, "kind": kind,
-            "host_cores_available": os.cpu_count(),
-            "sample": f"{sample}x{sample} single-channel Poisson{' (the headline system itself)' if sample == 16384 else ' (a sample: building the 16384^2 system on one host core takes minutes)'}, "
-                      f"{iters} lexicographic iterations, {secs:.2f} s inside gaussSeidel (sweep is serial by construction; "
-                      f"{setup:.1f} s to build the system on the host){note}"}
+    t_start = time.perf_counter()
+    log = open(log_path, "a") if log_path else sys.stderr
+
+    def phase(sample, name, t0, extra=""):
+        log.write(f"[cpu_baseline {time.perf_counter() - t_start:8.2f} s] {sample}^2 {name}: {time.perf_counter() - t0:.2f} s{extra}\n")
+        log.flush()
+        return time.perf_counter()
+
+    orc = oracle.Oracle()
+    try:
+        ref = oracle.Ref()
+    except (FileNotFoundError, OSError):
+        ref = None
+    for sample in sizes:
+        need = cpu_system_gb(sample)
+        avail = mem_available_gb()
+        if avail < 1.2 * need + 2.0:
+            log.write(f"[cpu_baseline] {sample}^2 skipped: needs {need:.0f} GB of host memory, {avail:.0f} GB available\n")
+            log.flush()
+            continue
+        iters = iters_arg if iters_arg > 0 else (5 if sample > 8192 else 24 if sample > 4096 else 96)
+        n = sample * sample
+        phases = {}
+        t0 = t_all = time.perf_counter()
+        # (1) every page the run will use, touched once on many threads, then handed back to the allocator
+        warm = np.empty(int(need * 2**30), dtype=np.uint8)
+        step = -(-warm.size // threads)
+        with ThreadPoolExecutor(threads) as ex:
+            list(ex.map(lambda i: warm[i * step:(i + 1) * step:4096].fill(1), range(threads)))
+        del warm
+        t0 = phase(sample, "warm (first touch of host memory)", t0, f", {need:.1f} GB on {threads} threads")
+        phases["warm"] = t0 - t_all
+        v, c, r = orc.poisson_csr_threaded(sample, sample, threads)
+        t1 = phase(sample, "generator (closed form, C oracle, row bands)", t0, f", {len(v)} entries")
+        phases["generator"] = t1 - t0
+        xt = synth.x_true(n, 1234)
+        t2 = phase(sample, "x_true (mt19937, numpy)", t1)
+        b = orc.poisson_apply_threaded(sample, sample, xt, threads)
+        del xt
+        t3 = phase(sample, "b = A x_true (row bands)", t2)
+        phases["rhs"] = t3 - t1
+        if ref is not None:
+            kind = "reference"
+            ingest, secs = ref.gs_csr_timed_phases(v, c, r, b, iters)
+            phase(sample, "reference ingest (initializeFromEigenRowMajor, serial copy) + gaussSeidel", t3, f", of which ingest {ingest:.2f} s")
+            phases["ingest"] = ingest
+        else:
+            kind = "port"
+            m = orc.from_csr(v, c, r)
+            t4 = phase(sample, "oracle ingest", t3)
+            m.gauss_seidel(b, 0.0, iters)
+            secs = time.perf_counter() - t4
+        phase(sample, f"gaussSeidel, {iters} sweeps", time.perf_counter() - secs, f" = {n * iters / secs:.4g} pixel-updates/s")
+        del v, c, r, b
+        print(json.dumps({"sample": sample, "iters": iters, "kind": kind, "seconds_in_gauss_seidel": secs,
+                          "value": float(n) * iters / secs, "phases_s": {k: round(x, 2) for k, x in phases.items()},
+                          "host_gb": round(need, 1), "build_threads": threads}), flush=True)
+
+
+class CpuBaselineRun:
+    """The CPU baseline as a child process started after the timed region: it needs no GPU and minutes of host time
+    (mostly first-touch page faults, see cpu_baseline_child), the untimed rest of the run needs the GPU and little host."""
+
+    def __init__(self, args):
+        import subprocess
+        import threading
+        sample = args.cpu_sample
+        sizes = [4096] + ([sample] if sample != 4096 else [])
+        self.threads = args.cpu_threads or max(1, min(32, os.cpu_count() or 1))
+        out_dir = os.path.join(ROOT, "gpurun_out")
+        self.log_path = args.cpu_log or (os.path.join(out_dir, "cpu_baseline_phases.log") if os.path.isdir(out_dir) else "")
+        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", ",".join(str(x) for x in sizes),
+               "--cpu-iters", str(args.cpu_iters), "--cpu-threads", str(self.threads)]
+        if self.log_path:
+            cmd += ["--cpu-log", self.log_path]
+        self.t0 = time.perf_counter()
+        self.deadline = args.cpu_deadline
+        self.lines = []
+        self.proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True)
+        self.reader = threading.Thread(target=lambda: [self.lines.append(ln) for ln in self.proc.stdout], daemon=True)
+        self.reader.start()
+
+    def result(self):
+        import subprocess
+        left = max(1.0, self.deadline - (time.perf_counter() - self.t0))
+        note = ""
+        try:
+            self.proc.wait(timeout=left)
+        except subprocess.TimeoutExpired:
+            self.proc.kill()                                           # exactly the child started above
+            self.proc.wait()
+            note = f"; the child was stopped after {self.deadline:.0f} s (phases: {self.log_path or 'stderr'})"
+        self.reader.join(timeout=5.0)
+        done = []
+        for ln in self.lines:
+            try:
+                done.append(json.loads(ln))
+            except ValueError:
+                pass
+        if not done:
+            return None
+        best = done[-1]
+        s = best["sample"]
+        ph = best["phases_s"]
+        what = ("the headline system itself" if s == 16384 else "a sample of the headline workload")
+        return {"value": best["value"], "unit": "pixel-updates/s", "cores": 1, "kind": best["kind"],
+                "host_cores_available": os.cpu_count(),
+                "sample": f"{s}x{s} single-channel Poisson ({what}), {best['iters']} lexicographic iterations, "
+                          f"{best['seconds_in_gauss_seidel']:.2f} s inside gaussSeidel (the sweep is serial by construction: 1 core); set-up on "
+                          f"{best['build_threads']} host threads, not timed: first touch of {best['host_gb']} GB {ph.get('warm')} s, generator "
+                          f"{ph.get('generator')} s, x_true and b {ph.get('rhs')} s, the reference's ingest copy {ph.get('ingest')} s{note}",
+                "phases_s": ph, "smaller_samples": [{"sample": d["sample"], "value": d["value"], "iters": d["iters"]} for d in done[:-1]]}
 
 
 def load_traffic(key):
@@ -394,8 +509,51 @@ def config4(capi):
                              "sample": f"the same matrix, 8 lexicographic sweeps of the C oracle, {secs:.2f} s"}}
 
 
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start the N rank processes ourselves (fresh interpreters, one per
+    GPU, rendezvous on 127.0.0.1) BEFORE anything in this process touches the GPU, wait for them and return the worst
+    exit code.  An external launcher (torch.distributed.run sets WORLD_SIZE) is honoured instead."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *sys.argv[1:]], env=env))
+    rc, live = 0, list(procs)
+    while live:
+        time.sleep(0.2)
+        for pr in list(live):
+            code = pr.poll()
+            if code is None:
+                continue
+            live.remove(pr)
+            if code != 0 and rc == 0:
+                rc = code
+                # a rank that failed leaves the others inside a collective: stop them (these exact children)
+                deadline = time.time() + 20.0
+                while live and time.time() < deadline:
+                    time.sleep(0.2)
+                    live = [q for q in live if q.poll() is None]
+                for q in live:
+                    q.kill()
+    for pr in procs:
+        pr.wait()
+    return rc
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_child:
+        cpu_baseline_child([int(x) for x in args.cpu_baseline_child.split(",")], args.cpu_iters,
+                           args.cpu_threads or max(1, min(32, os.cpu_count() or 1)), args.cpu_log)
+        return
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))
     import torch
     import torch.distributed as dist
 
@@ -403,8 +561,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} rank(s)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the Gauss-Seidel path has no CPU fallback")
     if args.same_device:
@@ -421,28 +578,51 @@ def main():
     W, H, C = args.width, args.height, args.channels
     parts = rowblock.partition_rows(H, world)
     row_begin, row_count = parts[rank]
-    ghost = args.ghost if world > 1 else 0
-    blk = rowblock.GridBlock(W, H, C, row_begin, row_count, ghost, local_rank)
-    halo = args.halo if (world > 1 and args.backend == "nccl") else "torch"
+    use_abi = args.halo == "abi" and world > 1 and args.backend == "nccl"
     halo_note = None
-    solver = None
-    if halo == "abi":
-        # the library's own RCCL communicator on every rank, or — decided together, every rank walking through the
-        # same collectives whatever failed where — the torch.distributed exchange on every rank, so that a scaling
-        # run still produces its line (rowblock_abi.setup_abi_solver)
-        from coursecomputationalphotography_amd import rowblock_abi
-        solver, why = rowblock_abi.setup_abi_solver(blk, rank, world, max(ghost, 2), dist, parts, H, overlap=not args.no_overlap)
-        if solver is None:
-            halo = "torch"
-            halo_note = f"{why}: torch.distributed halo exchange used instead"
-    if solver is None:
-        solver = rowblock.make_solver(blk, rank, world, max(ghost, 2), dist, parts, H, halo="torch", overlap=False)
-    g = blk.grid
+    comm_box = {"comm": None, "why": None}
 
-    # synthetic system, generated on device: x_true -> b = A x_true -> x0 = 1.0
-    g.randomize_x(1234, 0.0, 255.0)
-    g.b_from_x()
-    g.fill_x(1.0)
+    def make_block(ghost_rows):
+        """This rank's block with the synthetic system on it: x_true -> b = A x_true -> x0 = 1.0, all on device."""
+        blk_ = rowblock.GridBlock(W, H, C, row_begin, row_count, ghost_rows if world > 1 else 0, local_rank)
+        g_ = blk_.grid
+        g_.randomize_x(1234, 0.0, 255.0)
+        g_.b_from_x()
+        g_.fill_x(1.0)
+        return blk_
+
+    def make_solver(blk_, ghost_rows):
+        """The library's own RCCL communicator on every rank, or — decided together, every rank walking through the
+        same collectives whatever failed where — the torch.distributed exchange on every rank, so that a scaling run
+        still produces its line (rowblock_abi.setup_abi_solver).  One communicator serves every block of the run."""
+        if use_abi and comm_box["why"] is None:
+            from coursecomputationalphotography_amd import rowblock_abi
+            sv, why = rowblock_abi.setup_abi_solver(blk_, rank, world, max(ghost_rows, 2), dist, parts, H,
+                                                    overlap=not args.no_overlap, comm=comm_box["comm"])
+            if sv is not None:
+                if comm_box["comm"] is None:
+                    comm_box["comm"] = sv.comm
+                    sv.owns_comm = False                                   # closed at the end of the run, after every block
+                return sv
+            comm_box["why"] = why
+        return rowblock.make_solver(blk_, rank, world, max(ghost_rows, 2), dist, parts, H, halo="torch", overlap=False)
+
+    ghost, ghost_table = (args.ghost if world > 1 else 0), None
+    if world > 1 and ghost <= 0:
+        # ghost depth from what an exchange and an interval cost on THIS node (fewer, larger messages and more redundant
+        # rows against more, smaller ones): every candidate timed on the real blocks, the decision all-reduced
+        from coursecomputationalphotography_amd import rowblock_abi
+
+        def tuned_block(gh):
+            b_ = make_block(gh)
+            b_.grid.tune(8)
+            return b_
+        ghost, ghost_table = rowblock_abi.choose_ghost(tuned_block, make_solver, dist, world)
+    blk = make_block(ghost)
+    solver = make_solver(blk, ghost)
+    if use_abi and comm_box["why"] is not None:
+        halo_note = f"{comm_box['why']}: torch.distributed halo exchange used instead"
+    g = blk.grid
     if world > 1:
         solver.exchange_halos()
     g.synchronize()
@@ -475,6 +655,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     region_ms, region_launches, region_iters = g.region_end()
+    # the CPU baseline needs minutes of host time and no GPU: a child process beside the untimed rest of the run
+    cpu_run = CpuBaselineRun(args) if (world == 1 and rank == 0 and not args.no_cpu_baseline) else None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
@@ -499,6 +681,23 @@ def main():
     extra = {}
     total_iters = (args.warmup + args.steps) * ips
     extra["rel_residual_after_timed"] = [total_iters, float(solver.rel_residual().max())]
+    exchange_cost = {}
+    if world > 1:
+        # untimed: one halo exchange alone, and one exchange interval (its sweeps + the exchange beside or after the
+        # last pass), MAX over ranks — what the overlap has to hide and what is left of it
+        def timed(fn, reps):
+            barrier()
+            t_ = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            g.synchronize()
+            tt = torch.tensor([(time.perf_counter() - t_) / reps], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return float(tt.item()) * 1e3
+        ipe = solver.iters_per_exchange
+        solver.sweep(ipe)                                           # ends on an interval boundary whatever ips was
+        exchange_cost = {"exchange_ms": timed(solver.exchange_halos, 8), "interval_ms": timed(lambda: solver.sweep(ipe), 8),
+                         "interval_iterations": ipe}
     if world == 1 and not args.no_parity:
         extra["parity_check"] = parity_against_in_place(g, W, H, total_iters)
         extra["parity_check"]["tiling_checked"] = {"fused_depth": T, "rows_per_chunk": R}
@@ -561,25 +760,38 @@ def main():
             "roofline": roofline,
         }
         out.update(extra)
-        if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.cpu_sample, args.cpu_iters)
-            out["cpu_baseline"] = cpu
-            out["vs_cpu_baseline"] = value / cpu["value"]
+        if world > 1:
+            # what the multi-rank run really was: the ranks the library's communicator holds, the ghost depth chosen
+            # (with the timings that chose it) and what one halo exchange costs beside one exchange interval
+            info = comm_box["comm"].info() if comm_box["comm"] is not None else None
+            out["multi_gpu"] = {"rccl_ranks_seen": info["world"] if info else None,
+                                "rccl_version": info["rccl_version"] if info else None,
+                                "halo_path": "libccp_gs.so over its own RCCL communicator" if info else f"torch.distributed ({args.backend})",
+                                "ghost": ghost, "iters_per_exchange": solver.iters_per_exchange,
+                                "ghost_candidates_ms_per_iteration": ghost_table, **exchange_cost}
         if world == 1 and not args.no_configs:
             blk.close()
             cfg = {}
+            cfg_cpu = {"note": "see cpu_baseline of the line (one CPU run per bench run)"}
             for name, fn in (("configs[0]", lambda: config0(capi)),
-                             ("configs[1]", lambda: config1(capi, out.get("cpu_baseline"))),
+                             ("configs[1]", lambda: config1(capi, cfg_cpu)),
                              ("configs[4]", lambda: config4(capi))):
                 try:
                     cfg[name] = fn()
                 except Exception as e:                                # an extra must never cost the contract line
                     cfg[name] = {"error": f"{type(e).__name__}: {e}"}
             out["configs"] = cfg
+        if cpu_run is not None:
+            cpu = cpu_run.result()
+            if cpu is not None:
+                out["cpu_baseline"] = cpu
+                out["vs_cpu_baseline"] = value / cpu["value"]
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         solver.close()
+        if comm_box["comm"] is not None:
+            comm_box["comm"].close()
         dist.destroy_process_group()
 
 

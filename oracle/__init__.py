@@ -169,6 +169,12 @@ class Oracle:
         L.orc_veclen2.restype = C.c_double
         L.orc_poisson_csr.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_poisson_csr.restype = C.c_int64
+        L.orc_poisson_csr_band.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_poisson_csr_band.restype = C.c_int64
+        L.orc_poisson_row_starts.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
+        L.orc_poisson_row_starts.restype = None
+        L.orc_poisson_apply_band.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.orc_poisson_apply_band.restype = None
         L.orc_poisson_rhs.argtypes = [C.c_int32, C.c_int32, _f32p, _f32p, C.c_int64, C.c_int32,
                                       C.c_int32, C.c_int32, _f64p]
         L.orc_poisson_rhs.restype = None
@@ -239,6 +245,37 @@ class Oracle:
         rowp = np.empty(W * H + 1, dtype=np.int32)
         self.lib.orc_poisson_csr(W, H, values.ctypes.data, cols.ctypes.data, rowp.ctypes.data)
         return values, cols, rowp
+
+    @staticmethod
+    def _bands(H: int, threads: int):
+        step = -(-H // max(1, threads))
+        return [(y, min(H, y + step)) for y in range(0, H, step)]
+
+    def poisson_csr_threaded(self, W: int, H: int, threads: int = 8):
+        """poisson_csr built by `threads` host threads (row bands; ctypes releases the GIL) into arrays each band
+        touches first itself — same bytes as poisson_csr."""
+        from concurrent.futures import ThreadPoolExecutor
+        starts = np.empty(H + 1, dtype=np.int64)
+        self.lib.orc_poisson_row_starts(W, H, starts.ctypes.data)
+        nnz = int(starts[H])
+        values = np.empty(nnz, dtype=np.float64)
+        cols = np.empty(nnz, dtype=np.int32)
+        rowp = np.empty(W * H + 1, dtype=np.int32)
+        vp, cp, rp = values.ctypes.data, cols.ctypes.data, rowp.ctypes.data
+        with ThreadPoolExecutor(max(1, threads)) as ex:
+            list(ex.map(lambda b: self.lib.orc_poisson_csr_band(W, H, b[0], b[1], int(starts[b[0]]), vp, cp, rp),
+                        self._bands(H, threads)))
+        return values, cols, rowp
+
+    def poisson_apply_threaded(self, W: int, H: int, v, threads: int = 8) -> np.ndarray:
+        """A v of the W x H Poisson matrix in applyToVector's order, row bands on `threads` host threads."""
+        from concurrent.futures import ThreadPoolExecutor
+        v = _f64(v)
+        out = np.empty(W * H, dtype=np.float64)
+        ip, op = v.ctypes.data, out.ctypes.data
+        with ThreadPoolExecutor(max(1, threads)) as ex:
+            list(ex.map(lambda b: self.lib.orc_poisson_apply_band(W, H, b[0], b[1], ip, op), self._bands(H, threads)))
+        return out
 
     def poisson_matrix(self, W: int, H: int) -> OracleMatrix:
         v, c, r = self.poisson_csr(W, H)
@@ -340,6 +377,10 @@ class Ref:
         P.ref_gs_eigen_timed.argtypes = [_f64p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _f64p,
                                          C.c_int, C.c_void_p]
         P.ref_gs_eigen_timed.restype = C.c_double
+        if hasattr(P, "ref_gs_eigen_timed_phases"):
+            P.ref_gs_eigen_timed_phases.argtypes = [_f64p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _f64p,
+                                                    C.c_int, C.POINTER(C.c_double)]
+            P.ref_gs_eigen_timed_phases.restype = C.c_double
         L3.ref_lab3_known_answer.argtypes = [C.c_double, C.c_int, _f64p, C.c_void_p]
         L3.ref_lab3_int_insert_scenario.argtypes = [_i32p, _i32p, _i32p, C.c_int, _i32p, _i32p,
                                                     _i32p, C.c_int, C.c_int, C.c_int, _i32p]
@@ -427,6 +468,15 @@ class Ref:
         values, col_offset, row_offset = _f64(values), _i32(col_offset), _i32(row_offset)
         return self.P.ref_gs_eigen_timed(values, len(values), row_offset, n, col_offset, n,
                                          _f64(b), max_iteration, None)
+
+    def gs_csr_timed_phases(self, values, col_offset, row_offset, b, max_iteration):
+        """(seconds of the ingest, seconds inside the reference gaussSeidel) — epsilon = 0."""
+        n = len(row_offset) - 1
+        values, col_offset, row_offset = _f64(values), _i32(col_offset), _i32(row_offset)
+        ingest = C.c_double(0.0)
+        secs = self.P.ref_gs_eigen_timed_phases(values, len(values), row_offset, n, col_offset, n,
+                                                _f64(b), max_iteration, C.byref(ingest))
+        return ingest.value, secs
 
     # lab3 header -------------------------------------------------------------------------
     def lab3_known_answer(self, epsilon=1e-6, max_iteration=1000, with_cg=False):

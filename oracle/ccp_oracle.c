@@ -351,6 +351,72 @@ int64_t orc_poisson_csr(int32_t W, int32_t H, double *values, int32_t *col_offse
     return k;
 }
 
+/* The same closed form for the image rows [y0, y1) only, entries written from position k0 on (= the number of
+ * entries of the rows above, orc_poisson_row_starts): lets bench.py's cpu_baseline leg build the 1.34e9-entry
+ * system of the 16384^2 workload on several host threads.  Same bytes as orc_poisson_csr (tests). */
+int64_t orc_poisson_csr_band(int32_t W, int32_t H, int32_t y0, int32_t y1, int64_t k0, double *values,
+                             int32_t *col_offset, int32_t *row_offset)
+{
+    int64_t k = k0;
+    for (int32_t y = y0; y < y1; ++y) {
+        for (int32_t x = 0; x < W; ++x) {
+            const int32_t i = y * W + x;
+            const int up = has_cell(x, y - 1, W, H);
+            const int left = has_cell(x - 1, y, W, H);
+            const int here = has_cell(x, y, W, H);
+            const int diag = up + left + 2 * here + (i == 0 ? 1 : 0);
+            row_offset[i] = (int32_t)k;
+            if (up)   { values[k] = -1.0; col_offset[k] = i - W; ++k; }
+            if (left) { values[k] = -1.0; col_offset[k] = i - 1; ++k; }
+            if (diag) { values[k] = (double)diag; col_offset[k] = i; ++k; }
+            if (here) {
+                values[k] = -1.0; col_offset[k] = i + 1; ++k;
+                values[k] = -1.0; col_offset[k] = i + W; ++k;
+            }
+        }
+    }
+    if (y1 == H) row_offset[(int64_t)W * H] = (int32_t)k;
+    return k;
+}
+
+/* starts[y] = entries of the image rows above y, y = 0..H (starts[H] = nnz). */
+void orc_poisson_row_starts(int32_t W, int32_t H, int64_t *starts)
+{
+    int64_t k = 0;
+    for (int32_t y = 0; y < H; ++y) {
+        starts[y] = k;
+        for (int32_t x = 0; x < W; ++x) {
+            const int up = has_cell(x, y - 1, W, H), left = has_cell(x - 1, y, W, H), here = has_cell(x, y, W, H);
+            k += up + left + 2 * here + ((up + left + 2 * here + (y == 0 && x == 0)) != 0);
+        }
+    }
+    starts[H] = k;
+}
+
+/* out = A v for the rows [y0, y1) of that matrix, in applyToVector's accumulation order (sparse-matrix.h:382-393:
+ * storage order = up, left, diagonal, right, down, from 0.0). */
+void orc_poisson_apply_band(int32_t W, int32_t H, int32_t y0, int32_t y1, const double *v, double *out)
+{
+    for (int32_t y = y0; y < y1; ++y) {
+        for (int32_t x = 0; x < W; ++x) {
+            const int64_t i = (int64_t)y * W + x;
+            const int up = has_cell(x, y - 1, W, H);
+            const int left = has_cell(x - 1, y, W, H);
+            const int here = has_cell(x, y, W, H);
+            const int diag = up + left + 2 * here + (i == 0 ? 1 : 0);
+            double acc = 0.0;
+            if (up)   acc += -1.0 * v[i - W];
+            if (left) acc += -1.0 * v[i - 1];
+            if (diag) acc += (double)diag * v[i];
+            if (here) {
+                acc += -1.0 * v[i + 1];
+                acc += -1.0 * v[i + W];
+            }
+            out[i] = acc;
+        }
+    }
+}
+
 static const float *grad_px(const float *base, int64_t stride_bytes, int32_t channels,
                             int32_t x, int32_t y)
 {

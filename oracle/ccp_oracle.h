@@ -94,6 +94,12 @@ double orc_rel_residual(const orc_matrix *m, const double *b, const double *x);
  * Returns nnz; call with NULL outputs to query the size. */
 int64_t orc_poisson_csr(int32_t W, int32_t H, double *values, int32_t *col_offset,
                         int32_t *row_offset);
+/* Band forms of the same closed form (rows [y0, y1) of the image), for threaded set-up of large systems. */
+int64_t orc_poisson_csr_band(int32_t W, int32_t H, int32_t y0, int32_t y1, int64_t k0, double *values,
+                             int32_t *col_offset, int32_t *row_offset);
+void orc_poisson_row_starts(int32_t W, int32_t H, int64_t *starts);
+void orc_poisson_apply_band(int32_t W, int32_t H, int32_t y0, int32_t y1, const double *v, double *out);
+
 
 /* ATb for one channel.  gx/gy: H x W x channels float32, row stride in BYTES
  * (cv::Mat CV_32FC3 layout).  Summation order is Eigen's row-major sparse*dense
