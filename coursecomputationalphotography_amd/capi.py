@@ -27,7 +27,7 @@ ORDER_MULTICOLOUR = 1
 # every symbol include/ccp_gs.h declares (tests check the library exports all of them)
 ABI_SYMBOLS = (
     "ccp_status_string", "ccp_abi_version", "ccp_device_count",
-    "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_upload_rows", "ccp_csr_rows_info", "ccp_csr_set_colouring", "ccp_csr_get_colouring", "ccp_csr_insert", "ccp_csr_insert_many", "ccp_csr_edit_stats", "ccp_csr_last_path", "ccp_csr_embed_region_host",
+    "ccp_csr_create", "ccp_csr_destroy", "ccp_csr_upload", "ccp_csr_upload_rows", "ccp_csr_rows_info", "ccp_csr_set_colouring", "ccp_csr_get_colouring", "ccp_csr_insert", "ccp_csr_insert_many", "ccp_csr_edit_stats", "ccp_csr_device_footprint", "ccp_csr_last_path", "ccp_csr_embed_region_host",
     "ccp_csr_gauss_seidel", "ccp_csr_conjugate_gradient", "ccp_csr_conjugate_gradient_jacobi", "ccp_csr_apply_to_vector", "ccp_csr_residual_norm2",
     "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
@@ -152,6 +152,7 @@ def load() -> C.CDLL:
     L.ccp_csr_insert_many.argtypes = [vp, i64, vp, vp, vp]
     L.ccp_csr_last_path.argtypes = [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32), C.POINTER(i64)]
     L.ccp_csr_edit_stats.argtypes = [vp] + [C.POINTER(i64)] * 5
+    L.ccp_csr_device_footprint.argtypes = [vp] + [C.POINTER(i64)] * 2
     L.ccp_csr_gauss_seidel.argtypes = [vp, vp, vp, vp, dbl, i32, i32, i32, C.POINTER(Report)]
     L.ccp_csr_conjugate_gradient.argtypes = [vp, vp, vp, vp, dbl, i32, C.POINTER(Report)]
     L.ccp_csr_conjugate_gradient_jacobi.argtypes = [vp, vp, vp, dbl, i32, C.POINTER(Report)]
@@ -392,6 +393,12 @@ class CsrMatrix:
         v = [C.c_int64() for _ in range(5)]
         check(self.L.ccp_csr_edit_stats(self.h, *[C.byref(t) for t in v]), "ccp_csr_edit_stats")
         return dict(zip(("edits", "image_uploads", "rows_patched", "slices_relocated", "image_rebuilds"), (t.value for t in v)))
+
+    def device_footprint(self):
+        """(device bytes held for a copy of the stored matrix, uploads whose background copy was skipped for lack of room)."""
+        v = [C.c_int64() for _ in range(2)]
+        check(self.L.ccp_csr_device_footprint(self.h, *[C.byref(t) for t in v]), "ccp_csr_device_footprint")
+        return v[0].value, v[1].value
 
     def get_colouring(self):
         """(colour[n_rows], n_colours) the multi-colour sweep uses (caller's or the library's greedy one)."""

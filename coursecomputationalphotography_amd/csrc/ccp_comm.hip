@@ -39,6 +39,24 @@ std::set<std::string> loaded_copies(const char *needle)
 // Why the communicator layer is unusable ("" while it is usable); ccp_comm_probe prints it under CCP_GS_DEBUG.
 static std::string g_rccl_refusal;
 
+// One HIP runtime and one collective library per process.  Two copies of either (say /opt/rocm's next to the ones a
+// Python package bundles) each keep their own device state and their own exit handlers: at best the communicator runs
+// on a runtime the grid handles do not live on, at worst the process aborts in the teardown.  Looked at when RCCL is
+// bound AND again at every ccp_comm_probe / ccp_comm_create: a second copy mapped later is refused as well, whatever
+// order the host program loaded things in.
+static std::string two_copies_refusal()
+{
+    for (const char *needle : {"libamdhip64.so", "librccl.so"}) {
+        const std::set<std::string> copies = loaded_copies(needle);
+        if (copies.size() > 1) {
+            std::string why = std::string("two copies of ") + needle + " are mapped in this process:";
+            for (const std::string &c : copies) why += " " + c;
+            return why;
+        }
+    }
+    return std::string();
+}
+
 const RcclApi *rccl_api()
 {
     static RcclApi api{};
@@ -71,18 +89,10 @@ const RcclApi *rccl_api()
             if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] %s\n", g_rccl_refusal.c_str());
             return;
         }
-        // One HIP runtime and one collective library per process.  Two copies of either (say /opt/rocm's next to
-        // the ones a Python package bundles) each keep their own device state and their own exit handlers: at
-        // best the communicator runs on a runtime the grid handles do not live on, at worst the process aborts
-        // in the teardown.  Refused here, whatever order the host program loaded things in.
-        for (const char *needle : {"libamdhip64.so", "librccl.so"}) {
-            const std::set<std::string> copies = loaded_copies(needle);
-            if (copies.size() > 1) {
-                g_rccl_refusal = std::string("two copies of ") + needle + " are mapped in this process:";
-                for (const std::string &c : copies) g_rccl_refusal += " " + c;
-                if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] RCCL refused: %s\n", g_rccl_refusal.c_str());
-                return;
-            }
+        g_rccl_refusal = two_copies_refusal();
+        if (!g_rccl_refusal.empty()) {
+            if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] RCCL refused: %s\n", g_rccl_refusal.c_str());
+            return;
         }
         bool all = true;
         auto sym = [&](const char *name) -> void * {
@@ -125,6 +135,11 @@ try {
         if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] ccp_comm_probe: %s\n", g_rccl_refusal.c_str());
         return CCP_ERR_RCCL;
     }
+    const std::string later = two_copies_refusal();             // (a second copy mapped since RCCL was bound)
+    if (!later.empty()) {
+        if (getenv("CCP_GS_DEBUG")) fprintf(stderr, "[ccp_gs] ccp_comm_probe: %s\n", later.c_str());
+        return CCP_ERR_RCCL;
+    }
     int v = 0;
     if (api->GetVersion(&v) != ncclSuccess) return CCP_ERR_RCCL;
     return select_device(device);
@@ -149,6 +164,7 @@ try {
     CCP_TRY(select_device(device));
     const RcclApi *api = rccl_api();
     if (!api) return CCP_ERR_RCCL;
+    if (!two_copies_refusal().empty()) return CCP_ERR_RCCL;     // as ccp_comm_probe (which the ranks agree on first)
     ccp_comm *c = new (std::nothrow) ccp_comm();
     if (!c) return CCP_ERR_ALLOC;
     c->rank = rank;

@@ -133,6 +133,7 @@ struct ccp_csr {
     std::unordered_map<int, RowContent> overlay;
     std::vector<int> touched;
     long stat_uploads = 0, stat_rows_patched = 0, stat_slices_relocated = 0, stat_schedule_rebuilds = 0, stat_edits = 0;
+    long stat_eager_skipped = 0;           // background copies of the structure skipped because the device allocation failed
     DevBuf<long> patch_base;
     DevBuf<int> patch_cap, patch_cols;
     DevBuf<long> patch_off;
@@ -523,33 +524,58 @@ void wait_device_upload(ccp_csr *m)
 {
     if (m->uploader.joinable()) {
         m->uploader.join();
-        if (m->uploader_status == CCP_OK) m->dev_csr_valid = m->dev_val_valid = true;
+        if (m->uploader_status == CCP_OK) m->dev_csr_valid = true;     // (structure only: the values travel with the first image)
     }
 }
 
-// Start copying the compact host arrays to the device in the background.
+// Start copying the STRUCTURE of the compact host copy (row offsets, columns) to the device in the background: the
+// raster-region recognition reads it at the first solve.  Best effort — ensure_device_csr copies whatever is missing
+// when something needs it, so a failed allocation here never fails the upload — and only where it can pay:
+//  * a matrix whose row 0 is SolveChannel's [3, -1@1, -1@W] is examined on the host (detect_poisson) and swept
+//    matrix-free on its grid twin: nothing on the device ever reads the stored matrix (18 GB at 16384^2);
+//  * the values travel only when an image of the matrix is built (ensure_device_csr(m, true)).
+// release_device_csr gives the copy back once a grid twin has taken the matrix over.
 int start_device_upload(ccp_csr *m)
 {
     wait_device_upload(m);
     m->dev_csr_valid = m->dev_val_valid = false;
+    m->d_row_ptr.release();
+    m->d_col.release();
+    m->d_val.release();
     const int n = m->n_rows;
     const long nnz = m->row_ptr[n];
     if (n <= 0 || nnz < (1L << 22)) return CCP_OK;        // small matrices: copied when first needed
-    CCP_TRY(m->d_row_ptr.alloc((size_t)n + 1));
-    CCP_TRY(m->d_col.alloc((size_t)nnz));
-    CCP_TRY(m->d_val.alloc((size_t)nnz));
+    if (m->allow_structured && n == m->n_cols && m->row_ptr[1] - m->row_ptr[0] == 3 && m->val[m->row_ptr[0]] == 3.0) return CCP_OK;
+    const bool refuse = getenv("CCP_GS_FAIL_EAGER_ALLOC") && atoi(getenv("CCP_GS_FAIL_EAGER_ALLOC")) != 0;   // test seam
+    if (refuse || m->d_row_ptr.alloc((size_t)n + 1) != CCP_OK || m->d_col.alloc((size_t)nnz) != CCP_OK) {
+        (void)hipGetLastError();                          // the failed hipMalloc must not poison a later error check
+        m->d_row_ptr.release();
+        m->d_col.release();
+        m->stat_eager_skipped++;
+        return CCP_OK;
+    }
     m->uploader_status = CCP_OK;
     m->uploader = std::thread([m, n, nnz] {
         hipStream_t s = nullptr;
         bool ok = hipSetDevice(m->device) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
         ok = ok && hipMemcpyAsync(m->d_row_ptr.p, m->row_ptr.data(), sizeof(long) * ((size_t)n + 1), hipMemcpyHostToDevice, s) == hipSuccess;
         ok = ok && hipMemcpyAsync(m->d_col.p, m->col.data(), sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice, s) == hipSuccess;
-        ok = ok && hipMemcpyAsync(m->d_val.p, m->val.data(), sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, s) == hipSuccess;
         ok = ok && hipStreamSynchronize(s) == hipSuccess;
         if (s) (void)hipStreamDestroy(s);
         if (!ok) m->uploader_status = CCP_ERR_HIP;
     });
     return CCP_OK;
+}
+
+// A grid twin sweeps, applies and checks the matrix from now on: the device copy of the stored matrix is dead weight
+// (2.8 GB at the 8192^2 mask).  An edit or a solve that needs an image copies it again (ensure_device_csr).
+void release_device_csr(ccp_csr *m)
+{
+    wait_device_upload(m);
+    m->dev_csr_valid = m->dev_val_valid = false;
+    m->d_row_ptr.release();
+    m->d_col.release();
+    m->d_val.release();
 }
 
 int ensure_device_csr(ccp_csr *m, bool with_values)
@@ -1213,7 +1239,18 @@ int resolve_colouring(ccp_csr *m, std::vector<int> &colour, int &nc);
 // Recognise (once per upload) and set up the Dirichlet-mask twin.
 bool bipartite_colouring(ccp_csr *m, std::vector<int> &colour);
 
+int detect_region_impl(ccp_csr *m, bool for_reference_order);
+
 int detect_region(ccp_csr *m, bool for_reference_order = false)
+{
+    const int before = m->region_state;
+    const int st = detect_region_impl(m, for_reference_order);
+    // recognised in colour order AND in index order: the grid twin sweeps, applies and checks the matrix from here on
+    if (st == CCP_OK && before < 1 && m->region_state == 1 && !m->rb.on) release_device_csr(m);
+    return st;
+}
+
+int detect_region_impl(ccp_csr *m, bool for_reference_order)
 {
     if (m->region_state >= 1) return CCP_OK;
     if (m->region_state == 0 && !(for_reference_order && m->region_wants_two_colouring)) return CCP_OK;
@@ -1816,12 +1853,15 @@ try {
     m->dev_csr_valid = false;
     m->edited = false;
     m->rb.reset();                         // (ccp_csr_upload_rows sets the row block up again after this call)
+    m->allow_region = true;
     if (const char *e = getenv("CCP_GS_MASKED")) m->allow_region = atoi(e) != 0;
     if (m->grid) ccp_grid_destroy(m->grid);
     m->grid = nullptr;
     if (m->region_grid) ccp_grid_destroy(m->region_grid);      // canvas-sized buffers of the previous matrix (GBs at 8192^2)
     m->region_grid = nullptr;
     m->region_wants_two_colouring = false;
+    // a handle that held a row block (ccp_csr_upload_rows switches the one-GPU forms off) returns to the defaults
+    m->allow_structured = m->allow_one_block = m->allow_pipeline = true;
     if (const char *e = getenv("CCP_GS_STRUCTURED")) m->allow_structured = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_ONE_BLOCK")) m->allow_one_block = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_PIPELINE")) m->allow_pipeline = atoi(e) != 0;
@@ -1834,10 +1874,11 @@ try {
     return start_device_upload(m);         // the device copy proceeds in the background
 } CCP_ABI_CATCH
 
-int ccp_csr_upload_rows(ccp_csr *m, ccp_comm *c, int32_t first_row, int32_t n_rows, int32_t n_global, int64_t n_values,
-                        const double *values, const int32_t *col_offset, const int32_t *row_begin, const int32_t *row_num_nze,
-                        const int32_t *colour, int32_t n_colours)
-try {
+namespace {
+int upload_rows_impl(ccp_csr *m, ccp_comm *c, int32_t first_row, int32_t n_rows, int32_t n_global, int64_t n_values,
+                     const double *values, const int32_t *col_offset, const int32_t *row_begin, const int32_t *row_num_nze,
+                     const int32_t *colour, int32_t n_colours)
+{
     CCP_TRY(bind(m));
     if (!c || c->device != m->device) return CCP_ERR_BAD_ARG;
     const RcclApi *api = rccl_api();
@@ -1927,6 +1968,8 @@ try {
         serve_total += serve_cnt[(size_t)r];
     }
     if (serve_total > INT32_MAX) status = CCP_ERR_UNSUPPORTED;
+    // every rank or none enters the exchanges of step 4 (the offsets above are ints)
+    CCP_TRY(rb_agree(c, s, status));
 
     // ---- 4. the halo index lists travel to the owners, the colours of those rows travel back ----------------------
     CCP_TRY(d_req.alloc((size_t)std::max(n_ghost, 1)));
@@ -2131,6 +2174,30 @@ try {
     }
     rb.on = true;
     return CCP_OK;
+}
+}  // namespace
+
+int ccp_csr_upload_rows(ccp_csr *m, ccp_comm *c, int32_t first_row, int32_t n_rows, int32_t n_global, int64_t n_values,
+                        const double *values, const int32_t *col_offset, const int32_t *row_begin, const int32_t *row_num_nze,
+                        const int32_t *colour, int32_t n_colours)
+try {
+    int status = CCP_ERR_STATE;
+    try {
+        status = upload_rows_impl(m, c, first_row, n_rows, n_global, n_values, values, col_offset, row_begin, row_num_nze, colour, n_colours);
+    } catch (...) {
+        if (m) {
+            m->uploaded = false;
+            m->rb.reset();
+        }
+        throw;                                  // (CCP_ABI_CATCH turns it into a status)
+    }
+    if (status != CCP_OK && m) {
+        // after ANY refusal the handle holds no matrix (ccp_gs.h): a caller that ignores the error must not solve an
+        // earlier block against peers that have dropped theirs
+        m->uploaded = false;
+        m->rb.reset();
+    }
+    return status;
 } CCP_ABI_CATCH
 
 int ccp_csr_rows_info(ccp_csr *m, int32_t *first_row, int32_t *n_rows, int32_t *n_ghost, int32_t *n_peers, int32_t *edge_slices,
@@ -2274,6 +2341,17 @@ try {
     return CCP_OK;
 } CCP_ABI_CATCH
 
+int ccp_csr_device_footprint(ccp_csr *m, int64_t *stored_matrix_bytes, int64_t *eager_copies_skipped)
+try {
+    if (!m) return CCP_ERR_BAD_ARG;
+    wait_device_upload(m);
+    if (stored_matrix_bytes)
+        *stored_matrix_bytes = (int64_t)(m->d_row_ptr.p ? m->d_row_ptr.n * sizeof(long) : 0) + (int64_t)(m->d_col.p ? m->d_col.n * sizeof(int) : 0) +
+                               (int64_t)(m->d_val.p ? m->d_val.n * sizeof(double) : 0);
+    if (eager_copies_skipped) *eager_copies_skipped = m->stat_eager_skipped;
+    return CCP_OK;
+} CCP_ABI_CATCH
+
 int ccp_csr_get_colouring(ccp_csr *m, int32_t *colour, int32_t *n_colours)
 try {
     CCP_TRY(bind(m));
@@ -2321,6 +2399,7 @@ try {
                 ccp_grid_desc d{m->poisson_w, m->poisson_h, 1, 0, m->poisson_h, 0, m->device, 0};
                 CCP_TRY(ccp_grid_create(&d, &m->grid));
                 (void)grid_set_allow_swap(m->grid, true);  // (results leave through ccp_grid_get_x_host)
+                release_device_csr(m);                     // nothing on the device reads the stored matrix any more
             }
             CCP_TRY(ccp_grid_set_stream(m->grid, m->stream));
             CCP_TRY(ccp_grid_set_b_host(m->grid, 0, b, 0, m->poisson_h));
@@ -2401,6 +2480,7 @@ try {
                 ccp_grid_desc d{m->poisson_w, m->poisson_h, 1, 0, m->poisson_h, 0, m->device, 0};
                 CCP_TRY(ccp_grid_create(&d, &m->grid));
                 (void)grid_set_allow_swap(m->grid, true);  // (results leave through ccp_grid_get_x_host)
+                release_device_csr(m);                     // nothing on the device reads the stored matrix any more
             }
             CCP_TRY(ccp_grid_set_stream(m->grid, m->stream));
             CCP_TRY(ccp_grid_set_b_host(m->grid, 0, b, 0, m->poisson_h));
@@ -2629,6 +2709,7 @@ try {
                 ccp_grid_desc d{m->poisson_w, m->poisson_h, 1, 0, m->poisson_h, 0, m->device, 0};
                 CCP_TRY(ccp_grid_create(&d, &m->grid));
                 (void)grid_set_allow_swap(m->grid, true);  // (results leave through ccp_grid_get_x_host)
+                release_device_csr(m);                     // nothing on the device reads the stored matrix any more
             }
             CCP_TRY(ccp_grid_set_stream(m->grid, m->stream));
             CCP_TRY(ccp_grid_set_b_host(m->grid, 0, b, 0, m->poisson_h));

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCP_GS_ABI_VERSION 4
+#define CCP_GS_ABI_VERSION 5
 
 typedef enum ccp_status {
     CCP_OK = 0,
@@ -122,6 +122,12 @@ int ccp_csr_insert(ccp_csr *m, int32_t row, int32_t col, double val);
 int ccp_csr_insert_many(ccp_csr *m, int64_t count, const int32_t *rows, const int32_t *cols, const double *vals);
 int ccp_csr_edit_stats(ccp_csr *m, int64_t *edits, int64_t *image_uploads, int64_t *rows_patched, int64_t *slices_relocated,
                        int64_t *image_rebuilds);
+/* Device memory the handle holds for a copy of the STORED matrix (row offsets, columns, values; bytes): ccp_csr_upload
+ * starts copying the structure in the background for the recognition of the first solve — best effort: when the device
+ * has no room the upload still succeeds (eager_copies_skipped counts that) and the copy is made when something needs it —
+ * and the copy is given back (0 bytes) once a grid twin sweeps the matrix.  Waits for the background copy.  Outputs may
+ * be NULL. */
+int ccp_csr_device_footprint(ccp_csr *m, int64_t *stored_matrix_bytes, int64_t *eager_copies_skipped);
 
 /* The colouring the multi-colour sweep uses (the caller's, or the library's greedy one): colour[i]
  * for every row (n_rows entries; may be NULL to ask for the count only).  With it a caller can hand

@@ -57,3 +57,25 @@ def test_bench_two_ranks_on_one_card_matches_single():
     # same iterates on the partitioned grid: the residual trace agrees to reduction rounding
     a, b = d["rel_residual_after_timed"], single["rel_residual_after_timed"]
     assert a[0] == b[0] and abs(a[1] - b[1]) <= 1e-12 * b[1] + 1e-18
+
+
+def test_bare_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` with NO launcher (no WORLD_SIZE in the environment): bench.py starts the two rank
+    processes itself before anything touches the GPU, picks the ghost depth from timed candidates and prints one line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--same-device", *SMALL]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 1e9
+    mg = d["multi_gpu"]
+    assert mg["ghost"] in (32, 64, 128) and mg["iters_per_exchange"] == mg["ghost"] // 2
+    assert set(mg["ghost_candidates_ms_per_iteration"]) == {"32", "64", "128"}
+    assert mg["exchange_ms"] > 0 and mg["interval_ms"] > 0 and mg["halo_path"].startswith("torch.distributed")
+    assert "ghost " + str(mg["ghost"]) in d["config"]["partition"]
+    single = last_json(subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *SMALL], capture_output=True,
+                                      text=True, timeout=600).stdout)
+    a, b = d["rel_residual_after_timed"], single["rel_residual_after_timed"]
+    assert a[0] == b[0] and abs(a[1] - b[1]) <= 1e-12 * b[1] + 1e-18

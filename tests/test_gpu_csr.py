@@ -373,3 +373,48 @@ def test_apply_and_residual_of_the_poisson_matrix_need_no_image(capi, orc, monke
     assert np.array_equal(m2.apply_to_vector(xv), want)
     assert m2.edit_stats()["image_uploads"] >= 1
     m2.close()
+
+
+def test_upload_succeeds_when_the_background_copy_finds_no_room(capi, orc, monkeypatch):
+    """ccp_csr_upload starts copying the matrix's structure to the device in the background for the recognition of the
+    first solve.  That copy is best effort: a device allocation that fails there must not fail the upload (the copy is
+    made when something needs it), and the copy is given back once a grid twin sweeps the matrix."""
+    from coursecomputationalphotography_amd import synth
+    mask = synth.disc_mask(1400, 1400, seed=4321)
+    v, c, r, colour, ys, xs = synth.masked_laplacian_csr(mask)
+    n = len(ys)
+    assert len(v) >= (1 << 22)                                  # large enough for the background copy
+    b = synth.csr_apply(v, c, r, synth.x_true(n, 9))
+    want, _, _ = orc.multicolour_gauss_seidel(v, c, r, colour, b, 0.0, 5)
+    # (1) the allocation refused (test seam): the upload succeeds, nothing is held, the solve still finds the region
+    monkeypatch.setenv("CCP_GS_FAIL_EAGER_ALLOC", "1")
+    m = capi.CsrMatrix().upload_compressed(v, c, r)
+    monkeypatch.delenv("CCP_GS_FAIL_EAGER_ALLOC")
+    assert m.device_footprint() == (0, 1)
+    m.set_colouring(colour, 2)
+    x, _ = m.gauss_seidel(b, 0.0, 5, check_every=0)
+    assert m.last_path().startswith("region grid") and np.array_equal(x, want)
+    assert m.device_footprint()[0] == 0                         # the twin has the matrix: no copy of the stored one
+    # (2) the ordinary case: structure only (row offsets + columns, no values), given back after the recognition
+    m.upload_compressed(v, c, r)
+    held, skipped = m.device_footprint()
+    assert held == 8 * (n + 1) + 4 * len(v) and skipped == 1
+    m.set_colouring(colour, 2)
+    x, _ = m.gauss_seidel(b, 0.0, 5, check_every=0)
+    assert m.last_path().startswith("region grid") and np.array_equal(x, want)
+    assert m.device_footprint()[0] == 0
+    # (3) kept on the stored-matrix path, where the images are built from it (values included)
+    monkeypatch.setenv("CCP_GS_MASKED", "0")
+    m.upload_compressed(v, c, r)
+    monkeypatch.delenv("CCP_GS_MASKED")
+    m.set_colouring(colour, 2)
+    x, _ = m.gauss_seidel(b, 0.0, 5, check_every=0)
+    assert m.last_path() == "sliced ELL" and np.array_equal(x, want)
+    assert m.device_footprint()[0] == 8 * (n + 1) + 12 * len(v)
+    m.close()
+    # SolveChannel's matrix is examined on the host and swept on its grid twin: never copied at all
+    pv, pc, pr = synth.poisson_csr(1100, 1000)
+    assert len(pv) >= (1 << 22)
+    p = capi.CsrMatrix().upload_compressed(pv, pc, pr)
+    assert p.device_footprint() == (0, 0)
+    p.close()

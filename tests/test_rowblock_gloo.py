@@ -165,3 +165,120 @@ def test_ranks_fall_back_together_when_the_communicator_cannot_be_set_up(scenari
         assert p.exitcode == 0
     assert all(none for _, none, _ in results), results          # nobody kept a half-built communicator
     assert all(why for _, _, why in results), results            # and everybody knows why (bench.py's halo_note)
+
+
+# ---- ghost depth chosen from measured times (rowblock_abi.choose_ghost) -----------------------------------------
+class _ClockedSolver:
+    """A stand-in whose exchange and sweeps advance a virtual clock: an exchange costs `latency + rows * per_row`,
+    a sweep of k iterations costs the rows it marches (owned + the ghost rows still valid, both sides)."""
+
+    def __init__(self, clock, ghost, rows, latency, per_row_sweep):
+        self.clock, self.ghost, self.rows, self.latency, self.per_row = clock, ghost, rows, latency, per_row_sweep
+        self.iters_per_exchange = ghost // 2
+        self.since = 0
+        self.closed = False
+
+    def exchange_halos(self):
+        self.clock[0] += self.latency + self.ghost * 1e-7
+        self.since = 0
+
+    def sweep(self, iterations):
+        left = iterations
+        while left > 0:
+            if self.since >= self.iters_per_exchange:
+                self.exchange_halos()
+            room = min(left, self.iters_per_exchange - self.since)
+            self.clock[0] += room * (self.rows + 2 * self.ghost) * self.per_row
+            self.since += room
+            left -= room
+
+    def close(self):
+        self.closed = True
+
+
+class _ClockedBlock:
+    class grid:
+        @staticmethod
+        def synchronize():
+            pass
+
+    def __init__(self):
+        self.closed = False
+
+    def close(self):
+        self.closed = True
+
+
+@pytest.mark.parametrize("latency, want", [(0.0, 32), (2e-3, 128), (5e-5, 64)])
+def test_ghost_depth_follows_the_measured_exchange_cost(latency, want):
+    """Cheap exchanges -> the shallowest ghosts (least redundant rows); expensive ones -> the deepest (fewest messages);
+    in between the middle.  Virtual clock: the decision depends on the timings alone."""
+    from coursecomputationalphotography_amd import rowblock_abi
+    clock = [0.0]
+    made = []
+
+    def make_block(ghost):
+        made.append(_ClockedBlock())
+        return made[-1]
+
+    def make_solver(block, ghost):
+        return _ClockedSolver(clock, ghost, rows=2048, latency=latency, per_row_sweep=1e-8)
+
+    best, table = rowblock_abi.choose_ghost(make_block, make_solver, dist=None, world=1, clock=lambda: clock[0])
+    assert best == want, table
+    assert set(table) == {32, 64, 128} and all(b.closed for b in made)
+    assert all(t["exchange_ms"] >= latency * 1e3 for t in table.values())
+
+
+def test_ghost_candidates_a_block_is_too_thin_for_are_skipped():
+    from coursecomputationalphotography_amd import rowblock_abi
+    clock = [0.0]
+
+    def make_block(ghost):
+        if ghost > 64:
+            raise ValueError("row block thinner than the ghost depth")
+        return _ClockedBlock()
+    best, table = rowblock_abi.choose_ghost(make_block, lambda b, g: _ClockedSolver(clock, g, 100, 1.0, 1e-8), dist=None, world=1,
+                                            clock=lambda: clock[0])
+    assert best == 64 and set(table) == {32, 64}
+
+
+def _ghost_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from coursecomputationalphotography_amd import rowblock_abi
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        clock = [0.0]
+        # rank 1 sees a slow link, rank 0 a free one: the MAX over ranks decides, both take the same depth;
+        # rank 1 cannot build the 128-row candidate: it is skipped on BOTH ranks
+        lat = 2e-3 if rank == 1 else 0.0
+
+        def make_block(ghost):
+            if rank == 1 and ghost == 128:
+                raise ValueError("too thin")
+            return _ClockedBlock()
+        best, table = rowblock_abi.choose_ghost(make_block, lambda b, g: _ClockedSolver(clock, g, 2048, lat, 1e-8), dist, world,
+                                                clock=lambda: clock[0])
+        q.put((rank, best, sorted(table)))
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_ranks_take_the_same_ghost_depth():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ghost_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] == 64 and res[0][2] == res[1][2] == [32, 64]
