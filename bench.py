@@ -120,11 +120,20 @@ def mem_available_gb():
     return 0.0
 
 
+def cpu_needs_wide_index(sample: int) -> bool:
+    """The reference's default IndexType (int) sweeps a matrix only while every entry position stays below 2^30:
+    getNearestIndex computes `(end + idx) / 2` in Index arithmetic (sparse-matrix.h:636).  SolveChannel's 16384^2 system
+    has 1.34e9 entries — its last fifth of rows overflows (round 4's first attempt: > 400 s inside gaussSeidel, the
+    search wandering over gigabytes, at(i, i) wrong) — so there the header is instantiated with a 64-bit IndexType."""
+    return 5.0 * sample * sample > 2**30
+
+
 def cpu_system_gb(sample: int) -> float:
-    """Host memory of the CPU baseline at sample^2: CSR (12 B per entry, ~5 entries per row) twice (ours and the reference's
-    ingest copy), its three row arrays, x_true, b and the reference's b copy, x and prev."""
+    """Host memory of the CPU baseline at sample^2: CSR (8 B values + 4 or 8 B columns per entry, ~5 entries per row) twice
+    (ours and the reference's ingest copy), its three row arrays, x_true, b and the reference's b copy, x and prev."""
     n = float(sample) * sample
-    return (2 * 5 * 12 * n + 3 * 4 * n + 5 * 8 * n) / 2**30
+    idx = 8 if cpu_needs_wide_index(sample) else 4
+    return (2 * 5 * (8 + idx) * n + 4 * idx * n + 5 * 8 * n) / 2**30
 
 
 def cpu_baseline_child(sizes, iters_arg: int, threads: int, log_path: str) -> None:
@@ -175,8 +184,9 @@ def cpu_baseline_child(sizes, iters_arg: int, threads: int, log_path: str) -> No
         del warm
         t0 = phase(sample, "warm (first touch of host memory)", t0, f", {need:.1f} GB on {threads} threads")
         phases["warm"] = t0 - t_all
-        v, c, r = orc.poisson_csr_threaded(sample, sample, threads)
-        t1 = phase(sample, "generator (closed form, C oracle, row bands)", t0, f", {len(v)} entries")
+        wide = cpu_needs_wide_index(sample) and ref is not None
+        v, c, r = orc.poisson_csr_threaded(sample, sample, threads, np.int64 if wide else np.int32)
+        t1 = phase(sample, "generator (closed form, C oracle, row bands)", t0, f", {len(v)} entries, {'64' if wide else '32'}-bit indices")
         phases["generator"] = t1 - t0
         xt = synth.x_true(n, 1234)
         t2 = phase(sample, "x_true (mt19937, numpy)", t1)
@@ -186,7 +196,7 @@ def cpu_baseline_child(sizes, iters_arg: int, threads: int, log_path: str) -> No
         phases["rhs"] = t3 - t1
         if ref is not None:
             kind = "reference"
-            ingest, secs = ref.gs_csr_timed_phases(v, c, r, b, iters)
+            ingest, secs = (ref.gs_csr_timed_phases_i64 if wide else ref.gs_csr_timed_phases)(v, c, r, b, iters)
             phase(sample, "reference ingest (initializeFromEigenRowMajor, serial copy) + gaussSeidel", t3, f", of which ingest {ingest:.2f} s")
             phases["ingest"] = ingest
         else:
@@ -199,7 +209,8 @@ def cpu_baseline_child(sizes, iters_arg: int, threads: int, log_path: str) -> No
         del v, c, r, b
         print(json.dumps({"sample": sample, "iters": iters, "kind": kind, "seconds_in_gauss_seidel": secs,
                           "value": float(n) * iters / secs, "phases_s": {k: round(x, 2) for k, x in phases.items()},
-                          "host_gb": round(need, 1), "build_threads": threads}), flush=True)
+                          "host_gb": round(need, 1), "build_threads": threads,
+                          "index_type": "int64" if wide else "int"}), flush=True)
 
 
 class CpuBaselineRun:
@@ -248,12 +259,15 @@ class CpuBaselineRun:
         s = best["sample"]
         ph = best["phases_s"]
         what = ("the headline system itself" if s == 16384 else "a sample of the headline workload")
+        wide_note = ("; SparseMatrix<double, IndexType = 64-bit>: with the default int the reference's getNearestIndex "
+                     "(sparse-matrix.h:636, `(end + idx) / 2`) overflows beyond 2^30 stored entries and cannot sweep this system"
+                     if best.get("index_type") == "int64" else "")
         return {"value": best["value"], "unit": "pixel-updates/s", "cores": 1, "kind": best["kind"],
-                "host_cores_available": os.cpu_count(),
+                "host_cores_available": os.cpu_count(), "index_type": best.get("index_type"),
                 "sample": f"{s}x{s} single-channel Poisson ({what}), {best['iters']} lexicographic iterations, "
                           f"{best['seconds_in_gauss_seidel']:.2f} s inside gaussSeidel (the sweep is serial by construction: 1 core); set-up on "
                           f"{best['build_threads']} host threads, not timed: first touch of {best['host_gb']} GB {ph.get('warm')} s, generator "
-                          f"{ph.get('generator')} s, x_true and b {ph.get('rhs')} s, the reference's ingest copy {ph.get('ingest')} s{note}",
+                          f"{ph.get('generator')} s, x_true and b {ph.get('rhs')} s, the reference's ingest copy {ph.get('ingest')} s{wide_note}{note}",
                 "phases_s": ph, "smaller_samples": [{"sample": d["sample"], "value": d["value"], "iters": d["iters"]} for d in done[:-1]]}
 
 

@@ -171,6 +171,8 @@ class Oracle:
         L.orc_poisson_csr.restype = C.c_int64
         L.orc_poisson_csr_band.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_poisson_csr_band.restype = C.c_int64
+        L.orc_poisson_csr_band64.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_poisson_csr_band64.restype = C.c_int64
         L.orc_poisson_row_starts.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
         L.orc_poisson_row_starts.restype = None
         L.orc_poisson_apply_band.argtypes = [C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
@@ -251,20 +253,22 @@ class Oracle:
         step = -(-H // max(1, threads))
         return [(y, min(H, y + step)) for y in range(0, H, step)]
 
-    def poisson_csr_threaded(self, W: int, H: int, threads: int = 8):
+    def poisson_csr_threaded(self, W: int, H: int, threads: int = 8, index_dtype=np.int32):
         """poisson_csr built by `threads` host threads (row bands; ctypes releases the GIL) into arrays each band
-        touches first itself — same bytes as poisson_csr."""
+        touches first itself — same bytes as poisson_csr; index_dtype np.int64: the arrays of a 64-bit IndexType."""
         from concurrent.futures import ThreadPoolExecutor
         starts = np.empty(H + 1, dtype=np.int64)
         self.lib.orc_poisson_row_starts(W, H, starts.ctypes.data)
         nnz = int(starts[H])
+        if index_dtype == np.int32 and nnz > 2**31 - 1:
+            raise ValueError("more stored entries than a 32-bit index holds")
         values = np.empty(nnz, dtype=np.float64)
-        cols = np.empty(nnz, dtype=np.int32)
-        rowp = np.empty(W * H + 1, dtype=np.int32)
+        cols = np.empty(nnz, dtype=index_dtype)
+        rowp = np.empty(W * H + 1, dtype=index_dtype)
         vp, cp, rp = values.ctypes.data, cols.ctypes.data, rowp.ctypes.data
+        fill = self.lib.orc_poisson_csr_band if index_dtype == np.int32 else self.lib.orc_poisson_csr_band64
         with ThreadPoolExecutor(max(1, threads)) as ex:
-            list(ex.map(lambda b: self.lib.orc_poisson_csr_band(W, H, b[0], b[1], int(starts[b[0]]), vp, cp, rp),
-                        self._bands(H, threads)))
+            list(ex.map(lambda b: fill(W, H, b[0], b[1], int(starts[b[0]]), vp, cp, rp), self._bands(H, threads)))
         return values, cols, rowp
 
     def poisson_apply_threaded(self, W: int, H: int, v, threads: int = 8) -> np.ndarray:
@@ -377,6 +381,10 @@ class Ref:
         P.ref_gs_eigen_timed.argtypes = [_f64p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _f64p,
                                          C.c_int, C.c_void_p]
         P.ref_gs_eigen_timed.restype = C.c_double
+        if hasattr(P, "ref_gs_eigen_timed_phases_i64"):
+            P.ref_gs_eigen_timed_phases_i64.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p,
+                                                        C.c_int, C.POINTER(C.c_double), C.c_void_p]
+            P.ref_gs_eigen_timed_phases_i64.restype = C.c_double
         if hasattr(P, "ref_gs_eigen_timed_phases"):
             P.ref_gs_eigen_timed_phases.argtypes = [_f64p, C.c_int, _i32p, C.c_int, _i32p, C.c_int, _f64p,
                                                     C.c_int, C.POINTER(C.c_double)]
@@ -468,6 +476,19 @@ class Ref:
         values, col_offset, row_offset = _f64(values), _i32(col_offset), _i32(row_offset)
         return self.P.ref_gs_eigen_timed(values, len(values), row_offset, n, col_offset, n,
                                          _f64(b), max_iteration, None)
+
+    def gs_csr_timed_phases_i64(self, values, col_offset, row_offset, b, max_iteration, x_out=None):
+        """The same through SparseMatrix<double, int64_t> (col_offset, row_offset: int64 arrays) — the header's own
+        IndexType parameter, for systems whose entry positions overflow the default int (see orc_poisson_csr_band64)."""
+        n = len(row_offset) - 1
+        values, b = _f64(values), _f64(b)
+        col_offset = np.ascontiguousarray(col_offset, dtype=np.int64)
+        row_offset = np.ascontiguousarray(row_offset, dtype=np.int64)
+        ingest = C.c_double(0.0)
+        secs = self.P.ref_gs_eigen_timed_phases_i64(values.ctypes.data, len(values), row_offset.ctypes.data, n, col_offset.ctypes.data, n,
+                                                    b.ctypes.data, max_iteration, C.byref(ingest),
+                                                    None if x_out is None else x_out.ctypes.data)
+        return ingest.value, secs
 
     def gs_csr_timed_phases(self, values, col_offset, row_offset, b, max_iteration):
         """(seconds of the ingest, seconds inside the reference gaussSeidel) — epsilon = 0."""

@@ -379,6 +379,35 @@ int64_t orc_poisson_csr_band(int32_t W, int32_t H, int32_t y0, int32_t y1, int64
     return k;
 }
 
+/* The same with 64-bit indices: the arrays SparseMatrix<double, int64_t> ingests.  The reference's default IndexType
+ * (int) cannot hold the 16384^2 system: getNearestIndex computes (end + idx) / 2 in Index arithmetic
+ * (sparse-matrix.h:636), which overflows once a row's entries lie beyond position 2^30 — the last fifth of that
+ * matrix's 1.34e9 entries — so bench.py's cpu_baseline leg instantiates the header with a 64-bit IndexType there. */
+int64_t orc_poisson_csr_band64(int32_t W, int32_t H, int32_t y0, int32_t y1, int64_t k0, double *values,
+                               int64_t *col_offset, int64_t *row_offset)
+{
+    int64_t k = k0;
+    for (int32_t y = y0; y < y1; ++y) {
+        for (int32_t x = 0; x < W; ++x) {
+            const int64_t i = (int64_t)y * W + x;
+            const int up = has_cell(x, y - 1, W, H);
+            const int left = has_cell(x - 1, y, W, H);
+            const int here = has_cell(x, y, W, H);
+            const int diag = up + left + 2 * here + (i == 0 ? 1 : 0);
+            row_offset[i] = k;
+            if (up)   { values[k] = -1.0; col_offset[k] = i - W; ++k; }
+            if (left) { values[k] = -1.0; col_offset[k] = i - 1; ++k; }
+            if (diag) { values[k] = (double)diag; col_offset[k] = i; ++k; }
+            if (here) {
+                values[k] = -1.0; col_offset[k] = i + 1; ++k;
+                values[k] = -1.0; col_offset[k] = i + W; ++k;
+            }
+        }
+    }
+    if (y1 == H) row_offset[(int64_t)W * H] = k;
+    return k;
+}
+
 /* starts[y] = entries of the image rows above y, y = 0..H (starts[H] = nnz). */
 void orc_poisson_row_starts(int32_t W, int32_t H, int64_t *starts)
 {

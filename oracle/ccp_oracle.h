@@ -97,6 +97,8 @@ int64_t orc_poisson_csr(int32_t W, int32_t H, double *values, int32_t *col_offse
 /* Band forms of the same closed form (rows [y0, y1) of the image), for threaded set-up of large systems. */
 int64_t orc_poisson_csr_band(int32_t W, int32_t H, int32_t y0, int32_t y1, int64_t k0, double *values,
                              int32_t *col_offset, int32_t *row_offset);
+int64_t orc_poisson_csr_band64(int32_t W, int32_t H, int32_t y0, int32_t y1, int64_t k0, double *values,
+                               int64_t *col_offset, int64_t *row_offset);
 void orc_poisson_row_starts(int32_t W, int32_t H, int64_t *starts);
 void orc_poisson_apply_band(int32_t W, int32_t H, int32_t y0, int32_t y1, const double *v, double *out);
 

@@ -187,3 +187,24 @@ extern "C" double ref_gs_eigen_timed_phases(const double *values, int n_values, 
     if (ingest_seconds) *ingest_seconds = std::chrono::duration<double>(t0 - i0).count();
     return std::chrono::duration<double>(t1 - t0).count();
 }
+
+// The header's IndexType template parameter at 64 bits: the only way the reference can hold SolveChannel's 16384 x 16384
+// system (1,342,046,211 stored entries): with the default int, getNearestIndex's `(end + idx) / 2` (sparse-matrix.h:636)
+// overflows for every row whose entries lie beyond position 2^30, the search wanders over gigabytes and at(i, i) comes
+// back wrong.  Same unmodified header, same member functions.
+extern "C" double ref_gs_eigen_timed_phases_i64(const double *values, long long n_values, const long long *row_offset,
+                                                long long n_rows, const long long *col_offset, long long n_cols,
+                                                const double *b, int max_iteration, double *ingest_seconds, double *x_out)
+{
+    using Mat64 = SparseMatrix<double, long long>;
+    auto i0 = std::chrono::steady_clock::now();
+    Mat64 m;
+    m.initializeFromEigenRowMajor(values, n_values, row_offset, n_rows, col_offset, n_cols, nullptr, 0);
+    std::vector<double> bv(b, b + n_cols);
+    auto t0 = std::chrono::steady_clock::now();
+    std::vector<double> x = m.gaussSeidel(bv, 0.0, max_iteration);
+    auto t1 = std::chrono::steady_clock::now();
+    if (ingest_seconds) *ingest_seconds = std::chrono::duration<double>(t0 - i0).count();
+    if (x_out) std::memcpy(x_out, x.data(), sizeof(double) * x.size());
+    return std::chrono::duration<double>(t1 - t0).count();
+}

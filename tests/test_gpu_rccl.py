@@ -5,6 +5,7 @@ C++ host tests/cpp/rowblock_driver.cpp; plus the in-launch edge hand-off that le
 the sweep, exercised with several row blocks on ONE card (halo messages staged by the test)."""
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -289,3 +290,32 @@ def test_a_refused_row_block_leaves_no_matrix_behind(capi):
         m.gauss_seidel(np.ones(200), 0.0, 1, check_every=0)
     m.close()
     comm.close()
+
+
+_EXIT_CHILD = r"""
+import importlib.util, os, sys
+sys.path.insert(0, {root!r})
+if {by_path!r}:
+    spec = importlib.util.find_spec("torch")
+    os.environ["CCP_GS_RCCL_LIB"] = os.path.join(os.path.dirname(spec.origin), "lib", "librccl.so")
+from coursecomputationalphotography_amd import capi
+assert not {by_path!r} or "torch" not in sys.modules
+comm = capi.Comm(capi.comm_unique_id(), 0, 1, 0)
+assert comm.info()["world"] == 1
+comm.close()
+import torch
+assert torch.cuda.is_available()
+print("clean", flush=True)
+"""
+
+
+@pytest.mark.parametrize("by_path", [True, False])
+def test_a_process_that_used_the_communicator_and_imports_torch_exits_cleanly(by_path):
+    """Regression test of round 2's at-exit abort ("double free or corruption (!prev)", exit code -6): a process that
+    used RCCL through the library and imported torch AFTERWARDS died in librocm_smi64's exit handlers because the
+    library had opened RCCL with RTLD_GLOBAL (csrc/ccp_comm.hip: rccl_api).  by_path: torch's RCCL bound by hand before
+    torch is imported — the order that aborted; otherwise the binding's default order (torch first)."""
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    out = subprocess.run([sys.executable, "-c", _EXIT_CHILD.format(root=root, by_path=by_path)], capture_output=True, text=True, timeout=300)
+    assert "clean" in out.stdout, out.stderr[-2000:]
+    assert out.returncode == 0, (out.returncode, out.stderr[-2000:])
