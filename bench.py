@@ -436,9 +436,9 @@ def config1(capi, cpu):
             "bytes_model": f"{BYTES_PER_PIXEL_PASS:.0f} B per pixel and channel per pass of {T} iterations",
             "avg_launch_ms": per_launch, "frac": model / (per_launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
             **traffic_fields(f"{W}x{H}x{C}_T{T}_R{R}", per_launch * 1e-3),
-            "frac_note": "x, b and the ping-pong buffer are 1.2 GB: past the 256 MiB Infinity Cache; the pass is bound by vector "
-                         "issue (143.5 VALU instructions per march step, DESIGN section 4.1) at 23 % more marched rows per stored row "
-                         "than the 16384^2 tiling (R = 140 + 32 against 364 + 32)",
+            "frac_note": "geometry, not the kernel's speed (DESIGN section 4.1): per wave and march step the pass runs as fast as the "
+                         "16384^2 one, but a chunk marches (R + 32) / R rows per stored row and the waves fill a fractional number of "
+                         "rounds of the 2,048 wave slots",
             "cpu_baseline": cpu}
 
 
@@ -502,10 +502,8 @@ def config4(capi):
                                                                       f"for the {iters} iterations")
     else:
         frac, model_txt = csr_bytes * iters / rep.seconds / 1e9 / HBM_PEAK_GBS, "SURVEY §8d CSR model: 12 B per stored entry + 32 B per row"
-    om = oracle.Oracle().from_csr(v, c, r)
-    t0 = time.perf_counter()
-    want8 = om.gauss_seidel(b, 0.0, 8)[0]
-    secs = time.perf_counter() - t0
+    want8 = oracle.Oracle().from_csr(v, c, r).gauss_seidel(b, 0.0, 8)[0]         # the checker of x8 above
+    kind, secs = cpu_gs_timed(v, c, r, b, 8)                                       # the baseline: the compiled reference where built
     return {"workload": f"{canvas}x{canvas} canvas, union-of-discs + brush mask: {n} unknowns, {nnz} non-zeros, "
                         "5-point Laplacian restricted to the mask, 2-colour Gauss-Seidel",
             "path": path, "ms_per_iteration": rep.seconds * 1e3 / iters, "iters": iters, "passes": passes, "row_updates_per_s": ups,
@@ -519,8 +517,9 @@ def config4(capi):
             "reference_order": {"what": "the same matrix swept in index order (sparse-matrix.h:350-380 as it is), 64 sweeps",
                                 "path": path_ref, "row_updates_per_s": n * 64 / rep_ref.seconds,
                                 "bit_identical_to_oracle_8_sweeps": bool(np.array_equal(x8, want8))},
-            "cpu_baseline": {"value": n * 8 / secs, "unit": "row-updates/s", "cores": 1, "kind": "port",
-                             "sample": f"the same matrix, 8 lexicographic sweeps of the C oracle, {secs:.2f} s"}}
+            "cpu_baseline": {"value": n * 8 / secs, "unit": "row-updates/s", "cores": 1, "kind": kind,
+                             "sample": f"the same matrix, 8 lexicographic sweeps of "
+                                       f"{'the compiled reference gaussSeidel' if kind == 'reference' else 'the C oracle'}, {secs:.2f} s"}}
 
 
 def spawn_ranks(n: int) -> int:
