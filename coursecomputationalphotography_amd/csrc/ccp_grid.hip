@@ -2,7 +2,6 @@
 #include "ccp_grid_kernels.hpp"
 #include "ccp_grid_fused.hpp"
 #include "ccp_grid_lex.hpp"
-#include "ccp_grid_lex2.hpp"
 #include "ccp_cg.hpp"
 #include "ccp_grid_cg.hpp"
 #include "ccp_comm.hpp"
@@ -95,12 +94,10 @@ struct ccp_grid {
     DevBuf<unsigned> lex_progress, lex_ticket;   // strip-wave pipeline: diagonals finished per (channel, sweep, strip); work tickets
     DevBuf<double> lex_edges;    // time-skewed strips: results of each strip's lanes 62/63 per step and sweep (read by the strip to its right)
     int lex_mode = 3;            // 3: time-skewed strips, the T sweeps of a pass on the T waves of a workgroup (k_lex_wg, default);
-                                 // CCP_GS_LEX_MODE=strips -> 1: one sweep per wave, all sweeps in one launch; =skew -> 2: the T sweeps
-                                 // of a pass in one wave's registers; =planes -> 0: one launch per hyperplane
-    int lex_tmax = 8;            // deepest time-skewed pass (CCP_GS_LEX_T: 1, 2, 4 or 8)
+                                 // CCP_GS_LEX_MODE=planes -> 0: one launch per hyperplane (k_lex_plane, the independent engine)
+    int lex_tmax = 8;            // deepest time-skewed pass
     DevBuf<unsigned> lex_order;  // k_lex_wg: ticket -> group * strips + strip, in wavefront order
     int lex_order_groups = 0, lex_order_strips = 0;
-    int lex_chunk = 0;           // diagonals between two progress publications (CCP_GS_LEX_CHUNK; 0 = by size)
     LexGeom lexg{};
     DevBuf<double> stage;        // natural-order staging rows for host transfers
     long stage_rows = 0;
@@ -113,7 +110,6 @@ struct ccp_grid {
     int last_launches = 0;
     bool timing_pending = false;
     int cpt = 2;                 // half-columns per thread of the sweep kernel
-    bool shfl = true;            // horizontal neighbour from the adjacent lane (vs. re-load)
     int rows_per_block = 32;
 };
 
@@ -145,7 +141,6 @@ void choose_tiling(ccp_grid *g)
     const long bx = sweep_blocks_x(g);
     long r = (long)g->geom.local_rows * bx * g->desc.channels / 4096;
     r = std::max<long>(4, std::min<long>(64, r));
-    if (const char *e = getenv("CCP_GS_ROWS_PER_BLOCK")) r = std::max(1, atoi(e));
     g->rows_per_block = (int)r;
 }
 
@@ -164,10 +159,8 @@ int launch_half_sweep(ccp_grid *g, int c, int l_lo, int l_hi, const int *active)
     if (g->masked) {
         hipLaunchKernelGGL((k_half_sweep<2, L1, true, true>), grid, block, 0, g->stream, g->x.p, g->x.p, g->b.p, geo, c, l_lo, l_hi,
                            rpb, part, active, g->maskp.p);
-    } else if (g->cpt == 4) {
-        if (g->shfl) CCP_LAUNCH_SWEEP(4, true); else CCP_LAUNCH_SWEEP(4, false);
     } else {
-        if (g->shfl) CCP_LAUNCH_SWEEP(2, true); else CCP_LAUNCH_SWEEP(2, false);
+        CCP_LAUNCH_SWEEP(2, true);
     }
 #undef CCP_LAUNCH_SWEEP
     CCP_HIP(hipGetLastError());
@@ -853,8 +846,6 @@ try {
     geo.pitch = (((long)d->width + 1) / 2 + 15) / 16 * 16;
     geo.ch_stride = (long)geo.local_rows * 2 * geo.pitch;
     g->cpt = 2;
-    if (const char *e = getenv("CCP_GS_CPT")) g->cpt = (atoi(e) == 4) ? 4 : 2;
-    if (const char *e = getenv("CCP_GS_SHFL")) g->shfl = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_FUSE")) g->fuse = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_SHORT_EDGES")) g->short_edges = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_XCD")) g->xcd_swizzle = atoi(e) != 0;
@@ -862,9 +853,7 @@ try {
     if (const char *e = getenv("CCP_GS_TRACE_FILE")) g->trace_file = e[0] ? e : nullptr;
     if (const char *e = getenv("CCP_GS_SIDE_ROWS")) g->side_rows_override = atoi(e);
     if (const char *e = getenv("CCP_GS_LEX_MODE"))
-        g->lex_mode = strcmp(e, "planes") == 0 ? 0 : (strcmp(e, "strips") == 0 ? 1 : (strcmp(e, "skew") == 0 ? 2 : (strcmp(e, "wg2") == 0 ? 4 : (strcmp(e, "wg") == 0 ? 3 : g->lex_mode))));
-    if (const char *e = getenv("CCP_GS_LEX_T")) g->lex_tmax = std::max(1, std::min(8, atoi(e)));
-    if (const char *e = getenv("CCP_GS_LEX_CHUNK")) g->lex_chunk = atoi(e);
+        g->lex_mode = strcmp(e, "planes") == 0 ? 0 : 3;
     if (const char *e = getenv("CCP_GS_TMAX")) g->fuse_tmax = std::max(1, std::min(kFusedMaxT, atoi(e)));
     if (const char *e = getenv("CCP_GS_ALL_BORDER")) g->all_border = atoi(e) != 0;
     if (const char *e = getenv("CCP_GS_FORCE_BORDER")) g->force_border = atoi(e) != 0;
@@ -1421,63 +1410,33 @@ namespace {
 
 // `iterations` lexicographic sweeps of the channels in `mask`, pipelined over the hyperplanes
 // tau = x + y + 2k (ccp_grid_lex.hpp).  partial != nullptr: per-sweep step sums are written too.
-int lex_strips(const ccp_grid *g) { return (g->desc.width + kLexStripCols - 1) / kLexStripCols; }
-
 // partial sums one checked sweep writes per channel
 // (time-skewed strips: the strip count depends on the depth; the partial layout uses the largest, depth 8's —
 // slots a shallower launch does not write must read as zero, so the buffer is cleared per batch)
 long lex_partials_per_sweep(const ccp_grid *g)
 {
-    if (g->lex_mode >= 2) return (long)((g->desc.width - 1 + 2 * 7) / kLexSkewCols + 1);
-    return g->lex_mode == 1 ? (long)lex_strips(g) : (long)g->lexg.n_diag * g->lexg.nbx;
+    if (g->lex_mode == 3) return (long)((g->desc.width - 1 + 2 * 7) / kLexSkewCols + 1);
+    return (long)g->lexg.n_diag * g->lexg.nbx;
 }
 
-// `iterations` lexicographic sweeps of the channels in `mask` as ONE launch of strip waves (k_lex_strips).
-int lex_run_strips(ccp_grid *g, int iterations, unsigned mask, double *partial)
-{
-    const LexGeom &lg = g->lexg;
-    const int C = g->desc.channels, S = lex_strips(g);
-    int chunk = g->lex_chunk;
-    if (chunk <= 0) chunk = std::min(lg.W, lg.H) <= 1024 ? 8 : (std::min(lg.W, lg.H) <= 4096 ? 16 : 32);
-    chunk = std::max(1, std::min(chunk, kWave));
-    const size_t need = (size_t)C * iterations * S;
-    if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
-    if (!g->lex_ticket.p) CCP_TRY(g->lex_ticket.alloc(kMaxChannels));
-    CCP_HIP(hipMemsetAsync(g->lex_progress.p, 0, need * sizeof(unsigned), g->stream));
-    CCP_HIP(hipMemsetAsync(g->lex_ticket.p, 0, kMaxChannels * sizeof(unsigned), g->stream));
-    dim3 grid((unsigned)((long)iterations * S), (unsigned)C);
-    if (partial)
-        hipLaunchKernelGGL((k_lex_strips<true>), grid, dim3(kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, iterations, S, chunk,
-                           g->lex_progress.p, g->lex_ticket.p, mask, partial);
-    else
-        hipLaunchKernelGGL((k_lex_strips<false>), grid, dim3(kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, iterations, S, chunk,
-                           g->lex_progress.p, g->lex_ticket.p, mask, static_cast<double *>(nullptr));
-    CCP_HIP(hipGetLastError());
-    return CCP_OK;
-}
-
-// `iterations` lexicographic sweeps as time-skewed strip waves: groups of T sweeps per pass through memory
-// (k_lex_skew), T = 8, 4, 2, 1 for what is left over; every depth is one launch holding all its groups.
+// `iterations` lexicographic sweeps as time-skewed strips: groups of T sweeps per pass through memory (k_lex_wg),
+// T = 8, 4, 2, 1 for what is left over; every depth is one launch holding all its groups.
 extern "C++" {
 template <int T>
 int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
 {
     const LexGeom &lg = g->lexg;
     const int C = g->desc.channels;
-    const bool wg2 = g->lex_mode == 4;                       // two pixels per lane and step: strips of 126 skewed columns
-    const int S = (lg.W - 1 + 2 * (T - 1)) / (wg2 ? kLex2Cols : kLexSkewCols) + 1;
-    const long edge_steps = (wg2 ? 2 * kWave : kWave) + lg.H + 2 * (T - 1);
-    int chunk = g->lex_chunk;
-    if (chunk <= 0) chunk = std::min(lg.W, lg.H) <= 1024 ? 8 : 16;
-    chunk = std::max(kLexSkewAhead, std::min(chunk, kWave)) / kLexSkewAhead * kLexSkewAhead;   // whole ring turns per chunk
-    const bool wg = g->lex_mode == 3 || wg2;
-    const size_t need = (size_t)C * groups * S * (wg ? kLexWordStride : 1), edges = (size_t)C * S * edge_steps * 2 * T + (wg ? (size_t)C * groups * S * kLexScratch : 0);   // (+ the storers' scratch slots)
+    const int S = (lg.W - 1 + 2 * (T - 1)) / kLexSkewCols + 1;
+    const long edge_steps = kWave + lg.H + 2 * (T - 1);
+    const size_t need = (size_t)C * groups * S * kLexWordStride;
+    const size_t edges = (size_t)C * S * edge_steps * 2 * T + (size_t)C * groups * S * kLexScratch;   // (+ the storers' scratch slots)
     if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
-    if (wg && (g->lex_order_groups != groups || g->lex_order_strips != S)) {
+    if (g->lex_order_groups != groups || g->lex_order_strips != S) {
         // Tickets in wavefront order: strip s of group k starts about (s + rho k) strip-lags after the first one,
         // and a workgroup that is resident but waiting keeps a slot from one that could run.  Everything (k, s)
         // waits for — (k, s-1), (k-1, s), (k-1, s+1) — sorts before it for any rho >= 1 (ties: lower group first).
-        static const long rho = std::max(1, getenv("CCP_GS_LEX_RHO") ? atoi(getenv("CCP_GS_LEX_RHO")) : 3);
+        const long rho = 3;
         std::vector<unsigned> order((size_t)groups * S);
         size_t n = 0;
         for (long key = 0; key <= (long)(S - 1) + rho * (groups - 1); ++key)
@@ -1495,42 +1454,24 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     CCP_HIP(hipMemsetAsync(g->lex_progress.p, 0, need * sizeof(unsigned), g->stream));
     CCP_HIP(hipMemsetAsync(g->lex_ticket.p, 0, kMaxChannels * sizeof(unsigned), g->stream));
     dim3 grid((unsigned)((long)groups * S), (unsigned)C);
-    if (wg) {                                                // the T sweeps of a group on the T waves of a workgroup
-        static const int pad = getenv("CCP_GS_LEX_PAD_LDS") ? atoi(getenv("CCP_GS_LEX_PAD_LDS")) : 0;   // (occupancy experiments: extra LDS per workgroup)
-        if (getenv("CCP_GS_DEBUG")) {
-            int nb = 0;
-            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lex_wg<T, false>, (T + 2) * kWave, pad);
-            fprintf(stderr, "[ccp_gs] k_lex_wg<%d>: %d workgroups per CU, %d groups x %d strips\n", T, nb, groups, S);
-        }
-        const dim3 block((T + 2) * kWave);
-        double *nop = nullptr;
-#define CCP_LEX_WG(KERNEL, CHECK, P, STRIDE)                                                                                        \
-    hipLaunchKernelGGL((KERNEL<T, CHECK>), grid, block, pad, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,              \
-                       g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, P, STRIDE)
-        if (wg2 && g->masked) {
-            if (partial) CCP_LEX_WG(k_lex_wg2_masked, true, partial, lex_partials_per_sweep(g));
-            else CCP_LEX_WG(k_lex_wg2_masked, false, nop, 0L);
-        } else if (wg2) {
-            if (partial) CCP_LEX_WG(k_lex_wg2, true, partial, lex_partials_per_sweep(g));
-            else CCP_LEX_WG(k_lex_wg2, false, nop, 0L);
-        } else if (g->masked) {
-            if (partial) CCP_LEX_WG(k_lex_wg_masked, true, partial, lex_partials_per_sweep(g));
-            else CCP_LEX_WG(k_lex_wg_masked, false, nop, 0L);
-        } else {
-            if (partial) CCP_LEX_WG(k_lex_wg, true, partial, lex_partials_per_sweep(g));
-            else CCP_LEX_WG(k_lex_wg, false, nop, 0L);
-        }
-#undef CCP_LEX_WG
-        CCP_HIP(hipGetLastError());
-        return CCP_OK;
+    if (getenv("CCP_GS_DEBUG")) {
+        int nb = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lex_wg<T, false>, (T + 2) * kWave, 0);
+        fprintf(stderr, "[ccp_gs] k_lex_wg<%d>: %d workgroups per CU, %d groups x %d strips\n", T, nb, groups, S);
     }
-    if (g->masked) return CCP_ERR_UNSUPPORTED;               // (only k_lex_wg / k_lex_wg2 know Dirichlet masks)
-    if (partial)
-        hipLaunchKernelGGL((k_lex_skew<T, true>), grid, dim3(kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S, chunk,
-                           g->lex_progress.p, g->lex_ticket.p, g->lex_edges.p, edge_steps, mask, partial, lex_partials_per_sweep(g));
-    else
-        hipLaunchKernelGGL((k_lex_skew<T, false>), grid, dim3(kWave), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S, chunk,
-                           g->lex_progress.p, g->lex_ticket.p, g->lex_edges.p, edge_steps, mask, static_cast<double *>(nullptr), 0L);
+    const dim3 block((T + 2) * kWave);
+    double *nop = nullptr;
+#define CCP_LEX_WG(KERNEL, CHECK, P, STRIDE)                                                                                        \
+    hipLaunchKernelGGL((KERNEL<T, CHECK>), grid, block, 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,                \
+                       g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, P, STRIDE)
+    if (g->masked) {
+        if (partial) CCP_LEX_WG(k_lex_wg_masked, true, partial, lex_partials_per_sweep(g));
+        else CCP_LEX_WG(k_lex_wg_masked, false, nop, 0L);
+    } else {
+        if (partial) CCP_LEX_WG(k_lex_wg, true, partial, lex_partials_per_sweep(g));
+        else CCP_LEX_WG(k_lex_wg, false, nop, 0L);
+    }
+#undef CCP_LEX_WG
     CCP_HIP(hipGetLastError());
     return CCP_OK;
 }
@@ -1557,14 +1498,11 @@ int lex_run_skew(ccp_grid *g, int iterations, unsigned mask, double *partial)
 
 int lex_run(ccp_grid *g, int iterations, unsigned mask, double *partial)
 {
-    if (g->lex_mode >= 2 && iterations > 0) return lex_run_skew(g, iterations, mask, partial);
-    if (g->lex_mode == 1 && iterations > 0) return lex_run_strips(g, iterations, mask, partial);
+    if (g->lex_mode == 3 && iterations > 0) return lex_run_skew(g, iterations, mask, partial);
     const LexGeom &lg = g->lexg;
     const int d_max = lg.n_diag - 1;
     const int C = g->desc.channels;
-    static const int sync_every = getenv("CCP_GS_LEX_SYNC_EVERY") ? atoi(getenv("CCP_GS_LEX_SYNC_EVERY")) : 0;   // profiling aid
     for (int tau = 0; tau <= d_max + 2 * (iterations - 1); ++tau) {
-        if (sync_every > 0 && tau % sync_every == sync_every - 1) CCP_HIP(hipStreamSynchronize(g->stream));
         const int k_lo = std::max(0, (tau - d_max + 1) / 2);          // smallest k with tau - 2k <= d_max
         const int k_hi = std::min(iterations - 1, tau / 2);           // largest k with tau - 2k >= 0
         if (k_hi < k_lo) continue;
@@ -1587,7 +1525,7 @@ int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max
 try {
     CCP_TRY(bind(g));
     if (g->ghost_top || g->ghost_bottom || g->desc.row_count != g->desc.height) return CCP_ERR_STATE;   // whole image only
-    if (g->masked && g->lex_mode < 3) return CCP_ERR_UNSUPPORTED;   // Dirichlet masks: k_lex_wg / k_lex_wg2 only
+    if (g->masked && g->lex_mode != 3) return CCP_ERR_UNSUPPORTED;  // Dirichlet masks: k_lex_wg only
     if (max_iteration < 0 || check_every < 0) return CCP_ERR_BAD_ARG;
     const int C = g->desc.channels, W = g->desc.width, H = g->desc.height;
     LexGeom &lg = g->lexg;
@@ -1624,7 +1562,7 @@ try {
         // fixed count — or the reference loop never starts (eps = 10 <= epsilon)
         const int n = check_every == 0 ? max_iteration : 0;
         for (int done = 0; done < n;) {                    // gridDim.y carries the sweeps in flight: keep it small
-            const int kb = std::min(g->lex_mode != 0 ? 4096 : 32768, n - done);   // (strip waves: one progress word per sweep and strip)
+            const int kb = std::min(g->lex_mode != 0 ? 4096 : 32768, n - done);   // (k_lex_wg: one progress word per group and strip)
             CCP_TRY(lex_run(g, kb, all, nullptr));
             done += kb;
         }
@@ -1641,7 +1579,7 @@ try {
         while (mask && done < max_iteration) {
             const int kb = std::min(batch_max, max_iteration - done);
             CCP_HIP(hipMemcpyAsync(g->lex_snap.p, g->lex_x.p, elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
-            if (g->lex_mode >= 2) CCP_HIP(hipMemsetAsync(g->lex_partial.p, 0, sizeof(double) * (size_t)per * kb * C, g->stream));
+            if (g->lex_mode == 3) CCP_HIP(hipMemsetAsync(g->lex_partial.p, 0, sizeof(double) * (size_t)per * kb * C, g->stream));
             CCP_TRY(lex_run(g, kb, mask, g->lex_partial.p));
             hipLaunchKernelGGL(k_lex_reduce, dim3((unsigned)kb, (unsigned)C), dim3(kBlock), 0, g->stream, g->lex_partial.p, per,
                                g->lex_eps.p);

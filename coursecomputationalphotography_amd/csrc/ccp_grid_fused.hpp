@@ -52,14 +52,6 @@ constexpr int kFusedUnroll = CCP_FUSED_UNROLL;          // march steps unrolled 
 // pair and keep 1).  Measured (profiles/r03_window_forms.jsonl):
 // +2-3 % at 16384^2 and 4096^2 x 3 over one trip.
 constexpr int kFusedLand = CCP_FUSED_LAND;
-#ifndef CCP_FUSED_RING
-#define CCP_FUSED_RING 0
-#endif
-constexpr bool kFusedRing = CCP_FUSED_RING != 0;        // ordinary tiles of unchecked passes: the ring form of the window (FusedRing)
-#ifndef CCP_FUSED_RING_MASKED
-#define CCP_FUSED_RING_MASKED 0
-#endif
-constexpr bool kFusedRingMasked = CCP_FUSED_RING_MASKED != 0;
 constexpr int kStripLanes = kWave;       // half-columns per strip
 
 __host__ __device__ constexpr int fused_halo_px(int T) { return 2 * T; }               // per side
@@ -225,7 +217,6 @@ __host__ __device__ __forceinline__ void fused_chunk_rows(const FusedParams &P, 
 template <int T, int UNR>
 struct FusedWindow {
     static_assert(UNR > 0 && UNR % 2 == 0, "row parity must be a compile-time constant per unrolled step");
-    static constexpr bool kRing = false;
     static constexpr int HS = 2 * T;
     static constexpr int G = UNR;
     static constexpr int NT = HS + G + 1;
@@ -233,27 +224,9 @@ struct FusedWindow {
     __host__ __device__ static constexpr int slot(int i, int dist) { return HS + 1 + i - dist; }
 };
 
-// The RING form of the window (ordinary tiles, passes without the step norm): the row that is `dist` rows behind the
-// newest row of unrolled step i sits in slot (i - dist) mod P, and P march steps are unrolled per loop trip, so
-// every slot index is a compile-time constant and NOTHING is ever moved: a row stays in the registers its load put it
-// in until the row that comes P rows later overwrites it.  P = 2T + 2 rows in use (the newest row down to the row
-// above the one being stored) + kRingAhead rows in flight from memory, even (the colour of every unrolled update is
-// a compile-time constant).  Against the shifted form at T = 8 this removes the ~47 v_mov_b64 of a step's ~143 vector
-// instructions (the SQ counters of DESIGN 4.1 put the pass at the vector-issue limit wherever it is not at the HBM
-// limit); the loop body is P steps long (~17 KB at T = 8: it stays in the instruction cache).
-#ifndef CCP_RING_AHEAD
-#define CCP_RING_AHEAD 2
-#endif
-constexpr int kRingAhead = CCP_RING_AHEAD;          // even
-template <int T>
-struct FusedRing {
-    static constexpr bool kRing = true;
-    static constexpr int HS = 2 * T;
-    static constexpr int G = HS + 2 + kRingAhead;       // steps per loop trip = slots
-    static constexpr int NT = G;
-    static_assert(G % 2 == 0, "row parity must be a compile-time constant per unrolled step");
-    __host__ __device__ static constexpr int slot(int i, int dist) { return ((i - dist) % G + G) % G; }
-};
+// (A RING form of the window — slot (i - dist) mod P with P = 2T + 2 + rows in flight steps unrolled per trip, nothing
+// ever moved: a third fewer vector instructions — was built and measured in round 3: 7-20 % SLOWER, the waves parked on
+// s_waitcnt twice as long; the pass is bound by memory, not by vector issue.  NOTES.md, profiles/r03_window_forms.jsonl.)
 
 // Memory goes through raw buffer instructions with one descriptor per image row: a row that does
 // not exist gets num_records = 0 and a lane whose half-column does not exist (or must not be
@@ -305,7 +278,6 @@ struct FusedCtx {
     bool px_right[2];   // x < W-1
     bool px_first[2];   // x == 0
     bool has_first;     // wave-uniform: the strip holds pixel column 0 (the a_ii = 3 column)
-    double quarter;     // 0.25 in a scalar register pair the compiler cannot see through (fused_step, ring form)
 };
 
 // Row q of x (red, black) and b (red, black); rows outside [m0, m1) and lanes outside the image read 0.
@@ -381,9 +353,7 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
         double nv = old;
         if (MODE == kStepFast) {
             if (MASKED) nv = __builtin_fma(((up + left) + right) + dn, __hiloint2double(c ? qk[MASKED ? sr : 0] : qr[MASKED ? sr : 0], 0), bq);
-            // (ring form: 1/4 from a register — as a literal it forces the two-address v_fmac, whose destination is
-            // the b/4 the window must keep, i.e. a copy per update; the shifted form folds that copy into its shifts)
-            else nv = __builtin_fma(((up + left) + right) + dn, Win::kRing ? cx.quarter : 0.25, bq);
+            else nv = __builtin_fma(((up + left) + right) + dn, 0.25, bq);
         } else if (MODE == kStepSide) {
             const double bv = bq * 4.0;
             // ordinary row y in [1, H-2]: cell(x,y-1), cell(x,y) exist iff x < W-1 (up, right,
@@ -452,11 +422,6 @@ __device__ __forceinline__ void fused_ctx_init(FusedCtx &cx, const double *__res
 {
     constexpr int HS = 2 * T;
     cx.xin = xin; cx.xout = xout; cx.bb = bb;
-    {
-        double q = 0.25;
-        asm volatile("" : "+s"(q));
-        cx.quarter = q;
-    }
     const int lane = (int)(threadIdx.x & (kWave - 1));
     const int U = fused_useful_px(T);
     const int px0 = sx * U - fused_halo_px(T);          // first pixel column of the strip (even)
@@ -486,98 +451,6 @@ __device__ __forceinline__ void fused_ctx_init(FusedCtx &cx, const double *__res
     cx.m1 = min(rb + HS, g.local_rows);
 }
 
-// Row q of x and b straight into window slot S (ring form: no landing registers).
-template <int S, int NT, bool COH>
-__device__ __forceinline__ void fused_load_row_into(const FusedCtx &cx, const Geom &g, int q, double (&wr)[NT], double (&wk)[NT],
-                                                    double (&br)[NT], double (&bk)[NT])
-{
-    const bool exists = q >= cx.m0 && q < cx.m1;
-    const __amdgpu_buffer_rsrc_t rx = row_rsrc(cx.xin, g, q, exists), rbb = row_rsrc(cx.bb, g, q, exists);
-    wr[S] = buf_load<COH>(rx, cx.ld_r);
-    wk[S] = buf_load<COH>(rx, cx.ld_k);
-    br[S] = buf_load(rbb, cx.ld_r);
-    bk[S] = buf_load(rbb, cx.ld_k);
-}
-
-// One unrolled step of the ring march (I = its position in the loop body).
-template <int T, int I, int AN, bool MASKED, int NQ, bool COH>
-__device__ __forceinline__ void fused_ring_step(double (&wr)[FusedRing<T>::NT], double (&wk)[FusedRing<T>::NT], double (&br)[FusedRing<T>::NT],
-                                                double (&bk)[FusedRing<T>::NT], QWord (&qr)[NQ], QWord (&qk)[NQ],
-                                                int (&landm)[kRingAhead][2], double (&acc)[AN], const FusedCtx &cx, const Geom &g, int f)
-{
-    using Win = FusedRing<T>;
-    constexpr int NT = Win::NT;
-    // the row that becomes the newest row kRingAhead steps from now starts its way from memory
-    fused_load_row_into<Win::slot(I, -kRingAhead), NT, COH>(cx, g, f + kRingAhead, wr, wk, br, bk);
-    // the newest row enters: the window holds b/4 (fused_step), the mask bytes become the factor 1/4 or 0
-    constexpr int s0 = Win::slot(I, 0);
-    br[s0] = br[s0] * 0.25;
-    bk[s0] = bk[s0] * 0.25;
-    if (MASKED) {
-        qr[MASKED ? s0 : 0] = landm[I % kRingAhead][0] ? kQuarterHi : 0;
-        qk[MASKED ? s0 : 0] = landm[I % kRingAhead][1] ? kQuarterHi : 0;
-        fused_load_mask(cx, g, f + kRingAhead, landm[I % kRingAhead]);
-    }
-    fused_step<T, kStepFast, 0, 0, NT, AN, MASKED, NQ, COH, Win>(wr, wk, br, bk, acc, cx, g, f, I, qr, qk);
-}
-
-template <int T, int I, int AN, bool MASKED, int NQ, bool COH>
-struct FusedRingTrip {
-    // steps I .. P-1 of a loop trip; false: the march ended inside the trip
-    static __device__ __forceinline__ bool run(double (&wr)[FusedRing<T>::NT], double (&wk)[FusedRing<T>::NT], double (&br)[FusedRing<T>::NT],
-                                               double (&bk)[FusedRing<T>::NT], QWord (&qr)[NQ], QWord (&qk)[NQ], int (&landm)[kRingAhead][2],
-                                               double (&acc)[AN], const FusedCtx &cx, const Geom &g, int fb, int f_end)
-    {
-        if constexpr (I >= FusedRing<T>::G) {
-            return true;
-        } else {
-            if (fb + I > f_end) return false;               // (wave-uniform)
-            fused_ring_step<T, I, AN, MASKED, NQ, COH>(wr, wk, br, bk, qr, qk, landm, acc, cx, g, fb + I);
-            return FusedRingTrip<T, I + 1, AN, MASKED, NQ, COH>::run(wr, wk, br, bk, qr, qk, landm, acc, cx, g, fb, f_end);
-        }
-    }
-};
-
-template <int T, int J, bool MASKED, bool COH>
-struct FusedRingPrologue {
-    static __device__ __forceinline__ void run(double (&wr)[FusedRing<T>::NT], double (&wk)[FusedRing<T>::NT], double (&br)[FusedRing<T>::NT],
-                                               double (&bk)[FusedRing<T>::NT], int (&landm)[kRingAhead][2], const FusedCtx &cx, const Geom &g, int base)
-    {
-        if constexpr (J < kRingAhead) {
-            fused_load_row_into<FusedRing<T>::slot(J, 0), FusedRing<T>::NT, COH>(cx, g, base + J, wr, wk, br, bk);
-            if (MASKED) fused_load_mask(cx, g, base + J, landm[J]);
-            FusedRingPrologue<T, J + 1, MASKED, COH>::run(wr, wk, br, bk, landm, cx, g, base);
-        }
-    }
-};
-
-// One wave of an ordinary tile, ring form (see FusedRing): same rows, same arithmetic, same stores as fused_wave.
-template <int T, int AN, bool MASKED, bool COH>
-__device__ __forceinline__ void fused_wave_ring(const double *__restrict__ xin, double *__restrict__ xout,
-                                                const double *__restrict__ bb, const Geom &g, int sx, int ra, int rb,
-                                                double (&acc)[AN], const unsigned char *__restrict__ mask)
-{
-    using Win = FusedRing<T>;
-    constexpr int HS = Win::HS, P = Win::G, NT = Win::NT;
-    FusedCtx cx;
-    fused_ctx_init<T>(cx, xin, xout, bb, g, sx, ra, rb, mask);
-    const int base = cx.m0 - ((g.y0 + cx.m0) & 1);      // the march starts on an even image row
-    const int f_end = rb - 1 + HS;
-    double wr[NT], wk[NT], br[NT], bk[NT];
-    constexpr int NQ = MASKED ? NT : 1;
-    QWord qr[NQ], qk[NQ];
-    int landm[kRingAhead][2];
-#pragma unroll
-    for (int s = 0; s < NT; ++s) wr[s] = wk[s] = br[s] = bk[s] = 0.0;
-#pragma unroll
-    for (int s = 0; s < NQ; ++s) qr[s] = qk[s] = 0;
-#pragma unroll
-    for (int j = 0; j < kRingAhead; ++j) landm[j][0] = landm[j][1] = 0;
-    FusedRingPrologue<T, 0, MASKED, COH>::run(wr, wk, br, bk, landm, cx, g, base);
-    for (int fb = base; fb <= f_end; fb += P)
-        if (!FusedRingTrip<T, 0, AN, MASKED, NQ, COH>::run(wr, wk, br, bk, qr, qk, landm, acc, cx, g, fb, f_end)) break;
-}
-
 // One wave: strip `sx`, rows [ra, rb) of channel data at xin/xout/b (already channel-offset).
 // BORDERTILE = false: every pixel the wave can touch is ordinary: one straight-line loop of
 // kStepFast trips.  BORDERTILE = true: each trip picks among the three bodies (force_border:
@@ -589,10 +462,6 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
                                            const unsigned char *__restrict__ mask = nullptr)
 {
     static_assert(!(MASKED && BORDERTILE), "a Dirichlet-mask grid has no border tiles: everything outside is zero");
-    if constexpr (kFusedRing && !BORDERTILE && L1 == 0 && (!MASKED || kFusedRingMasked)) {
-        fused_wave_ring<T, AN, MASKED, COH>(xin, xout, bb, g, sx, ra, rb, acc, mask);
-        return;
-    }
     using Win = FusedWindow<T, UNR>;
     constexpr int HS = Win::HS, G = Win::G, NT = Win::NT;
     FusedCtx cx;

@@ -6,12 +6,13 @@
 // hyperplane tau - 1:  (x,y-1,k) and (x-1,y,k) trivially, (x+1,y,k-1) and (x,y+1,k-1) because
 // x+y+1 + 2(k-1) = tau - 1.  All points of one hyperplane are therefore independent, any order that
 // walks tau upwards reproduces the sequential sweep exactly, and one hyperplane holds pixels of many
-// iterations at once — the pipeline never drains between sweeps.  Four engines walk it (ccp_grid.hip,
-// CCP_GS_LEX_MODE):  k_lex_plane, one launch per tau, anti-diagonal d = tau - 2k of every iteration k in
-// flight (a launch writes diagonals of one parity and reads the other: no hazard inside a launch);
-// k_lex_strips, one launch, a wave per (sweep, strip of 64 columns) with neighbour-only progress words;
-// k_lex_skew, T sweeps per pass in one wave after the skew x' = x + 2t, y' = y + 2t; and k_lex_wg, the
-// default: the same skew with the T sweeps on the T waves of a workgroup, rows exchanged through LDS.
+// iterations at once — the pipeline never drains between sweeps.  Two engines walk it (ccp_grid.hip):
+// k_lex_wg, the default — time-skewed strips (x' = x + 2t, y' = y + 2t), the T sweeps of a pass on the T waves of a
+// workgroup, rows exchanged through LDS, all passes in one launch — and k_lex_plane (CCP_GS_LEX_MODE=planes), one
+// launch per tau, anti-diagonal d = tau - 2k of every iteration k in flight (a launch writes diagonals of one parity
+// and reads the other: no hazard inside a launch): the simple statement of the same order, kept as the independent
+// engine the parity tests run beside the default.  (Rounds 2-3 also carried a wave-per-sweep strip engine, the skewed
+// pass in one wave and a two-pixels-per-lane variant of k_lex_wg: all bit-identical, none faster — NOTES.md.)
 //
 // Layout: "diagonal-major" — diagonal d = x + y is row d of a (W+H-1) x P array, pixel at column x:
 //   (x,y-1) -> [d-1][x]   (x-1,y) -> [d-1][x-1]   (x+1,y) -> [d+1][x+1]   (x,y+1) -> [d+1][x]
@@ -114,168 +115,19 @@ k_lex_plane(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexG
 }
 
 // ---------------------------------------------------------------------------------------------
-// The same sweep without a launch per hyperplane: STRIP WAVES.  One wavefront owns a strip of 64 image
-// columns of one sweep k and marches down the diagonals d = x + y: lane l walks down column x0 + l, one row
-// per step, so at step d the wave's 64 pixels are exactly the strip's piece of diagonal d — one 512-byte
-// row of the diagonal-major arrays.  Of the four neighbours of a pixel
-//   up    (x, y-1), new : the lane's own previous result          (register)
-//   left  (x-1, y), new : the left lane's previous result         (DPP wave_shr; lane 0: the strip to the left)
-//   down  (x, y+1), old : row d+1 of x, same column               (coalesced load)
-//   right (x+1, y), old : the right lane's `down` value           (DPP wave_shl; lane 63: the strip to the right)
-// only the two strip-edge values come from another wave, through memory: wave (k, s) at step d needs
-//   (k, s-1) finished through diagonal d-1,  (k-1, s) and (k-1, s+1) finished through diagonal d+1,
-// exactly the hyperplane order restricted to neighbours.  Every wave publishes its progress (diagonals
-// finished) every `chunk` steps and checks its three producers once per chunk.  Hand-off through memory
-// (MI355X_MICROARCH.md, correctness boundaries: the per-XCD L2s are not coherent with each other): every
-// access to x is an agent-scope (sc1) load or store — write-through, never served from a stale line — and a
-// wave drains its stores (s_waitcnt vmcnt(0)) before it publishes the counter.  Cache-wide release/acquire
-// fences instead (buffer_wbl2 / buffer_inv per chunk and wave) were measured 4x slower: thousands of waves
-// flushing and invalidating whole L2s serialise on the caches.  In place on the diagonal-major x: a value is
-// overwritten only after every reader of the old one is past it (the readers are the producers this wave
-// waits for, or this wave itself).
-// Work items are handed out by a ticket counter in (sweep, strip) order: a wave only ever waits for tickets
-// smaller than its own, which belong to waves that have already started — no assumption about dispatch
-// order or co-residency, no deadlock.  The whole pipeline of K sweeps is ONE launch: the sweep count no
-// longer multiplies launches, and the rate is the same whether 4 or 4000 sweeps are asked for.
-// grid = (K * S, channels), block = 64.  CHECK: partial[(k*channels + ch)*S + s] = the wave's sum |new - old|.
-constexpr int kLexStripCols = kWave;
-constexpr int kLexSub = 8;               // steps per software-pipeline block
+// Hand-off through memory between workgroups of one launch (MI355X_MICROARCH.md, correctness boundaries: the per-XCD
+// L2s are not coherent with each other): every access to x that another workgroup of the launch reads or wrote is an
+// agent-scope (sc1) load or store — write-through, never served from a stale line — and a wave makes sure its stores
+// are acknowledged before it publishes a progress counter.  Cache-wide release/acquire fences instead (buffer_wbl2 /
+// buffer_inv per chunk and wave) were measured 4x slower.  Work items are handed out by a ticket counter: a workgroup
+// only ever waits for tickets smaller than its own, which belong to workgroups that have already started — no
+// assumption about dispatch order or co-residency, no deadlock.
 constexpr unsigned kLexDone = 0xffffffffu;
 
 __device__ __forceinline__ double lex_ld(const double *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void lex_st(double *p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-__device__ __forceinline__ void lex_wait(const unsigned *progress, unsigned need)
-{
-    if (progress == nullptr) return;
-    if ((threadIdx.x & (kWave - 1)) == 0) {
-        while (__hip_atomic_load(progress, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) __builtin_amdgcn_s_sleep(2);
-    }
-}
-
-template <bool CHECK>
-__global__ void __launch_bounds__(kWave)
-k_lex_strips(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int K, int S, int chunk,
-             unsigned *__restrict__ progress, unsigned *__restrict__ ticket, unsigned active_mask, double *__restrict__ partial)
-{
-    const int ch = blockIdx.y;
-    if (!((active_mask >> ch) & 1u)) return;
-    const int lane = threadIdx.x;
-    unsigned t = 0;
-    if (lane == 0) t = atomicAdd(&ticket[ch], 1u);
-    t = (unsigned)__builtin_amdgcn_readfirstlane((int)__shfl((int)t, 0, kWave));
-    const int k = (int)(t / (unsigned)S), s = (int)(t % (unsigned)S);
-    const int x0 = s * kLexStripCols, x = x0 + lane;
-    const bool col_ok = x < lg.W;
-    const int x_last = min(x0 + kLexStripCols - 1, lg.W - 1);
-    const int d_begin = x0, d_end = x_last + lg.H - 1;
-    unsigned *prog = progress + ((long)ch * K + k) * S;
-    unsigned *mine = prog + s;
-    const unsigned *left_p = s > 0 ? prog + (s - 1) : nullptr;
-    const unsigned *prev0_p = k > 0 ? prog - S + s : nullptr;
-    const unsigned *prev1_p = (k > 0 && s + 1 < S) ? prog - S + s + 1 : nullptr;
-    const long plane = (long)ch * lg.plane;
-    double prev_new = 0.0;                                   // the lane's latest result: (x, y-1) for itself, (x-1, y) for the next lane
-    double acc = 0.0;
-    for (int dc = d_begin; dc <= d_end; dc += chunk) {
-        const int de = min(dc + chunk - 1, d_end);
-        // producers: (k, s-1) through diagonal de-1; (k-1, s) and (k-1, s+1) through diagonal de+1
-        lex_wait(left_p, (unsigned)de);
-        lex_wait(prev0_p, (unsigned)(de + 2));
-        if (de + 1 >= x0 + kLexStripCols) lex_wait(prev1_p, (unsigned)(de + 2));
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");       // compiler ordering only: no load of x moves above the waits
-        // the two edge columns of this chunk, one step per lane (chunk <= 64):
-        //   left  edge: pixel (x0-1, y) on diagonal d-1, new   -> element [d-1][x0-1]
-        //   right edge: pixel (x_last+1, y) on diagonal d+1, old -> element [d+1][x_last+1]
-        double edge_left = 0.0, edge_right = 0.0;
-        {
-            const int d = dc + lane;
-            if (d <= de) {
-                if (x0 > 0) {
-                    const int yl = d - 1 - (x0 - 1);
-                    if (yl >= 0 && yl < lg.H) edge_left = lex_ld(&xd[plane + (long)(d - 1) * lg.P + (x0 - 1)]);
-                }
-                if (x_last + 1 < lg.W) {
-                    const int yr = d + 1 - (x_last + 1);
-                    if (yr >= 0 && yr < lg.H) edge_right = lex_ld(&xd[plane + (long)(d + 1) * lg.P + (x_last + 1)]);
-                }
-            }
-        }
-        // The march, software-pipelined in blocks of kLexSub steps: the loads of a block (the row below, b, and
-        // for the stop rule the old value) are issued a whole block ahead of their use, so a step never waits
-        // for memory — only the two edge gathers above and the first block of a chunk are exposed.
-        double q_down[kLexSub], q_b[kLexSub], q_old[kLexSub], n_down[kLexSub], n_b[kLexSub], n_old[kLexSub];
-        auto fetch = [&](int d0, double (&fd)[kLexSub], double (&fb)[kLexSub], double (&fo)[kLexSub]) {
-#pragma unroll
-            for (int q = 0; q < kLexSub; ++q) {
-                const int d = d0 + q, y = d - x;
-                const long i = plane + (long)d * lg.P + x;
-                const bool in_chunk = d <= de;
-                const bool on = in_chunk && col_ok && y >= 0 && y < lg.H;
-                fd[q] = 0.0;
-                fb[q] = 0.0;
-                fo[q] = 0.0;
-                // (x, y+1) on diagonal d+1, same column: also the RIGHT neighbour of the lane to the left, which is
-                // one row ahead — so it is fetched from the row before this lane's first (y = -1) as well
-                if (in_chunk && col_ok && y + 1 >= 0 && y + 1 < lg.H) fd[q] = lex_ld(&xd[i + lg.P]);
-                if (on) {
-                    fb[q] = bd[i];
-                    if (CHECK) fo[q] = lex_ld(&xd[i]);
-                }
-            }
-        };
-        fetch(dc, q_down, q_b, q_old);
-        for (int sb = dc; sb <= de; sb += kLexSub) {
-            if (sb + kLexSub <= de) fetch(sb + kLexSub, n_down, n_b, n_old);
-#pragma unroll
-            for (int q = 0; q < kLexSub; ++q) {
-                const int d = sb + q;
-                if (d <= de) {                                   // (wave-uniform)
-                    const int y = d - x;
-                    const bool on = col_ok && y >= 0 && y < lg.H;
-                    const long i = plane + (long)d * lg.P + x;
-                    const double down = q_down[q], bv = q_b[q], old = q_old[q];
-                    const int j = d - dc;
-                    double left = lane_prev(prev_new);
-                    const double el = __shfl(edge_left, j, kWave), er = __shfl(edge_right, j, kWave);
-                    if (lane == 0) left = el;
-                    double right = lane_next(down);
-                    if (x == x_last) right = er;
-                    if (on) {
-                        const Stencil st = classify(g, x, y, y);
-                        if (st.diag != 0) {                      // empty row: skipped (sparse-matrix.h:361-363)
-                            double nv;
-                            if (st.up && st.left && st.right && st.down && st.diag == 4) nv = (bv + (((prev_new + left) + right) + down)) * 0.25;
-                            else (void)gs_update(st, bv, prev_new, left, right, down, nv);
-                            if (CHECK) acc += fabs(nv - old);
-                            lex_st(&xd[i], nv);
-                            prev_new = nv;
-                        } else {
-                            prev_new = lex_ld(&xd[i]);           // the value the row keeps is what its neighbours see
-                        }
-                    }
-                }
-            }
-#pragma unroll
-            for (int q = 0; q < kLexSub; ++q) {
-                q_down[q] = n_down[q];
-                q_b[q] = n_b[q];
-                q_old[q] = n_old[q];
-            }
-        }
-        // publish: every lane's (write-through) stores acknowledged, then the counter
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // compiler ordering only
-        __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0) __hip_atomic_store(mine, de == d_end ? kLexDone : (unsigned)(de + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (CHECK) {
-        const double total = wave_sum(acc);
-        if (lane == 0) partial[((long)k * gridDim.y + ch) * S + s] = total;
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// Temporal blocking of the reference-order sweep: T sweeps per pass through memory (k_lex_skew).
+// Temporal blocking of the reference-order sweep: T sweeps per pass through memory.
 // A red-black pass can recompute halos redundantly; the index-order sweep cannot (the left neighbour is the
 // NEW value of the same sweep, which depends on the whole row to its left).  What it can do is SKEW: with
 //     x' = x + 2t,  y' = y + 2t      (t = sweep inside the group of T)
@@ -283,160 +135,18 @@ k_lex_strips(double *__restrict__ xd, const double *__restrict__ bd, Geom g, Lex
 //     (x-1, y, t) -> (x'-1, y',   t)      (x, y-1, t)   -> (x',   y'-1, t)
 //     (x+1, y, t-1) -> (x'-1, y'-2, t-1)  (x, y+1, t-1) -> (x'-2, y'-1, t-1)
 // all point to smaller x' (or equal x' and smaller y'): strips in x' depend on the strip to their LEFT only.
-// A wavefront owns 64 skewed columns and marches down the skewed diagonals d' = x' + y'; at every step each
-// lane updates its pixel of ALL T sweeps (pixel (x'-2t, y'-2t) of sweep t) — T independent updates — from
-// registers: its own results of the last three steps per sweep (h1..h3; h4 for the stop rule's old value)
-// and its left neighbours' by DPP:
-//     up = h1[t]   left = shr1(h1[t])   right = shr1(h3[t-1])   down = shr2(h3[t-1])   old = shr2(h4[t-1]).
-// Only sweep 0 reads x (the previous group's result: rows d'+1 and, for the stop rule, d') and only sweep T-1
-// writes it: 16/T B per update plus b (8 B, re-read by every sweep) instead of 32 B.
-// Lanes 0 and 1 are GHOST lanes: they carry the results of the left strip's lanes 62 and 63 (2T doubles per
-// step, written by that strip to `edges`, read back here) so every DPP shift is uniform; a strip therefore
-// advances 62 skewed columns.  Producers of wave (group, s): (group, s-1) through the same step; (group-1, s)
-// and (group-1, s+1) through step + 1 + 4(T-1) (they wrote the x this group's sweep 0 reads).  Progress
-// counters, tickets, sc1 hand-off as in k_lex_strips.
-// grid = (G * S, channels), block = 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
+// A strip owns 64 skewed columns and marches down the skewed diagonals d' = x' + y'; lane l walks down skewed column
+// xs0 + l, so `up` is the lane's own previous result and `left` the left lane's (DPP); sweep t takes `right` and `down`
+// from sweep t-1's results three steps back, one and two lanes to the left.  Lanes 0 and 1 are GHOST lanes: they carry
+// the results of the left strip's lanes 62 and 63 (2T doubles per step, written by that strip to `edges`, read back
+// here) so every lane shift is uniform; a strip therefore advances 62 skewed columns.  Producers of strip (group, s):
+// (group, s-1) through the same step; (group-1, s) and (group-1, s+1) through step + 1 + 4(T-1) (they wrote the x this
+// group's sweep 0 reads).  Only sweep 0 reads x and only sweep T-1 writes it; b is read once per pass.
 constexpr int kLexSkewCols = kWave - 2;
-constexpr int kLexSkewAhead = 4;         // steps the loads run ahead of the computation (ring of register slots)
-
-__device__ __forceinline__ double lane_prev2(double v) { return lane_prev(lane_prev(v)); }
-
-template <int T, bool CHECK>
-__global__ void __launch_bounds__(kWave)
-k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S, int chunk,
-           unsigned *__restrict__ progress, unsigned *__restrict__ ticket, double *__restrict__ edges, long edge_steps,
-           unsigned active_mask, double *__restrict__ partial, long partial_stride)
-{
-    const int ch = blockIdx.y;
-    if (!((active_mask >> ch) & 1u)) return;
-    const int lane = threadIdx.x;
-    unsigned tk = 0;
-    if (lane == 0) tk = atomicAdd(&ticket[ch], 1u);
-    tk = (unsigned)__builtin_amdgcn_readfirstlane((int)__shfl((int)tk, 0, kWave));
-    const int grp = (int)(tk / (unsigned)S), s = (int)(tk % (unsigned)S);
-    const int HS = lg.H + 2 * (T - 1);                        // skewed rows
-    const int xs0 = kLexSkewCols * s - 2;                     // skewed column of lane 0 (a ghost lane)
-    const int xp = xs0 + lane;
-    const bool ghost = lane < 2;
-    const int d_begin = xs0, d_end = xs0 + (kWave - 1) + HS - 1;
-    unsigned *prog = progress + ((long)ch * G + grp) * S;
-    unsigned *mine = prog + s;
-    const unsigned *left_p = s > 0 ? prog + (s - 1) : nullptr;
-    const unsigned *prev0_p = grp > 0 ? prog - S + s : nullptr;
-    const unsigned *prev1_p = (grp > 0 && s + 1 < S) ? prog - S + s + 1 : nullptr;
-    const long plane = (long)ch * lg.plane;
-    double *e_mine = edges + ((long)ch * S + s) * edge_steps * (2 * T);
-    const double *e_left = s > 0 ? edges + ((long)ch * S + s - 1) * edge_steps * (2 * T) : nullptr;
-    const int left_begin = xs0 - kLexSkewCols, left_end = left_begin + (kWave - 1) + HS - 1;
-    double h1[T], h2[T], h3[T], h4[T], acc[T];
-#pragma unroll
-    for (int t = 0; t < T; ++t) h1[t] = h2[t] = h3[t] = h4[t] = acc[t] = 0.0;
-    // Everything a step reads from memory is independent of the computation, so it is fetched kLexSkewAhead steps
-    // early into a ring of registers (slot = step mod kLexSkewAhead, refilled as soon as it has been consumed):
-    // sweep 0's two x values (and the old value for the stop rule), and per sweep one value that is b for a real
-    // lane and the left strip's result for a ghost lane.
-    constexpr int PF = kLexSkewAhead;
-    double q_dn[PF], q_rt[PF], q_old[PF], q_v[PF][T];
-    auto fetch = [&](int d, double &dn0, double &rt0, double &old0, double (&v)[T]) {
-        const int yp = d - xp;
-        dn0 = 0.0;
-        rt0 = 0.0;
-        old0 = 0.0;
-        const bool live = d <= d_end;
-        // sweep 0's inputs from x: (xp, yp+1) and (xp+1, yp) on diagonal d+1; for the stop rule (xp, yp) itself
-        if (live && xp >= 0 && xp < lg.W && yp + 1 >= 0 && yp + 1 < lg.H) dn0 = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp]);
-        if (live && xp + 1 >= 0 && xp + 1 < lg.W && yp >= 0 && yp < lg.H) rt0 = lex_ld(&xd[plane + (long)(d + 1) * lg.P + xp + 1]);
-        if (CHECK && live && xp >= 0 && xp < lg.W && yp >= 0 && yp < lg.H) old0 = lex_ld(&xd[plane + (long)d * lg.P + xp]);
-        const bool left_live = live && e_left != nullptr && d >= left_begin && d <= left_end;
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const int x = xp - 2 * t, y = yp - 2 * t;
-            v[t] = 0.0;
-            if (ghost) {                                                     // the left strip's lanes 62 / 63 of this step
-                if (left_live) v[t] = lex_ld(&e_left[((long)(d - left_begin) * T + t) * 2 + lane]);
-            } else if (live && x >= 0 && x < lg.W && y >= 0 && y < lg.H) {
-                v[t] = bd[plane + (long)(x + y) * lg.P + x];
-            }
-        }
-    };
-    bool primed = false;
-    for (int dc = d_begin; dc <= d_end; dc += chunk) {
-        const int de = min(dc + chunk - 1, d_end);
-        // producers, PF steps beyond the chunk (the ring is refilled that far ahead)
-        lex_wait(left_p, (unsigned)(de + PF + 1));                         // the left strip through step de + PF
-        lex_wait(prev0_p, (unsigned)(de + PF + 2 + 4 * (T - 1)));          // the previous group's x, rows up to de + PF + 1
-        lex_wait(prev1_p, (unsigned)(de + PF + 2 + 4 * (T - 1)));
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");             // compiler ordering only
-        if (!primed) {
-#pragma unroll
-            for (int j = 0; j < PF; ++j) fetch(d_begin + j, q_dn[j], q_rt[j], q_old[j], q_v[j]);
-            primed = true;
-        }
-        for (int db = dc; db <= de; db += PF) {
-#pragma unroll
-            for (int j = 0; j < PF; ++j) {
-                const int d = db + j;
-                if (d <= de) {                                               // (wave-uniform; chunk is a multiple of PF)
-                    const int yp = d - xp;
-                    const double dn0 = q_dn[j], rt0 = q_rt[j], old0 = q_old[j];
-                    double vv[T];
-#pragma unroll
-                    for (int t = 0; t < T; ++t) vv[t] = q_v[j][t];
-                    fetch(d + PF, q_dn[j], q_rt[j], q_old[j], q_v[j]);     // the slot is free again: refill it for step d + PF
-                    double nh[T];
-#pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        const int x = xp - 2 * t, y = yp - 2 * t;
-                        const bool on = !ghost && x >= 0 && x < lg.W && y >= 0 && y < lg.H;
-                        const double up = h1[t];
-                        const double left = lane_prev(h1[t]);
-                        const double right = t == 0 ? rt0 : lane_prev(h3[t > 0 ? t - 1 : 0]);
-                        const double down = t == 0 ? dn0 : lane_prev2(h3[t > 0 ? t - 1 : 0]);
-                        // (every DPP read happens here, with all lanes active: a source lane masked out by a branch reads as 0)
-                        const double old = !CHECK ? 0.0 : (t == 0 ? old0 : lane_prev2(h4[t > 0 ? t - 1 : 0]));
-                        double nv = ghost ? vv[t] : 0.0;
-                        if (on) {
-                            const double bv = vv[t];
-                            const Stencil st = classify(g, x, y, y);
-                            if (st.diag != 0) {
-                                if (st.up && st.left && st.right && st.down && st.diag == 4) nv = (bv + (((up + left) + right) + down)) * 0.25;
-                                else (void)gs_update(st, bv, up, left, right, down, nv);
-                                if (CHECK) acc[t] += fabs(nv - old);
-                                if (t == T - 1) lex_st(&xd[plane + (long)(x + y) * lg.P + x], nv);
-                            }
-                        }
-                        nh[t] = nv;
-                    }
-                    if (lane >= kWave - 2) {
-#pragma unroll
-                        for (int t = 0; t < T; ++t) lex_st(&e_mine[((long)(d - d_begin) * T + t) * 2 + (lane - (kWave - 2))], nh[t]);
-                    }
-#pragma unroll
-                    for (int t = 0; t < T; ++t) {
-                        if (CHECK) h4[t] = h3[t];
-                        h3[t] = h2[t];
-                        h2[t] = h1[t];
-                        h1[t] = nh[t];
-                    }
-                }
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // compiler ordering only
-        __builtin_amdgcn_s_waitcnt(0);
-        if (lane == 0) __hip_atomic_store(mine, de == d_end ? kLexDone : (unsigned)(de + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (CHECK) {
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-            const double total = wave_sum(acc[t]);
-            if (lane == 0) partial[(((long)grp * T + t) * gridDim.y + ch) * partial_stride + s] = total;
-        }
-    }
-}
 
 // ---------------------------------------------------------------------------------------------
-// The skewed pass with the T sweeps spread over the waves of a workgroup (k_lex_wg).  Same skew, strips, ghost
-// lanes, edge buffer, progress words and tickets as k_lex_skew, but a workgroup of T + 2 waves per strip:
+// The skewed pass with the T sweeps spread over the waves of a workgroup (k_lex_wg): a workgroup of T + 2 waves per
+// strip:
 //
 //   waves 0 .. T-1   one sweep each.  Wave t reads its inputs from LDS only — the results of sweep t-1 three and
 //                    steps back (one and two lanes to the left) from a ring of the last 4 result rows per
@@ -465,7 +175,7 @@ k_lex_skew(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGe
 constexpr bool kLexShiftDown = CCP_LEX_SHIFT_DOWN != 0;   // interior bodies of k_lex_wg: `down` from `right` by a lane shift
 constexpr int kLexRing = 4;                        // result rows kept per sweep: written at step d, read at step d+3, free at d+4
 constexpr int kLexBRows = 32;
-constexpr int kLexSlackRows = 320;                 // diagonal rows allocated beyond the last one (k_lex_wg / k_lex_wg2 prefetch past the image: up to ~160 rows at 128-column strips)
+constexpr int kLexSlackRows = 320;                 // diagonal rows allocated beyond the last one (k_lex_wg prefetches past the image)
 constexpr int kLexScratch = 32;                    // doubles per workgroup the storer of k_lex_wg may write to and nobody reads
 constexpr int kLexStoresPerBlock = 8 * 2 + 1;      // k_lex_wg's storer: two stores per step (x row, edge values) + the publication, per 8-step block
 constexpr int kLexPublishLagBlocks = 2;            // ... publishes the steps before block db - 8*2 ...

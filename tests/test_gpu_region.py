@@ -161,7 +161,7 @@ def test_region_in_the_references_own_order(capi, orc, monkeypatch, name):
     x, _ = m.gauss_seidel(b, 0.0, 4, x0=x0, check_every=0)
     assert np.array_equal(x, orc.multicolour_gauss_seidel(v, c, r, col, b, 0.0, 4, x0=x0)[0]), (name, nc, m.last_path())
     m.close()
-    for var, val in (("CCP_GS_LEX_MODE", "strips"), ("CCP_GS_MASKED", "0")):      # an engine that knows no masks; no region grid
+    for var, val in (("CCP_GS_LEX_MODE", "planes"), ("CCP_GS_MASKED", "0")):      # an engine that knows no masks; no region grid
         monkeypatch.setenv(var, val)
         m = capi.CsrMatrix().upload_compressed(v, c, r)
         x, _ = m.gauss_seidel(b, 0.0, 8, x0=x0, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
