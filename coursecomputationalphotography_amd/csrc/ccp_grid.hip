@@ -1461,9 +1461,16 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     }
     const dim3 block((T + 2) * kWave);
     double *nop = nullptr;
+    unsigned long long *trace = nullptr;
+    const size_t trace_words = (size_t)4 * C * groups * S;
+    if (g->trace_file) {
+        if (g->trace.n < trace_words) CCP_TRY(g->trace.alloc(trace_words));
+        CCP_HIP(hipMemsetAsync(g->trace.p, 0, trace_words * sizeof(unsigned long long), g->stream));
+        trace = g->trace.p;
+    }
 #define CCP_LEX_WG(KERNEL, CHECK, P, STRIDE)                                                                                        \
     hipLaunchKernelGGL((KERNEL<T, CHECK>), grid, block, 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,                \
-                       g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, P, STRIDE)
+                       g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, P, STRIDE, trace)
     if (g->masked) {
         if (partial) CCP_LEX_WG(k_lex_wg_masked, true, partial, lex_partials_per_sweep(g));
         else CCP_LEX_WG(k_lex_wg_masked, false, nop, 0L);
@@ -1473,6 +1480,19 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     }
 #undef CCP_LEX_WG
     CCP_HIP(hipGetLastError());
+    if (trace) {
+        CCP_HIP(hipStreamSynchronize(g->stream));
+        std::vector<unsigned long long> host(trace_words);
+        CCP_HIP(hipMemcpy(host.data(), trace, host.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(g->trace_file, "ab")) {
+            // (the same 8-word header as the fused passes' records, tag "LEXTRAC")
+            const unsigned long long head[8] = {0x4341525458454cull, (unsigned long long)T, (unsigned long long)groups, (unsigned long long)S,
+                                                (unsigned long long)C, (unsigned long long)lg.H, (unsigned long long)host.size(), (unsigned long long)lg.W};
+            fwrite(head, sizeof(head), 1, f);
+            fwrite(host.data(), sizeof(unsigned long long), host.size(), f);
+            fclose(f);
+        }
+    }
     return CCP_OK;
 }
 }  // extern "C++"

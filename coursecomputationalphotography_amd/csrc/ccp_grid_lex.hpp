@@ -375,7 +375,7 @@ __device__ __forceinline__ void lex_wg_gate(LexWgStrip &st, int db)
 template <int T, bool MASKED>
 __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexRing][kWave], double (*brow)[LexWgShape<T>::kRowW], int lane,
                                             int db0, int db1, const double *bp, const double *xq, long P, int n_diag, int W, int H, int cb,
-                                            int xs0, const double *e_left, int left_begin, int left_end)
+                                            int xs0, const double *e_left, int left_begin, int left_end, unsigned long long *tr)
 {
     constexpr int kCols = LexWgShape<T>::kCols, kGhost = LexWgShape<T>::kGhost;
     constexpr int kGhostOps = (16 * T + kWave - 1) / kWave;                  // 64-lane loads per ghost batch
@@ -404,6 +404,7 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
     };
     auto ghost_valid = [&](int blk, int q) { const int d = blk + g_k(q); return e_left != nullptr && d >= left_begin && d <= left_end; };
     lex_wg_gate(st, db0);
+    if (tr && lane == 0) tr[1] = wall_clock64();
     {   // what the first steps read before the rings are rolling: x rows db0, db0+1, db0+2 and the ghost values of
         // block db0 (the b rows up to db0: by all waves, in the kernel)
 #pragma unroll
@@ -539,7 +540,8 @@ template <int T, bool CHECK, bool MASKED>
 __device__ __forceinline__ void lex_wg_body(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S,
                                             unsigned *__restrict__ progress, unsigned *__restrict__ ticket,
                                             const unsigned *__restrict__ order, double *__restrict__ edges, long edge_steps,
-                                            unsigned active_mask, double *__restrict__ partial, long partial_stride)
+                                            unsigned active_mask, double *__restrict__ partial, long partial_stride,
+                                            unsigned long long *__restrict__ trace)
 {
     static_assert(kLexRing == 4 && T >= 1, "the unrolled step index mod 4 is the ring slot");
     static_assert(4 * (T - 1) + 4 <= kLexBRows, "a b row stays in LDS from step r-1 to step r+4(T-1)");
@@ -561,6 +563,14 @@ __device__ __forceinline__ void lex_wg_body(double *__restrict__ xd, const doubl
     __syncthreads();
     const unsigned tk = order[s_ticket];                     // (group, strip) in wavefront order
     const int grp = (int)(tk / (unsigned)S), s = (int)(tk % (unsigned)S);
+    // CCP_GS_TRACE_FILE (diagnostics): per workgroup — ticket taken, first gate passed, last step done, where it ran
+    unsigned long long *tr = trace ? trace + 4 * ((long)ch * G * S + s_ticket) : nullptr;
+    if (tr && threadIdx.x == 0) {
+        tr[0] = wall_clock64();
+        tr[3] = (unsigned long long)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffffffu)         // HW_REG_HW_ID
+                | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 24)                 // HW_REG_XCC_ID[3:0]
+                | ((unsigned long long)tk << 32);
+    }
     const int HS = lg.H + 2 * (T - 1);
     const int xs0 = kLexSkewCols * s - 2;
     const int xl = xs0 + lane - 2 * t;                       // this lane's image column
@@ -625,7 +635,7 @@ __device__ __forceinline__ void lex_wg_body(double *__restrict__ xd, const doubl
             if (lane == 0) partial[(((long)grp * T + t) * gridDim.y + ch) * partial_stride + s] = total;
         }
     } else if (wv == T) {
-        lex_wg_load<T, MASKED>(st, ring, brow, lane, db0, db1, bd + plane, xd + plane, lg.P, lg.n_diag, lg.W, lg.H, cb, xs0, e_left, left_begin, left_end);
+        lex_wg_load<T, MASKED>(st, ring, brow, lane, db0, db1, bd + plane, xd + plane, lg.P, lg.n_diag, lg.W, lg.H, cb, xs0, e_left, left_begin, left_end, tr);
     } else {
         // (scratch: kLexScratch doubles per workgroup behind the edge values of all strips)
         double *scratch = edges + (long)gridDim.y * S * edge_steps * (2 * T) + (((long)ch * G + grp) * S + s) * kLexScratch;
@@ -635,6 +645,7 @@ __device__ __forceinline__ void lex_wg_body(double *__restrict__ xd, const doubl
     __builtin_amdgcn_s_waitcnt(0);                                           // this wave's (write-through) stores acknowledged
     lex_lds_barrier();
     if (wv == T + 1 && lane == 0) __hip_atomic_store(st.mine, kLexDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
 }
 
 // The kernels.  Two workgroups share a CU only if 6 of their waves fit one SIMD (a workgroup's T + 2 = 10 waves go
@@ -646,18 +657,18 @@ template <int T, bool CHECK>
 __global__ void __launch_bounds__((T + 2) * kWave) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S, unsigned *__restrict__ progress,
          unsigned *__restrict__ ticket, const unsigned *__restrict__ order, double *__restrict__ edges, long edge_steps,
-         unsigned active_mask, double *__restrict__ partial, long partial_stride)
+         unsigned active_mask, double *__restrict__ partial, long partial_stride, unsigned long long *__restrict__ trace)
 {
-    lex_wg_body<T, CHECK, false>(xd, bd, g, lg, G, S, progress, ticket, order, edges, edge_steps, active_mask, partial, partial_stride);
+    lex_wg_body<T, CHECK, false>(xd, bd, g, lg, G, S, progress, ticket, order, edges, edge_steps, active_mask, partial, partial_stride, trace);
 }
 
 template <int T, bool CHECK>
 __global__ void __launch_bounds__((T + 2) * kWave)
 k_lex_wg_masked(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S, unsigned *__restrict__ progress,
-                unsigned *__restrict__ ticket, const unsigned *__restrict__ order, double *__restrict__ edges, long edge_steps,
-                unsigned active_mask, double *__restrict__ partial, long partial_stride)
+         unsigned *__restrict__ ticket, const unsigned *__restrict__ order, double *__restrict__ edges, long edge_steps,
+         unsigned active_mask, double *__restrict__ partial, long partial_stride, unsigned long long *__restrict__ trace)
 {
-    lex_wg_body<T, CHECK, true>(xd, bd, g, lg, G, S, progress, ticket, order, edges, edge_steps, active_mask, partial, partial_stride);
+    lex_wg_body<T, CHECK, true>(xd, bd, g, lg, G, S, progress, ticket, order, edges, edge_steps, active_mask, partial, partial_stride, trace);
 }
 
 // eps[k*channels + ch] = sum of the partials of iteration k in a fixed order.  grid = (iterations, channels)
