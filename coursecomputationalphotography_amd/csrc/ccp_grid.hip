@@ -1453,12 +1453,19 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     if (!g->lex_ticket.p) CCP_TRY(g->lex_ticket.alloc(kMaxChannels));
     CCP_HIP(hipMemsetAsync(g->lex_progress.p, 0, need * sizeof(unsigned), g->stream));
     CCP_HIP(hipMemsetAsync(g->lex_ticket.p, 0, kMaxChannels * sizeof(unsigned), g->stream));
-    dim3 grid((unsigned)((long)groups * S), (unsigned)C);
-    if (getenv("CCP_GS_DEBUG")) {
-        int nb = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, k_lex_wg<T, false>, (T + 2) * kWave, 0);
-        fprintf(stderr, "[ccp_gs] k_lex_wg<%d>: %d workgroups per CU, %d groups x %d strips\n", T, nb, groups, S);
-    }
+    // persistent workgroups: as many as are resident at once (k_lex_wg's comment), each taking strips from the ticket counter
+    int per_cu = 0, cus = 0;
+    if (g->masked) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wg_masked<T, false>, (T + 2) * kWave, 0);
+    else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wg<T, false>, (T + 2) * kWave, 0);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device);
+    static const bool one_per_strip = getenv("CCP_GS_LEX_PERSISTENT") && atoi(getenv("CCP_GS_LEX_PERSISTENT")) == 0;   // A/B: a workgroup per strip
+    long resident = (long)std::max(per_cu, 1) * std::max(cus, 1);
+    if (one_per_strip) resident = (long)groups * S * C;
+    const long wgs = std::max<long>(1, std::min<long>((long)groups * S, (resident + C - 1) / C));
+    dim3 grid((unsigned)wgs, (unsigned)C);
+    if (getenv("CCP_GS_DEBUG"))
+        fprintf(stderr, "[ccp_gs] k_lex_wg<%d>: %d workgroups per CU on %d CUs, %ld persistent workgroups per channel for %d groups x %d strips\n",
+                T, per_cu, cus, wgs, groups, S);
     const dim3 block((T + 2) * kWave);
     double *nop = nullptr;
     unsigned long long *trace = nullptr;
@@ -1469,8 +1476,9 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
         trace = g->trace.p;
     }
 #define CCP_LEX_WG(KERNEL, CHECK, P, STRIDE)                                                                                        \
-    hipLaunchKernelGGL((KERNEL<T, CHECK>), grid, block, 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S,                \
-                       g->lex_progress.p, g->lex_ticket.p, g->lex_order.p, g->lex_edges.p, edge_steps, mask, P, STRIDE, trace)
+    hipLaunchKernelGGL((KERNEL<T, CHECK>), grid, block, 0, g->stream,                                                                \
+                       LexWgArgs{g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S, g->lex_progress.p, g->lex_ticket.p, g->lex_order.p,  \
+                                 g->lex_edges.p, edge_steps, mask, P, STRIDE, trace})
     if (g->masked) {
         if (partial) CCP_LEX_WG(k_lex_wg_masked, true, partial, lex_partials_per_sweep(g));
         else CCP_LEX_WG(k_lex_wg_masked, false, nop, 0L);

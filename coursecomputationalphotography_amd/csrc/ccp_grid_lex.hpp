@@ -168,7 +168,7 @@ constexpr int kLexSkewCols = kWave - 2;
 //      the rest — every strip waits on its left neighbour);
 //   C  anything else (the first and last ~10 blocks of a strip): classify / gs_update at every step.
 // All three read their inputs from the rings: no wave but the loader loads, no wave but the storer stores.
-// grid = (G * S, channels), block = (T + 2) * 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
+// grid = (min(G * S, resident workgroups), channels), block = (T + 2) * 64.  CHECK: partial[((group*T + t)*channels + ch)*partial_stride + s].
 #ifndef CCP_LEX_SHIFT_DOWN
 #define CCP_LEX_SHIFT_DOWN 1
 #endif
@@ -215,13 +215,64 @@ __device__ __forceinline__ double lex_div3(double a, bool &finite)
     return r == 0.0 ? q0 : q1;
 }
 
+// The left strip's edge values ("ghost values": its lanes 62 / 63 of every sweep and step, 2T doubles per step in `edges`)
+// come in once per 8-step block, as one batch, into spare columns of the b rows in LDS: value (sweep g_t, step blk + g_k,
+// edge g_e) goes to b row (blk + g_k - 4 g_t), column kGhost + 2 g_t + g_e, where that sweep's ghost lanes read it as
+// their "b".  Compute wave 0 carries the batch beside its sweep (round 4; the loader did it before: it needed 82 VGPRs for
+// an 80-VGPR budget, and in the persistent form of the kernel a spill landed inside its prefetch loop).  The batch of
+// block blk + 8 is fetched behind the first barrier of block blk — the loader passes the block's gate, which vouches for
+// the left strip's steps up to blk + 15, before it gets there — and written before the block's last barrier.
+template <int T>
+struct LexGhosts {
+    static constexpr int kOps = (16 * T + kWave - 1) / kWave;               // 64-lane loads per batch
+    static constexpr int kGhost = LexWgShape<T>::kGhost;
+    const double *e_left;                                                    // nullptr: strip 0 (its ghost lanes lie off the image)
+    int left_begin, left_end;
+    bool on;                                                                 // this wave carries the batch (wave 0; uniform)
+    double q[kOps];
+    __device__ __forceinline__ bool lane_on(int lane, int k) const { return k * kWave + lane < 16 * T; }
+    __device__ __forceinline__ int g_t(int lane, int k) const { return min((k * kWave + lane) >> 4, T - 1); }
+    __device__ __forceinline__ int g_k(int lane) const { return (lane & 15) >> 1; }
+    __device__ __forceinline__ int g_col(int lane, int k) const { return kGhost + 2 * g_t(lane, k) + (lane & 1); }
+    // raw: whether the step exists is applied where the value is used — a select right behind the load would wait for it
+    __device__ __forceinline__ void issue(int blk, int lane)
+    {
+        // (worked out from the lane at every use: hoisted out of the block loop, the per-lane addresses are two more
+        // vector registers per load that live — and spill — across the step loops of every compute wave)
+        asm volatile("" : "+v"(lane));
+#pragma unroll
+        for (int k = 0; k < kOps; ++k) {
+            const int d = blk + g_k(lane);
+            q[k] = e_left == nullptr ? 0.0
+                                     : lex_ld(e_left + ((long)(min(max(d, left_begin), left_end) - left_begin) * T + g_t(lane, k)) * 2 + (lane & 1));
+        }
+    }
+    __device__ __forceinline__ void write(double (*brow)[LexWgShape<T>::kRowW], int blk, int lane) const
+    {
+        asm volatile("" : "+v"(lane));
+#pragma unroll
+        for (int k = 0; k < kOps; ++k) {
+            const int d = blk + g_k(lane);
+            const bool valid = e_left != nullptr && d >= left_begin && d <= left_end;
+            if (lane_on(lane, k)) brow[(d - 4 * g_t(lane, k)) & (kLexBRows - 1)][g_col(lane, k)] = valid ? q[k] : 0.0;
+        }
+    }
+    // step j of block db
+    __device__ __forceinline__ void step(double (*brow)[LexWgShape<T>::kRowW], int db, int j, int lane)
+    {
+        if (!on) return;
+        if (j == 1) issue(db + 8, lane);
+        if (j == 7) write(brow, db + 8, lane);
+    }
+};
+
 // One block (8 steps from db) of compute wave t with the general body C: a lane's pixel and row are worked out
 // at every step (classify / gs_update).  Inputs come from the rings like everywhere else.  A rolled loop: it runs
 // for the ~20 blocks at the two ends of a strip only.
 template <int T, bool CHECK>
 __device__ __forceinline__ void lex_wg_general_block(double &h1, double &acc, double &old, double (*ring)[kLexRing][kWave],
-                                                               const double (*brow)[LexWgShape<T>::kRowW], Geom g, int W, int H, int t,
-                                                               int lane, int db, int xp)
+                                                               double (*brow)[LexWgShape<T>::kRowW], Geom g, int W, int H, int t,
+                                                               int lane, int db, int xp, LexGhosts<T> &gh)
 {
     const bool ghost = lane < 2;
     const int lds2 = max(lane - 2, 0);
@@ -248,6 +299,7 @@ __device__ __forceinline__ void lex_wg_general_block(double &h1, double &acc, do
         old = down;
         ring[t + 1][j & (kLexRing - 1)][lane] = nv;
         h1 = nv;
+        gh.step(brow, db, j, lane);
         lex_lds_barrier();
     }
 }
@@ -262,8 +314,8 @@ __device__ __forceinline__ void lex_wg_general_block(double &h1, double &acc, do
 // take body C.  ring[t] holds sweep t's INPUT rows (ring[0]: x, filled by the loader), ring[t+1] its results.
 template <int T, bool CHECK, int KIND>
 __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (*ring)[kLexRing][kWave],
-                                               const double (*brow)[LexWgShape<T>::kRowW], Geom g, int W, int H, int t, int lane,
-                                               int db0, int db1, int xs0, bool lane_on, Stencil st_b)
+                                               double (*brow)[LexWgShape<T>::kRowW], Geom g, int W, int H, int t, int lane,
+                                               int db0, int db1, int xs0, bool lane_on, Stencil st_b, LexGhosts<T> &gh)
 {
     const bool ghost = lane < 2;
     const int lds2 = max(lane - 2, 0), lds1 = max(lane - 1, 0);
@@ -275,7 +327,7 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
     double old = 0.0;
     for (int db = db0; db <= db1; db += 8) {
         if (db < in_lo || db + 7 > in_hi) {
-            lex_wg_general_block<T, CHECK>(h1, acc, old, ring, brow, g, W, H, t, lane, db, xs0 + lane);
+            lex_wg_general_block<T, CHECK>(h1, acc, old, ring, brow, g, W, H, t, lane, db, xs0 + lane, gh);
             continue;
         }
         const int sb = (db - 4 * t) & (kLexBRows - 1);
@@ -306,6 +358,7 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
             old = down;                                                      // ... is what was `down` one step (one row) earlier
             ring[t + 1][j & (kLexRing - 1)][lane] = nv;
             h1 = nv;
+            gh.step(brow, db, j, lane);
             lex_lds_barrier();
         }
     }
@@ -315,7 +368,7 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
 // the marker — not an unknown, or off the canvas (the loader puts the marker there) — stays 0.
 template <int T, bool CHECK>
 __device__ __forceinline__ void lex_wg_compute_masked(double &h1, double &acc, double (*ring)[kLexRing][kWave],
-                                                      const double (*brow)[LexWgShape<T>::kRowW], int t, int lane, int db0, int db1)
+                                                      double (*brow)[LexWgShape<T>::kRowW], int t, int lane, int db0, int db1, LexGhosts<T> &gh)
 {
     const bool ghost = lane < 2;
     const int lds2 = max(lane - 2, 0), lds1 = max(lane - 1, 0);
@@ -337,6 +390,7 @@ __device__ __forceinline__ void lex_wg_compute_masked(double &h1, double &acc, d
             old = down;
             ring[t + 1][j & (kLexRing - 1)][lane] = nv;
             h1 = nv;
+            gh.step(brow, db, j, lane);
             lex_lds_barrier();
         }
     }
@@ -364,21 +418,22 @@ __device__ __forceinline__ void lex_wg_gate(LexWgStrip &st, int db)
     }
 }
 
-// The loader's side of blocks db0 .. db1 (the whole strip).  Rows and columns outside the arrays are clamped:
-// what such a load fetches is never used, and no load is conditional.  Every slot of the register rings is
-// refilled only after its old contents have been used (a load issued while the old value is live lands in
-// another register and costs a copy and a full drain at the loop's back edge).
+// The loader's side of blocks db0 .. db1 (the whole strip): the b rows, the x rows of sweep 0, and the gate — it is the
+// wave that watches the strips this one depends on and so holds the others back at the step's barrier.  Rows and columns
+// outside the arrays are clamped: what such a load fetches is never used, and no load is conditional.  Every slot of the
+// register rings is refilled only after its old contents have been used (a load issued while the old value is live lands
+// in another register and costs a copy and a full drain at the loop's back edge).
 //   bp, xq     b and x of this channel (diagonal-major: element (row r, column c) at r*P + c)
 //   cb         the leftmost image column any sweep of the strip touches (b row in LDS: column c - cb)
 //   MASKED     Dirichlet-mask grid: what lies off the canvas is made "not an unknown" (b: the marker) holding 0 (x)
 //              as it goes into LDS — there, not behind the load, where a select would wait for the load.
+// (The left strip's edge values are compute wave 0's job since round 4: LexGhosts.)
 template <int T, bool MASKED>
 __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexRing][kWave], double (*brow)[LexWgShape<T>::kRowW], int lane,
                                             int db0, int db1, const double *bp, const double *xq, long P, int n_diag, int W, int H, int cb,
-                                            int xs0, const double *e_left, int left_begin, int left_end, unsigned long long *tr)
+                                            int xs0, unsigned long long *tr)
 {
-    constexpr int kCols = LexWgShape<T>::kCols, kGhost = LexWgShape<T>::kGhost;
-    constexpr int kGhostOps = (16 * T + kWave - 1) / kWave;                  // 64-lane loads per ghost batch
+    constexpr int kCols = LexWgShape<T>::kCols;
     const unsigned c_b0 = (unsigned)min(max(cb + lane, 0), W - 1);
     const unsigned c_b1 = (unsigned)min(max(cb + kWave + min(lane, max(kCols - kWave - 1, 0)), 0), W - 1);
     const unsigned c_x = (unsigned)min(max(xs0 + 2 + min(lane, kWave - 2), 0), W - 1);   // as sweep 0's lanes 2.. read x: one and two places to their left
@@ -389,32 +444,13 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
     auto on_canvas = [&](int r, int c) { return c >= 0 && c < W && (unsigned)(r - c) < (unsigned)H; };
     auto b_in = [&](double v, int r, int c) { return (!MASKED || on_canvas(r, c)) ? v : lex_fixed_marker(); };
     auto x_in = [&](double v, int r, int c) { return (!MASKED || (lane < kWave - 1 && on_canvas(r, c))) ? v : 0.0; };
-    // lane's ghost value(s) of a block: sweep g_t, step g_k, edge g_e -> b row (d - 4 g_t), column kGhost + 2 g_t + g_e
-    // (worked out from the lane where needed: the loader is the wave that decides the kernel's register count)
-    auto g_on = [&](int q) { return q * kWave + lane < 16 * T; };
-    auto g_t = [&](int q) { return min((q * kWave + lane) >> 4, T - 1); };
-    auto g_k = [&](int q) { return (lane & 15) >> 1; };
-    auto g_col = [&](int q) { return kGhost + 2 * g_t(q) + (lane & 1); };
-    // the left strip's edge value for step blk + g_k (raw: whether that step exists is ghost_valid, applied where
-    // the value is used — a select right behind the load would wait for it, and for every prefetch before it)
-    auto ghost_load = [&](int blk, int q) -> double {
-        if (e_left == nullptr) return 0.0;
-        const int d = blk + g_k(q);
-        return lex_ld(e_left + ((long)(min(max(d, left_begin), left_end) - left_begin) * T + g_t(q)) * 2 + (g_col(q) & 1));
-    };
-    auto ghost_valid = [&](int blk, int q) { const int d = blk + g_k(q); return e_left != nullptr && d >= left_begin && d <= left_end; };
     lex_wg_gate(st, db0);
     if (tr && lane == 0) tr[1] = wall_clock64();
-    {   // what the first steps read before the rings are rolling: x rows db0, db0+1, db0+2 and the ghost values of
-        // block db0 (the b rows up to db0: by all waves, in the kernel)
+    lex_lds_barrier();                                                       // (wave 0 fetches the first ghost batch behind the gate)
+    // what the first steps read before the rings are rolling: x rows db0, db0+1, db0+2 (the b rows up to db0: by all
+    // waves, in the kernel)
 #pragma unroll
-        for (int q = 0; q < 3; ++q) ring[0][(db0 + q) & (kLexRing - 1)][lane] = x_in(lex_ld(x_row(db0 + q) + c_x), db0 + q, k_x);
-#pragma unroll
-        for (int q = 0; q < kGhostOps; ++q) {
-            const double v = ghost_load(db0, q);
-            if (g_on(q)) brow[(db0 + g_k(q) - 4 * g_t(q)) & (kLexBRows - 1)][g_col(q)] = ghost_valid(db0, q) ? v : 0.0;
-        }
-    }
+    for (int q = 0; q < 3; ++q) ring[0][(db0 + q) & (kLexRing - 1)][lane] = x_in(lex_ld(x_row(db0 + q) + c_x), db0 + q, k_x);
     double qb[8], qb1[8], qx[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -429,9 +465,6 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
         // issued here, looked at after the block's last step: no loaded value but the prefetch slots lives across
         // the loop's back edge
         const unsigned polled = __hip_atomic_load(st.words + st.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        double qg[kGhostOps];
-#pragma unroll
-        for (int q = 0; q < kGhostOps; ++q) qg[q] = ghost_load(db + 8, q);
         // The rows fetched from here on exist: b row d+9 >= 1 (the strip's first block starts at -8 or later), and
         // the arrays carry kLexSlackRows rows beyond the last diagonal for the prefetches that run past the image
         // at the end of the rightmost strips (never used).  Running pointers, nothing to clamp.
@@ -441,11 +474,6 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
             if (kCols >= kWave || lane < kCols) brow[r][lane] = b_in(qb[j], db + j + 1, k_b0);   // b row d + 1 (T = 1: 62 columns)
             if (kCols > kWave && lane < kCols - kWave) brow[r][kWave + lane] = b_in(qb1[j], db + j + 1, k_b1);
             ring[0][(j + 3) & (kLexRing - 1)][lane] = x_in(qx[j], db + j + 3, k_x);       // x row d + 3: read by sweep 0 at steps d+2, d+3
-            if (j == 7) {
-#pragma unroll
-                for (int q = 0; q < kGhostOps; ++q)
-                    if (g_on(q)) brow[(db + 8 + g_k(q) - 4 * g_t(q)) & (kLexBRows - 1)][g_col(q)] = ghost_valid(db + 8, q) ? qg[q] : 0.0;
-            }
             asm volatile("" ::: "memory");
             qb[j] = rb[c_b0];                                                // b row d + 9: plain loads (b does not change) — with
             if (kCols > kWave) qb1[j] = rb[c_b1];                            // sc1 here two workgroups sharing a CU run at half speed
@@ -471,7 +499,8 @@ __device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLex
     const bool lane_on = !ghost && xl >= 0 && xl < W;
     const int in_lo = xs0 + 64 + 2 * t, in_hi = xs0 + 2 * t + H;
     const int e_t = min(lane >> 1, T - 1) + 1, e_lane = kWave - 2 + (lane & 1);
-    lex_lds_barrier();                                                       // (the loader's priming barrier)
+    lex_lds_barrier();                                                       // (the loader is through the strip's first gate)
+    lex_lds_barrier();                                                       // (the priming barrier)
     for (int db = db0; db <= db1; db += 8) {
         // Exactly two stores per step, whatever the masks say (lane 0 and the edge lanes fall back to scratch slots
         // of this workgroup's own): the publication below counts on it.
@@ -536,12 +565,28 @@ __device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLex
 // Two workgroups share a CU only if 6 of their waves fit one SIMD (a workgroup's T + 2 = 10 waves go 3, 3, 2, 2): at
 // most 80 VGPRs; and above ~53 KB of LDS per workgroup the second one is not placed (traced block start times,
 // whatever the occupancy query says).
+// Everything a launch is given.  The kernels take it BY VALUE and never touch the parameter: lex_wg_body reads the fields
+// back from the kernel-argument segment at the top of every strip, through a pointer the compiler cannot see through, so
+// that no argument is live across the persistent loop's back edge (kept live there, the arguments cost 67 scalar and 28
+// vector spills at the 80-VGPR budget two workgroups per CU need).
+struct LexWgArgs {
+    double *xd;
+    const double *bd;
+    Geom g;
+    LexGeom lg;
+    int G, S;
+    unsigned *progress, *ticket;
+    const unsigned *order;
+    double *edges;
+    long edge_steps;
+    unsigned active_mask;
+    double *partial;
+    long partial_stride;
+    unsigned long long *trace;
+};
+
 template <int T, bool CHECK, bool MASKED>
-__device__ __forceinline__ void lex_wg_body(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S,
-                                            unsigned *__restrict__ progress, unsigned *__restrict__ ticket,
-                                            const unsigned *__restrict__ order, double *__restrict__ edges, long edge_steps,
-                                            unsigned active_mask, double *__restrict__ partial, long partial_stride,
-                                            unsigned long long *__restrict__ trace)
+__device__ __forceinline__ void lex_wg_body()
 {
     static_assert(kLexRing == 4 && T >= 1, "the unrolled step index mod 4 is the ring slot");
     static_assert(4 * (T - 1) + 4 <= kLexBRows, "a b row stays in LDS from step r-1 to step r+4(T-1)");
@@ -550,22 +595,60 @@ __device__ __forceinline__ void lex_wg_body(double *__restrict__ xd, const doubl
     __shared__ double brow[kLexBRows][kRowW];
     __shared__ unsigned s_ticket;
     const int ch = blockIdx.y;
-    if (!((active_mask >> ch) & 1u)) return;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));     // 0..T-1: sweeps, T: loader, T+1: storer
+    // Nothing of a strip may be carried around the persistent loop in VECTOR registers: the loader is held to 80 VGPRs
+    // (two workgroups per CU), and whatever the compiler hoists out of the loop — the thread index, the zero the rings
+    // are cleared with — is spilled inside the loader's prefetch loop, where a scratch load queues behind the prefetches
+    // (measured: +24 % per step).  The wave's index in the workgroup lives in a scalar register, the lane comes from
+    // mbcnt, the arguments are re-read from the kernel-argument segment per strip.
+    const int wv0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / kWave));
+    // PERSISTENT workgroups: the launch holds as many workgroups as the chip has room for (two per CU) and each takes
+    // strip after strip from the ticket counter.  One workgroup per strip — 4,240 of them at 16384^2 and 128 sweeps —
+    // left 40 % of the 512 slots empty in steady state (per-workgroup trace, profiles/r04_lex_trace.jsonl: 320 alive of
+    // 512, starts in bursts of four): the hardware hands workgroups to its shader engines in launch order, and one that
+    // has to wait for room on its engine holds back those behind it.  A ticket is still only ever waited for by larger
+    // tickets, and its holder never waits for a larger one: no deadlock, whatever the residency.
+    for (;;) {
+    auto kernarg = __builtin_amdgcn_kernarg_segment_ptr();   // (constant address space: scalar loads)
+    asm volatile("" : "+s"(kernarg));                        // (reloaded per strip, not hoisted: LexWgArgs)
+    int wv = wv0;                                            // 0..T-1: sweeps, T: loader, T+1: storer
+    asm volatile("" : "+s"(wv));
+    int lane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(lane));
+    const int tid = wv * kWave + lane;
     const int t = min(wv, T - 1);
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&ticket[ch], 1u);
-    if (wv <= T) {
+    const LexWgArgs *ap = (const LexWgArgs *)kernarg;
+    double *const xd = ap->xd;
+    const double *const bd = ap->bd;
+    const Geom g = ap->g;
+    const LexGeom lg = ap->lg;
+    const int G = ap->G, S = ap->S;
+    unsigned *const progress = ap->progress, *const ticket = ap->ticket;
+    const unsigned *const order = ap->order;
+    double *const edges = ap->edges;
+    const long edge_steps = ap->edge_steps;
+    double *const partial = ap->partial;
+    const long partial_stride = ap->partial_stride;
+    unsigned long long *const trace = ap->trace;
+    if (!((ap->active_mask >> ch) & 1u)) return;
+    __syncthreads();                                         // the previous strip of this workgroup has left LDS
+    if (tid == 0) s_ticket = atomicAdd(&ticket[ch], 1u);
+    {
+        double zero = 0.0;
+        asm volatile("" : "+v"(zero));                       // (made here, dead after the clearing: not a loop invariant)
+        if (wv <= T) {
 #pragma unroll
-        for (int q = 0; q < kLexRing; ++q) ring[wv][q][lane] = 0.0;
+            for (int q = 0; q < kLexRing; ++q) ring[wv][q][lane] = zero;
+        }
+        for (int i = tid; i < kLexBRows * kRowW; i += (T + 2) * kWave) (&brow[0][0])[i] = zero;
     }
-    for (int i = threadIdx.x; i < kLexBRows * kRowW; i += (T + 2) * kWave) (&brow[0][0])[i] = 0.0;
     __syncthreads();
-    const unsigned tk = order[s_ticket];                     // (group, strip) in wavefront order
+    const unsigned my_ticket = s_ticket;
+    if (my_ticket >= (unsigned)(G * S)) break;               // (uniform)
+    const unsigned tk = order[my_ticket];                    // (group, strip) in wavefront order
     const int grp = (int)(tk / (unsigned)S), s = (int)(tk % (unsigned)S);
-    // CCP_GS_TRACE_FILE (diagnostics): per workgroup — ticket taken, first gate passed, last step done, where it ran
-    unsigned long long *tr = trace ? trace + 4 * ((long)ch * G * S + s_ticket) : nullptr;
-    if (tr && threadIdx.x == 0) {
+    // CCP_GS_TRACE_FILE (diagnostics): per strip — ticket taken, first gate passed, last step done, where it ran
+    unsigned long long *tr = trace ? trace + 4 * ((long)ch * G * S + my_ticket) : nullptr;
+    if (tr && tid == 0) {
         tr[0] = wall_clock64();
         tr[3] = (unsigned long long)(__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) & 0xffffffu)         // HW_REG_HW_ID
                 | ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11)) << 24)                 // HW_REG_XCC_ID[3:0]
@@ -624,18 +707,28 @@ __device__ __forceinline__ void lex_wg_body(double *__restrict__ xd, const doubl
         // which borders this wave's columns xs0+2-2t .. xs0+63-2t hold
         const bool has_x0 = s == 0 && xs0 + 2 - 2 * t <= 0 && xs0 + 63 - 2 * t >= 0;
         const bool has_xl = xs0 + 63 - 2 * t >= lg.W - 1;                // (column W-1, or nothing on the image at all)
-        lex_lds_barrier();                                                   // (the loader's priming barrier)
-        if (MASKED) lex_wg_compute_masked<T, CHECK>(h1, acc, ring, brow, t, lane, db0, db1);
-        else if (strip_interior) lex_wg_compute<T, CHECK, 0>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
-        else if (has_x0 && !has_xl) lex_wg_compute<T, CHECK, 1>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
-        else if (!has_x0) lex_wg_compute<T, CHECK, 2>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
-        else lex_wg_compute<T, CHECK, 3>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b);
+        LexGhosts<T> gh;
+        gh.e_left = e_left;
+        gh.left_begin = left_begin;
+        gh.left_end = left_end;
+        gh.on = wv == 0;
+        lex_lds_barrier();                                                   // (the loader is through the strip's first gate)
+        if (gh.on) {                                                         // the ghost values of block db0
+            gh.issue(db0, lane);
+            gh.write(brow, db0, lane);
+        }
+        lex_lds_barrier();                                                   // (the priming barrier)
+        if (MASKED) lex_wg_compute_masked<T, CHECK>(h1, acc, ring, brow, t, lane, db0, db1, gh);
+        else if (strip_interior) lex_wg_compute<T, CHECK, 0>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b, gh);
+        else if (has_x0 && !has_xl) lex_wg_compute<T, CHECK, 1>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b, gh);
+        else if (!has_x0) lex_wg_compute<T, CHECK, 2>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b, gh);
+        else lex_wg_compute<T, CHECK, 3>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b, gh);
         if (CHECK) {
             const double total = wave_sum(acc);
             if (lane == 0) partial[(((long)grp * T + t) * gridDim.y + ch) * partial_stride + s] = total;
         }
     } else if (wv == T) {
-        lex_wg_load<T, MASKED>(st, ring, brow, lane, db0, db1, bd + plane, xd + plane, lg.P, lg.n_diag, lg.W, lg.H, cb, xs0, e_left, left_begin, left_end, tr);
+        lex_wg_load<T, MASKED>(st, ring, brow, lane, db0, db1, bd + plane, xd + plane, lg.P, lg.n_diag, lg.W, lg.H, cb, xs0, tr);
     } else {
         // (scratch: kLexScratch doubles per workgroup behind the edge values of all strips)
         double *scratch = edges + (long)gridDim.y * S * edge_steps * (2 * T) + (((long)ch * G + grp) * S + s) * kLexScratch;
@@ -645,7 +738,8 @@ __device__ __forceinline__ void lex_wg_body(double *__restrict__ xd, const doubl
     __builtin_amdgcn_s_waitcnt(0);                                           // this wave's (write-through) stores acknowledged
     lex_lds_barrier();
     if (wv == T + 1 && lane == 0) __hip_atomic_store(st.mine, kLexDone, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (tr && threadIdx.x == 0) tr[2] = wall_clock64();
+    if (tr && tid == 0) tr[2] = wall_clock64();
+    }
 }
 
 // The kernels.  Two workgroups share a CU only if 6 of their waves fit one SIMD (a workgroup's T + 2 = 10 waves go
@@ -655,20 +749,16 @@ __device__ __forceinline__ void lex_wg_body(double *__restrict__ xd, const doubl
 // Dirichlet-mask variant carries three more values in the loader and loses more to the spills than it gains.
 template <int T, bool CHECK>
 __global__ void __launch_bounds__((T + 2) * kWave) __attribute__((amdgpu_waves_per_eu(6, 8)))
-k_lex_wg(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S, unsigned *__restrict__ progress,
-         unsigned *__restrict__ ticket, const unsigned *__restrict__ order, double *__restrict__ edges, long edge_steps,
-         unsigned active_mask, double *__restrict__ partial, long partial_stride, unsigned long long *__restrict__ trace)
+k_lex_wg(LexWgArgs)
 {
-    lex_wg_body<T, CHECK, false>(xd, bd, g, lg, G, S, progress, ticket, order, edges, edge_steps, active_mask, partial, partial_stride, trace);
+    lex_wg_body<T, CHECK, false>();
 }
 
 template <int T, bool CHECK>
-__global__ void __launch_bounds__((T + 2) * kWave)
-k_lex_wg_masked(double *__restrict__ xd, const double *__restrict__ bd, Geom g, LexGeom lg, int G, int S, unsigned *__restrict__ progress,
-         unsigned *__restrict__ ticket, const unsigned *__restrict__ order, double *__restrict__ edges, long edge_steps,
-         unsigned active_mask, double *__restrict__ partial, long partial_stride, unsigned long long *__restrict__ trace)
+__global__ void __launch_bounds__((T + 2) * kWave) __attribute__((amdgpu_waves_per_eu(5, 8)))
+k_lex_wg_masked(LexWgArgs)
 {
-    lex_wg_body<T, CHECK, true>(xd, bd, g, lg, G, S, progress, ticket, order, edges, edge_steps, active_mask, partial, partial_stride, trace);
+    lex_wg_body<T, CHECK, true>();
 }
 
 // eps[k*channels + ch] = sum of the partials of iteration k in a fixed order.  grid = (iterations, channels)

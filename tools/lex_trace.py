@@ -93,7 +93,19 @@ def show(path):
         running = np.cumsum(run_ev[:, 1])
         dtr = np.diff(run_ev[:, 0], append=run_ev[-1, 0])
         out["mean_workgroups_past_their_first_gate"] = float((running * dtr).sum() / max(float(end[ok].max()), 1e-9))
+        out["max_workgroups_alive"] = int(alive.max())
+        # alive workgroups sampled over the launch (20 points), and how many share a CU (HW_ID: cu 11:8, sh 12, se 15:13)
+        grid_t = np.linspace(0.0, float(end[ok].max()), 21)[:-1]
+        out["alive_over_time"] = [int(((start[ok] <= t) & (end[ok] > t)).sum()) for t in grid_t]
+        out["running_over_time"] = [int(((gate[ok] <= t) & (end[ok] > t)).sum()) for t in grid_t]
         xcc = ((r[:, 3] >> 24) & 0xF).astype(np.int64)
+        hw = (r[:, 3] & 0xFFFFFF).astype(np.int64)
+        cu_key = xcc * 4096 + ((hw >> 8) & 0xFF)
+        out["distinct_cus"] = int(len(np.unique(cu_key[ok])))
+        mid = grid_t[len(grid_t) // 2]
+        live = ok & (start <= mid) & (end > mid)
+        per_cu = np.bincount(np.unique(cu_key[live], return_inverse=True)[1]) if live.any() else np.zeros(1, dtype=int)
+        out["workgroups_per_cu_at_mid_launch"] = np.bincount(per_cu).tolist()
         out["workgroups_per_xcc"] = np.bincount(xcc[ok], minlength=8).tolist()
         # the ideal: every slot-holder stepping at the isolated step time
         out["updates_per_s_of_this_launch"] = float(meta["W"]) * H * T * G / (float(end[ok].max()) * 1e-6)
