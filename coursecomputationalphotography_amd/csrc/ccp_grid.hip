@@ -97,6 +97,7 @@ struct ccp_grid {
                                  // CCP_GS_LEX_MODE=planes -> 0: one launch per hyperplane (k_lex_plane, the independent engine)
     int lex_tmax = 8;            // deepest time-skewed pass
     DevBuf<unsigned> lex_order;  // k_lex_wg: ticket -> group * strips + strip, in wavefront order
+    std::vector<unsigned> lex_order_host;
     int lex_order_groups = 0, lex_order_strips = 0;
     LexGeom lexg{};
     DevBuf<double> stage;        // natural-order staging rows for host transfers
@@ -1215,6 +1216,56 @@ try {
     }
     g->tuned = true;
     g->fuse_tmax = max_t;
+    // Several passes in ONE launch (k_fused_multi) pay where a pass is short against the drain and fill between two
+    // dependent launches: +5 % at 4096^2 x 3, nothing at 16384^2 (NOTES.md).  Decided here by timing four passes of the
+    // chosen depth both ways on this shape (whole-image handles; CCP_GS_MULTI overrides).  x is put back afterwards.
+    if (!getenv("CCP_GS_MULTI") && !g->shrink_top && !g->shrink_bottom && !g->trace_file && best_t >= 2) {
+        const size_t elems = (size_t)g->geom.ch_stride * g->desc.channels;
+        DevBuf<double> keep;
+        if (keep.alloc(elems) == CCP_OK) {
+            CCP_HIP(hipMemcpyAsync(keep.p, g->x.p, elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+            hipEvent_t t0, t1, t2;
+            CCP_HIP(hipEventCreate(&t0));
+            CCP_HIP(hipEventCreate(&t1));
+            CCP_HIP(hipEventCreate(&t2));
+            int lo[kMultiMaxPasses], hi[kMultiMaxPasses];
+            for (int q = 0; q < kMultiMaxPasses; ++q) {
+                lo[q] = 0;
+                hi[q] = rows;
+            }
+            int st = CCP_OK;
+            auto singles = [&]() {
+                for (int q = 0; q < 4 && st == CCP_OK; ++q)
+                    st = FusedDepth<kFusedMaxT>::launch(best_t, g, (q & 1) ? g->x_alt.p : g->x.p, (q & 1) ? g->x.p : g->x_alt.p, 0, rows, nullptr, 0, nullptr);
+            };
+            auto multi = [&]() { if (st == CCP_OK) st = FusedMultiDepth<kFusedMaxT>::launch(best_t, g, 4, g->x.p, g->x_alt.p, lo, hi); };
+            singles();                                          // warm both
+            multi();
+            (void)hipEventRecord(t0, g->stream);
+            singles();
+            singles();
+            (void)hipEventRecord(t1, g->stream);
+            multi();
+            multi();
+            (void)hipEventRecord(t2, g->stream);
+            float ms_single = 0.f, ms_multi = 0.f;
+            if (st == CCP_OK && hipEventSynchronize(t2) == hipSuccess) {
+                (void)hipEventElapsedTime(&ms_single, t0, t1);
+                (void)hipEventElapsedTime(&ms_multi, t1, t2);
+                g->multi = ms_multi < 0.98f * ms_single ? 1 : 0;
+                if (getenv("CCP_GS_DEBUG"))
+                    fprintf(stderr, "[ccp_gs] tune: 8 passes of depth %d one by one %.3f ms, four per launch %.3f ms -> %s\n", best_t, ms_single, ms_multi,
+                            g->multi ? "several passes per launch" : "one pass per launch");
+            }
+            (void)hipEventDestroy(t0);
+            (void)hipEventDestroy(t1);
+            (void)hipEventDestroy(t2);
+            CCP_HIP(hipMemcpyAsync(g->x.p, keep.p, elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+            CCP_HIP(hipStreamSynchronize(g->stream));
+            g->last_launches = saved_launches;
+            if (st != CCP_OK && st != CCP_ERR_UNSUPPORTED) return st;
+        }
+    }
     if (chosen_t) *chosen_t = best_t;
     if (chosen_rows_per_chunk) *chosen_rows_per_chunk = best_r;
     if (ms_per_iteration) *ms_per_iteration = best;
@@ -1429,39 +1480,43 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
     const int C = g->desc.channels;
     const int S = (lg.W - 1 + 2 * (T - 1)) / kLexSkewCols + 1;
     const long edge_steps = kWave + lg.H + 2 * (T - 1);
-    const size_t need = (size_t)C * groups * S * kLexWordStride;
-    const size_t edges = (size_t)C * S * edge_steps * 2 * T + (size_t)C * groups * S * kLexScratch;   // (+ the storers' scratch slots)
-    if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need));
-    if (g->lex_order_groups != groups || g->lex_order_strips != S) {
-        // Tickets in wavefront order: strip s of group k starts about (s + rho k) strip-lags after the first one,
-        // and a workgroup that is resident but waiting keeps a slot from one that could run.  Everything (k, s)
-        // waits for — (k, s-1), (k-1, s), (k-1, s+1) — sorts before it for any rho >= 1 (ties: lower group first).
-        const long rho = 3;
-        std::vector<unsigned> order((size_t)groups * S);
-        size_t n = 0;
-        for (long key = 0; key <= (long)(S - 1) + rho * (groups - 1); ++key)
-            for (long k = std::max(0L, (key - (S - 1) + rho - 1) / rho); k <= std::min<long>(groups - 1, key / rho); ++k)
-                order[n++] = (unsigned)(k * S + (key - rho * k));
-        if (n != order.size()) return CCP_ERR_STATE;
-        if (g->lex_order.n < order.size()) CCP_TRY(g->lex_order.alloc(order.size()));
-        CCP_HIP(hipMemcpyAsync(g->lex_order.p, order.data(), order.size() * sizeof(unsigned), hipMemcpyHostToDevice, g->stream));
-        CCP_HIP(hipStreamSynchronize(g->stream));               // (the vector goes out of scope)
-        g->lex_order_groups = groups;
-        g->lex_order_strips = S;
-    }
-    if (g->lex_edges.n < edges) CCP_TRY(g->lex_edges.alloc(edges));
-    if (!g->lex_ticket.p) CCP_TRY(g->lex_ticket.alloc(kMaxChannels));
-    CCP_HIP(hipMemsetAsync(g->lex_progress.p, 0, need * sizeof(unsigned), g->stream));
-    CCP_HIP(hipMemsetAsync(g->lex_ticket.p, 0, kMaxChannels * sizeof(unsigned), g->stream));
     // persistent workgroups: as many as are resident at once (k_lex_wg's comment), each taking strips from the ticket counter
     int per_cu = 0, cus = 0;
     if (g->masked) (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wg_masked<T, false>, (T + 2) * kWave, 0);
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wg<T, false>, (T + 2) * kWave, 0);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device);
-    static const bool one_per_strip = getenv("CCP_GS_LEX_PERSISTENT") && atoi(getenv("CCP_GS_LEX_PERSISTENT")) == 0;   // A/B: a workgroup per strip
-    long resident = (long)std::max(per_cu, 1) * std::max(cus, 1);
-    if (one_per_strip) resident = (long)groups * S * C;
+    const long resident = (long)std::max(per_cu, 1) * std::max(cus, 1);
     const long wgs = std::max<long>(1, std::min<long>((long)groups * S, (resident + C - 1) / C));
+    // Buffers are sized for the largest launch a solve can issue (a batch holds at most 4096 sweeps: 512 groups), not
+    // for this one: a call with more sweeps than the call before must not pay a 0.5 GB reallocation inside its own
+    // timing (the kernel trace of round 4 showed 25 ms of it between the layout conversion and the launch).
+    const size_t need = (size_t)C * groups * S * kLexWordStride;
+    const size_t need_cap = (size_t)C * std::max(groups, 512) * S * kLexWordStride;
+    const size_t edges = (size_t)C * S * edge_steps * 2 * T + (size_t)C * resident * kLexScratch;   // (+ the storers' scratch slots, one set per resident workgroup)
+    const size_t edges_cap = (size_t)C * ((lg.W - 1 + 14) / kLexSkewCols + 1) * (kWave + lg.H + 14) * 16 + (size_t)C * resident * kLexScratch;   // (what depth 8 needs)
+    if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need_cap));
+    if (g->lex_order_groups != groups || g->lex_order_strips != S) {
+        // Tickets in wavefront order: strip s of group k starts about (s + rho k) strip-lags after the first one,
+        // and a workgroup that is resident but waiting keeps a slot from one that could run.  Everything (k, s)
+        // waits for — (k, s-1), (k-1, s), (k-1, s+1) — sorts before it for any rho >= 1 (ties: lower group first).
+        const long rho = 3;
+        std::vector<unsigned> &order = g->lex_order_host;       // (kept in the handle: the copy below needs no host sync)
+        order.assign((size_t)groups * S, 0u);
+        size_t n = 0;
+        for (long key = 0; key <= (long)(S - 1) + rho * (groups - 1); ++key)
+            for (long k = std::max(0L, (key - (S - 1) + rho - 1) / rho); k <= std::min<long>(groups - 1, key / rho); ++k)
+                order[n++] = (unsigned)(k * S + (key - rho * k));
+        if (n != order.size()) return CCP_ERR_STATE;
+        if (g->lex_order.n < order.size()) CCP_TRY(g->lex_order.alloc(std::max(order.size(), (size_t)512 * S)));
+        CCP_HIP(hipStreamSynchronize(g->stream));               // (an earlier copy from this vector may still be in flight)
+        CCP_HIP(hipMemcpyAsync(g->lex_order.p, order.data(), order.size() * sizeof(unsigned), hipMemcpyHostToDevice, g->stream));
+        g->lex_order_groups = groups;
+        g->lex_order_strips = S;
+    }
+    if (g->lex_edges.n < edges) CCP_TRY(g->lex_edges.alloc(std::max(edges, edges_cap)));
+    if (!g->lex_ticket.p) CCP_TRY(g->lex_ticket.alloc(kMaxChannels));
+    CCP_HIP(hipMemsetAsync(g->lex_progress.p, 0, need * sizeof(unsigned), g->stream));
+    CCP_HIP(hipMemsetAsync(g->lex_ticket.p, 0, kMaxChannels * sizeof(unsigned), g->stream));
     dim3 grid((unsigned)wgs, (unsigned)C);
     if (getenv("CCP_GS_DEBUG"))
         fprintf(stderr, "[ccp_gs] k_lex_wg<%d>: %d workgroups per CU on %d CUs, %ld persistent workgroups per channel for %d groups x %d strips\n",

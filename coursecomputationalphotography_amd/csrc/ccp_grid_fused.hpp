@@ -875,6 +875,7 @@ k_fused_multi(FusedMultiParams M)
     if (!have) return;
     // ---- wait for the nine tiles of the previous pass around this one ------------------------------------------
     const long cells_per_pass = (long)M.channels * P.n_chunks * P.n_strips;
+    bool gave_up = false;                                            // (uniform) the wait timed out: the inputs may not be final
     if (q > 0) {
         const unsigned *prev = M.cells + (long)(q - 1) * cells_per_pass + (long)ch * P.n_chunks * P.n_strips;
         // chunks c-2 .. c+2: the one chunk of a pass that may be shorter than the halo (the remainder of the rows) has
@@ -886,18 +887,24 @@ k_fused_multi(FusedMultiParams M)
         const unsigned *word = prev + (mine ? (long)c2 * P.n_strips + s2 : 0);
         bool ok = !mine;
         const unsigned long long t0 = wall_clock64();
+        // acquire: the x loads of the tile must not be moved above the poll (the sc1 loads inside fused_wave read
+        // through to memory; the ordering is the language's business, stated here and not left to the access forms)
         while (!__all(ok)) {
-            if (!ok) ok = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
+            if (!ok) ok = __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need;
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > 100000000ull) {              // 1 s of the 100 MHz clock: never in a correct run
                 if (lane == 0) __hip_atomic_store(M.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                gave_up = true;
                 break;
             }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     // ---- the tile -------------------------------------------------------------------------------------------
-    const int r0 = max(ra, M.st_lo[q]), r1 = min(rb, M.st_hi[q]);
+    // a wave that gave up stores nothing (the handle's error word is up: every later call returns CCP_ERR_STATE) but still
+    // counts its tile, so that the waves behind it drain
+    const int r0 = max(ra, M.st_lo[q]), r1 = gave_up ? r0 : min(rb, M.st_hi[q]);
     if (r0 < r1) {
         const long off = (long)ch * g.ch_stride;
         const double *xin = ((q & 1) ? P.xout : P.xin) + off;
@@ -908,10 +915,9 @@ k_fused_multi(FusedMultiParams M)
         else fused_wave<T, false, 0, UNR, 1, false, true>(xin, xout, P.b + off, g, sx, r0, r1, acc);
     }
     // ---- publish: the (write-through) stores acknowledged, then the count ----------------------------------------
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // compiler ordering only
-    __builtin_amdgcn_s_waitcnt(0);
+    __builtin_amdgcn_s_waitcnt(0);                                   // every (write-through) store of the tile acknowledged
     if (lane == 0)
-        __hip_atomic_fetch_add(M.cells + (long)q * cells_per_pass + ((long)ch * P.n_chunks + chunk) * P.n_strips + sx, 1u, __ATOMIC_RELAXED,
+        __hip_atomic_fetch_add(M.cells + (long)q * cells_per_pass + ((long)ch * P.n_chunks + chunk) * P.n_strips + sx, 1u, __ATOMIC_RELEASE,
                                __HIP_MEMORY_SCOPE_AGENT);
 }
 

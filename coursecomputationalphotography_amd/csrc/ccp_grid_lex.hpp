@@ -730,8 +730,8 @@ __device__ __forceinline__ void lex_wg_body()
     } else if (wv == T) {
         lex_wg_load<T, MASKED>(st, ring, brow, lane, db0, db1, bd + plane, xd + plane, lg.P, lg.n_diag, lg.W, lg.H, cb, xs0, tr);
     } else {
-        // (scratch: kLexScratch doubles per workgroup behind the edge values of all strips)
-        double *scratch = edges + (long)gridDim.y * S * edge_steps * (2 * T) + (((long)ch * G + grp) * S + s) * kLexScratch;
+        // (scratch: kLexScratch doubles per resident workgroup behind the edge values of all strips)
+        double *scratch = edges + (long)gridDim.y * S * edge_steps * (2 * T) + ((long)ch * gridDim.x + blockIdx.x) * kLexScratch;
         lex_wg_store<T, MASKED>(st, ring, g, lg.W, lg.H, lane, db0, db1, xd + plane, lg.P, xs0, d_begin, d_end, e_mine, scratch, strip_interior, st_b);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                   // compiler ordering only

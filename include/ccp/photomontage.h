@@ -106,6 +106,53 @@ inline void SolveChannel(int channel_idx, int constraint, const ImageView &gx, c
     }
 }
 
+// The reference's own member-function shape (PhotoMontage.h:24):
+//     void SolveChannel(int channel_idx, int constraint, const cv::Mat &color_gradient_x, const cv::Mat &color_gradient_y,
+//                       cv::Mat &output, const std::vector<cv::Mat> &Images);
+// with the state it reads from its object (PhotoMontage.h:40,59; PhotoMontage.cpp:599-613): `iterations_`,
+// `fast_init_value` and `result_label_` — when fast_init_value is set the start vector is the composite
+// Images[result_label_(y, x)](y, x)[channel_idx].  A call site written against the reference class compiles against
+// this one with cv::Mat replaced by ccp::ImageView; `solver` picks what runs in the slot of the reference's
+// conjugateGradient call (:613).
+class PhotoMontage {
+public:
+    int fast_init_value = 0;                 // PhotoMontage.h:40
+    int iterations_ = 50;                    // PhotoMontage.h:59 (set by Run, PhotoMontage.cpp:248)
+    ImageView result_label_{nullptr, 0, 0, 1, 0};   // CV_8UC1 (BuildSolveMRF's labelling; PhotoMontage.cpp:391)
+    Solver solver = Solver::GaussSeidel;
+    int device = 0;
+
+    void SolveChannel(int channel_idx, int constraint, const ImageView &color_gradient_x, const ImageView &color_gradient_y,
+                      ImageView &output, const std::vector<ImageView> &Images)
+    {
+        const int W = color_gradient_x.cols, H = color_gradient_x.rows;
+        if (!fast_init_value) {
+            ccp::SolveChannel(channel_idx, constraint, color_gradient_x, color_gradient_y, output, iterations_, nullptr, solver, device);
+            return;
+        }
+        if (result_label_.data == nullptr || result_label_.cols != W || result_label_.rows != H)
+            throw std::invalid_argument("PhotoMontage::SolveChannel: fast_init_value needs result_label_ of the gradients' shape");
+        // the composite image (PhotoMontage.cpp:599-610): channel `channel_idx` of an interleaved image of the
+        // gradients' channel count, which is the form the free function takes its start vector in
+        const int C = color_gradient_x.channels;
+        std::vector<uint8_t> comp((std::size_t)W * H * C, 0);
+        for (int y = 0; y < H; ++y) {
+            const uint8_t *lab = static_cast<const uint8_t *>(result_label_.data) + y * result_label_.step;
+            for (int x = 0; x < W; ++x) {
+                const std::size_t k = lab[(std::size_t)x * result_label_.channels];
+                if (k >= Images.size()) throw std::invalid_argument("PhotoMontage::SolveChannel: label out of range");
+                const ImageView &im = Images[k];
+                if (im.cols != W || im.rows != H || channel_idx >= im.channels)
+                    throw std::invalid_argument("PhotoMontage::SolveChannel: image shapes differ");
+                comp[((std::size_t)y * W + x) * C + channel_idx] =
+                    (static_cast<const uint8_t *>(im.data) + y * im.step)[(std::size_t)x * im.channels + channel_idx];
+            }
+        }
+        const ImageView init{comp.data(), H, W, C, (std::size_t)W * C};
+        ccp::SolveChannel(channel_idx, constraint, color_gradient_x, color_gradient_y, output, iterations_, &init, solver, device);
+    }
+};
+
 // BuildSolveGradientFusion(Images, ResultLabel) (PhotoMontage.cpp:410-436): gradient field of the
 // label-selected images, three channel solves, clamped CV_8UC3 result — all three channels in one
 // device pass each.  images[k]: CV_8UC3 views of equal shape; label: CV_8UC1.

@@ -176,6 +176,16 @@ static int blend_file(const char *in, const char *out)
     for (int c = 0; c < 3; ++c)
         ccp::SolveChannel(c, imgs[0][c], vgx, vgy, r2, iters, fast ? &comp : nullptr);
     if (res1 != res2) { std::fprintf(stderr, "SolveChannel route differs from BuildSolveGradientFusion\n"); return 24; }
+    // route 3: the reference's member-function shape (PhotoMontage.h:24): SolveChannel(channel_idx, constraint, gx, gy,
+    // output, Images) on an object that carries iterations_, fast_init_value and result_label_ (PhotoMontage.cpp:428-434)
+    std::vector<uint8_t> res3((size_t)W * H * 3, 0);
+    ccp::ImageView r3{res3.data(), H, W, 3, (size_t)W * 3};
+    ccp::PhotoMontage pm;
+    pm.iterations_ = iters;
+    pm.fast_init_value = fast;
+    pm.result_label_ = lab;
+    for (int c = 0; c < 3; ++c) pm.SolveChannel(c, imgs[0][c], vgx, vgy, r3, views);
+    if (res1 != res3) { std::fprintf(stderr, "PhotoMontage::SolveChannel differs from BuildSolveGradientFusion\n"); return 26; }
     FILE *o = std::fopen(out, "wb");
     if (!o) return 25;
     std::fwrite(res1.data(), 1, res1.size(), o);
