@@ -227,3 +227,50 @@ def test_facade_insert_goes_to_the_device(tmp_path):
         y1, y2, stats2 = raw[:n], raw[n:2 * n], raw[3 * n:]
         assert np.array_equal(y1, y2) and np.array_equal(y1, x1)
         assert stats2[0] == len(edits) and stats2[4] == 0
+
+
+@pytest.mark.parametrize("sorted_by_row", [True, False])
+def test_a_batch_of_edits_equals_the_edits_one_by_one(capi, orc, sorted_by_row):
+    """ccp_csr_insert_many folds the edits of a row into ONE merge with the row's content (the lab3 benchmark: 200,000
+    insert(0) on a 1000 x 1000 matrix) — same result as ccp_csr_insert called once per edit in the order given, also with
+    several edits of one (row, column) in the batch (the last one wins), unsorted batches and no-op edits."""
+    rng = np.random.Generator(np.random.MT19937(11))
+    n = 300
+    a = sp.random(n, n, density=0.3, random_state=np.random.RandomState(3), data_rvs=lambda k: rng.integers(1, 50, k).astype(np.float64)).tocsr()
+    a.setdiag(np.asarray(abs(a).sum(axis=1)).ravel() + 7.0)
+    a = a.tocsr()
+    v, c, r = csr_arrays(a)
+    coo = a.tocoo()
+    k_rm = rng.choice(len(coo.row), 4000, replace=False)
+    edits = [(0.0, int(coo.row[k]), int(coo.col[k])) for k in k_rm if coo.row[k] != coo.col[k]]       # insert(0): removals
+    edits += [(float(rng.integers(1, 9)), int(i), int(j)) for i, j in rng.integers(0, n, (1500, 2)) if i != j]   # new or overwritten
+    edits += [(0.0, int(i), int(j)) for i, j in rng.integers(0, n, (500, 2)) if i != j]                 # some of them no-ops
+    edits += [(float(rng.integers(1, 9)), e[1], e[2]) for e in edits[:300]]                               # a second edit of the same entry
+    if sorted_by_row:
+        edits.sort(key=lambda e: e[1])                          # (stable: the order inside a row is kept)
+    else:
+        perm = rng.permutation(len(edits))
+        edits = [edits[k] for k in perm]
+    one, many = capi.CsrMatrix().upload_compressed(v, c, r), capi.CsrMatrix().upload_compressed(v, c, r)
+    xt = np.linspace(-2.0, 5.0, n)
+    one.apply_to_vector(xt)
+    many.apply_to_vector(xt)                                    # the images exist: the edits are patches
+    for e in edits:
+        one.insert(*e)
+    many.insert_many([e[0] for e in edits], [e[1] for e in edits], [e[2] for e in edits])
+    want = apply_edits(a, edits)
+    wv, wc, wr = csr_arrays(want)
+    om = orc.from_csr(wv, wc, wr)
+    assert np.array_equal(one.apply_to_vector(xt), om.apply_to_vector(xt))
+    assert np.array_equal(many.apply_to_vector(xt), om.apply_to_vector(xt))
+    b = rng.uniform(-5, 5, n)
+    for k in (1, 3):
+        xo, _ = one.gauss_seidel(b, 0.0, k, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+        xm, _ = many.gauss_seidel(b, 0.0, k, check_every=0, ordering=capi.ORDER_LEXICOGRAPHIC)
+        assert np.array_equal(xo, xm) and np.array_equal(xm, om.gauss_seidel(b, 0.0, k)[0])
+    assert many.edit_stats()["edits"] == len(edits)
+    with pytest.raises(capi.CcpError):                          # a batch with an entry outside the matrix: refused whole
+        many.insert_many([1.0] * 80, [0] * 79 + [n], [1] * 80)
+    assert np.array_equal(many.apply_to_vector(xt), om.apply_to_vector(xt))
+    one.close()
+    many.close()
