@@ -65,6 +65,7 @@ struct ccp_grid {
     // tile_live: which tiles of the current tiling hold any unknown (k_masked_tile_census), cached per tiling.
     bool masked = false;
     DevBuf<unsigned char> maskp, tile_live;
+    DevBuf<int> tile_rows;       // ... and which of a live tile's own rows do (two ints per tile)
     int live_T = -1, live_R = -1, live_lo = -1, live_hi = -1;
     long unknowns = 0;           // mask bytes set (owned rows), for the statistics
     bool fuse = true;            // use k_fused_sweep for unchecked sweeps
@@ -283,8 +284,9 @@ int masked_tile_census(ccp_grid *g, const FusedParams &P, int T)
     if (g->live_T != T || g->live_R != P.rows_per_chunk || g->live_lo != P.st_lo || g->live_hi != P.st_hi) {
         const size_t tiles = (size_t)P.n_chunks * P.n_strips;
         if (g->tile_live.n < tiles) CCP_TRY(g->tile_live.alloc(tiles));
+        if (g->tile_rows.n < 2 * tiles) CCP_TRY(g->tile_rows.alloc(2 * tiles));
         hipLaunchKernelGGL(k_masked_tile_census, dim3((unsigned)P.n_strips, (unsigned)P.n_chunks), dim3(kWave), 0, g->stream, P, T,
-                           g->tile_live.p);
+                           g->tile_live.p, g->tile_rows.p);
         CCP_HIP(hipGetLastError());
         g->live_T = T;
         g->live_R = P.rows_per_chunk;
@@ -320,11 +322,13 @@ int launch_fused_masked(ccp_grid *g, FusedParams &P, int l1, long *l1_blocks)
         l1_blocks[1] = 0;
     }
     CCP_TRY(masked_tile_census(g, P, T));
+    static const bool clip_rows = !(getenv("CCP_GS_MASK_ROWS") && atoi(getenv("CCP_GS_MASK_ROWS")) == 0);   // A/B: march every row of a live tile
+    const int *rows_p = clip_rows ? g->tile_rows.p : nullptr;
     if (l1 == 2 && T > kMaskedMaxCheckedT) return CCP_ERR_BAD_ARG;
     constexpr int TMC = T <= kMaskedMaxCheckedT ? T : 1;
-    if (l1 == 2) hipLaunchKernelGGL((k_fused_sweep_masked<TMC, 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P, g->tile_live.p);
-    else if (l1 == 1) hipLaunchKernelGGL((k_fused_sweep_masked<TM, 1, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P, g->tile_live.p);
-    else hipLaunchKernelGGL((k_fused_sweep_masked<TM, 0, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P, g->tile_live.p);
+    if (l1 == 2) hipLaunchKernelGGL((k_fused_sweep_masked<TMC, 2, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P, g->tile_live.p, rows_p);
+    else if (l1 == 1) hipLaunchKernelGGL((k_fused_sweep_masked<TM, 1, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P, g->tile_live.p, rows_p);
+    else hipLaunchKernelGGL((k_fused_sweep_masked<TM, 0, kFusedUnroll>), grid, dim3(kBlock), 0, g->stream, P, g->tile_live.p, rows_p);
     CCP_HIP(hipGetLastError());
     g->last_launches++;
     g->region_launches++;
@@ -1628,9 +1632,10 @@ try {
     }
     CCP_TRY(begin_timing(g));
     dim3 cgrid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, (unsigned)C);
-    hipLaunchKernelGGL((k_lex_convert<true>), cgrid, dim3(kBlock), 0, g->stream, g->x.p, g->lex_x.p, g->geom, lg);
+    dim3 tgrid((unsigned)((W + kLexCT - 1) / kLexCT), (unsigned)((H + kLexCT - 1) / kLexCT), (unsigned)C);
+    hipLaunchKernelGGL((k_lex_convert_tiled<true>), tgrid, dim3(kBlock), 0, g->stream, g->x.p, g->lex_x.p, g->geom, lg);
     if (g->masked) hipLaunchKernelGGL(k_lex_convert_b_masked, cgrid, dim3(kBlock), 0, g->stream, g->b.p, g->maskp.p, g->lex_b.p, g->geom, lg);
-    else hipLaunchKernelGGL((k_lex_convert<true>), cgrid, dim3(kBlock), 0, g->stream, g->b.p, g->lex_b.p, g->geom, lg);
+    else hipLaunchKernelGGL((k_lex_convert_tiled<true>), tgrid, dim3(kBlock), 0, g->stream, g->b.p, g->lex_b.p, g->geom, lg);
     CCP_HIP(hipGetLastError());
 
     const unsigned all = (C >= 32) ? 0xffffffffu : ((1u << C) - 1u);
@@ -1697,7 +1702,7 @@ try {
         for (int ch = 0; ch < C; ++ch)
             if (!converged[ch]) iterations_of[ch] = done;
     }
-    hipLaunchKernelGGL((k_lex_convert<false>), cgrid, dim3(kBlock), 0, g->stream, g->x.p, g->lex_x.p, g->geom, lg);
+    hipLaunchKernelGGL((k_lex_convert_tiled<false>), tgrid, dim3(kBlock), 0, g->stream, g->x.p, g->lex_x.p, g->geom, lg);
     CCP_HIP(hipGetLastError());
     CCP_TRY(end_timing(g));
     CCP_HIP(hipStreamSynchronize(g->stream));

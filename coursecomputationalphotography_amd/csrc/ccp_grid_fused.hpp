@@ -662,9 +662,12 @@ __host__ __device__ constexpr int masked_waves_per_simd(int T, int L1 = 0)
     return L1 == 0 ? (T <= 1 ? 6 : T <= 2 ? 5 : T <= 3 ? 3 : 2) : (T <= 1 ? 4 : T <= 2 ? 3 : 2);
 }
 
+// tile_rows (round 4): the rows of the tile that hold an unknown in the strip's columns, [2i] .. [2i + 1) — a tile on the
+// rim of a region marches only those (rows without an unknown are zero in both ping-pong buffers and stay so, like the
+// dead tiles; what the kept rows read of them is the zero that is there).
 template <int T, int L1, int UNR>
 __global__ void __launch_bounds__(kBlock, masked_waves_per_simd(T, L1))
-k_fused_sweep_masked(FusedParams P, const unsigned char *__restrict__ tile_live)
+k_fused_sweep_masked(FusedParams P, const unsigned char *__restrict__ tile_live, const int *__restrict__ tile_rows)
 {
     __shared__ double scratch[kBlock / kWave];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
@@ -681,17 +684,25 @@ k_fused_sweep_masked(FusedParams P, const unsigned char *__restrict__ tile_live)
     for (int t = 0; t < AN; ++t) acc[t] = 0.0;
     const bool run = (P.active == nullptr) || (P.active[ch] != 0);
     if (run && sx < P.n_strips && ra < rb && (tile_live == nullptr || tile_live[(long)chunk * P.n_strips + sx] != 0)) {
-        const Geom &g = P.g;
-        const long off = (long)ch * g.ch_stride;
-        fused_wave<T, false, L1, UNR, AN, true>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc, false, P.mask);
+        if (tile_rows != nullptr) {
+            ra = max(ra, tile_rows[2 * ((long)chunk * P.n_strips + sx)]);
+            rb = min(rb, tile_rows[2 * ((long)chunk * P.n_strips + sx) + 1]);
+        }
+        if (ra < rb) {
+            const Geom &g = P.g;
+            const long off = (long)ch * g.ch_stride;
+            fused_wave<T, false, L1, UNR, AN, true>(P.xin + off, P.xout + off, P.b + off, g, sx, ra, rb, acc, false, P.mask);
+        }
     }
     fused_write_partials<L1, AN>(acc, P.partial, ch, scratch, bx, by);
 }
 
 // tile_live[chunk * n_strips + strip] = does the tile's extended region (its rows and columns plus the 2T
-// halo) hold any unknown?  grid = (n_strips, n_chunks), one wave per tile.
+// halo) hold any unknown?  tile_rows[2 i], [2 i + 1]: first row, and one past the last, of the tile's OWN rows that hold
+// an unknown anywhere in the strip's columns (halo columns included: conservative).  grid = (n_strips, n_chunks), one
+// wave per tile.
 __global__ void __launch_bounds__(kWave)
-k_masked_tile_census(FusedParams P, int T, unsigned char *__restrict__ tile_live)
+k_masked_tile_census(FusedParams P, int T, unsigned char *__restrict__ tile_live, int *__restrict__ tile_rows)
 {
     const int sx = blockIdx.x, chunk = blockIdx.y, lane = threadIdx.x;
     int ra, rb;
@@ -701,11 +712,27 @@ k_masked_tile_census(FusedParams P, int T, unsigned char *__restrict__ tile_live
     const int m0 = max(ra - HS, 0), m1 = min(rb + HS, g.local_rows);
     const int U = fused_useful_px(T);
     const int j = (sx * U - fused_halo_px(T)) / 2 + lane;
-    int any = 0;
+    int any = 0, first = INT_MAX, last = -1;
     if (j >= 0 && j < g.pitch)
-        for (int q = m0; q < m1; ++q) any |= P.mask[(long)q * 2 * g.pitch + j] | P.mask[(long)q * 2 * g.pitch + g.pitch + j];
+        for (int q = m0; q < m1; ++q) {
+            const int here = P.mask[(long)q * 2 * g.pitch + j] | P.mask[(long)q * 2 * g.pitch + g.pitch + j];
+            any |= here;
+            if (here && q >= ra && q < rb) {
+                first = min(first, q);
+                last = q;
+            }
+        }
     const unsigned long long vote = __ballot(any != 0);
-    if (lane == 0) tile_live[(long)chunk * P.n_strips + sx] = vote ? 1 : 0;
+#pragma unroll
+    for (int o = kWave / 2; o > 0; o >>= 1) {
+        first = min(first, __shfl_xor(first, o));
+        last = max(last, __shfl_xor(last, o));
+    }
+    if (lane == 0) {
+        tile_live[(long)chunk * P.n_strips + sx] = vote ? 1 : 0;
+        tile_rows[2 * ((long)chunk * P.n_strips + sx)] = first & ~1;                 // (the march starts on an even row: keep the parity)
+        tile_rows[2 * ((long)chunk * P.n_strips + sx) + 1] = last + 1;
+    }
 }
 
 // Border tiles, compactly enumerated: first the top and bottom chunk rows (strips away from the
