@@ -53,7 +53,7 @@ MIN_BYTES_PER_PIXEL_PASS = 20.0  # what an unchecked pass must move: black x 4 +
 # full-width oracle test (tests/test_gpu_fullsize.py) were made with.  --tune re-times it on the box.
 DEFAULT_TILING = {(16384, 16384, 1): (8, 364)}
 CONFIG1_TILING = (8, 140)
-TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "r03_traffic.json"), os.path.join(ROOT, "profiles", "r02_traffic.json")]
+TRAFFIC_FILES = [os.path.join(ROOT, "profiles", "r04_traffic.json"), os.path.join(ROOT, "profiles", "r03_traffic.json")]
 
 
 def parse():

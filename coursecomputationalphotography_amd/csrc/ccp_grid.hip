@@ -1478,7 +1478,7 @@ long lex_partials_per_sweep(const ccp_grid *g)
 // T = 8, 4, 2, 1 for what is left over; every depth is one launch holding all its groups.
 extern "C++" {
 template <int T>
-int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
+int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial, int t_last = T)
 {
     const LexGeom &lg = g->lexg;
     const int C = g->desc.channels;
@@ -1537,7 +1537,7 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial)
 #define CCP_LEX_WG(KERNEL, CHECK, P, STRIDE)                                                                                        \
     hipLaunchKernelGGL((KERNEL<T, CHECK>), grid, block, 0, g->stream,                                                                \
                        LexWgArgs{g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S, g->lex_progress.p, g->lex_ticket.p, g->lex_order.p,  \
-                                 g->lex_edges.p, edge_steps, mask, P, STRIDE, trace})
+                                 g->lex_edges.p, edge_steps, mask, P, STRIDE, trace, t_last})
     if (g->masked) {
         if (partial) CCP_LEX_WG(k_lex_wg_masked, true, partial, lex_partials_per_sweep(g));
         else CCP_LEX_WG(k_lex_wg_masked, false, nop, 0L);
@@ -1569,6 +1569,12 @@ int lex_run_skew(ccp_grid *g, int iterations, unsigned mask, double *partial)
     const int C = g->desc.channels;
     const long per_sweep = (long)C * lex_partials_per_sweep(g);          // partial doubles per sweep (all channels)
     int left = iterations, done = 0;
+    if (!partial && g->lex_tmax >= 8 && left >= 8 && left % 8 != 0) {
+        // a count that is not a multiple of 8, no stop rule: ONE launch of depth-8 groups whose last group passes the
+        // sweeps it does not have through (lex_wg_pass_through) instead of remainder launches of depth 4, 2, 1
+        const int groups = (left + 7) / 8;
+        return lex_launch_skew<8>(g, groups, mask, nullptr, left - 8 * (groups - 1));
+    }
     for (int T = 8; T >= 1; T >>= 1) {
         if (T > g->lex_tmax || left < T) continue;
         const int groups = left / T;

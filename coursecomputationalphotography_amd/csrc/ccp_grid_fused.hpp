@@ -914,10 +914,15 @@ k_fused_multi(FusedMultiParams M)
         const unsigned *word = prev + (mine ? (long)c2 * P.n_strips + s2 : 0);
         bool ok = !mine;
         const unsigned long long t0 = wall_clock64();
-        // acquire: the x loads of the tile must not be moved above the poll (the sc1 loads inside fused_wave read
-        // through to memory; the ordering is the language's business, stated here and not left to the access forms)
+        // The hand-off itself travels by ACCESS FORM, not by cache-wide fences: the producer's x stores are sc1 (write
+        // through) and acknowledged (s_waitcnt) before its count, the consumer's x loads are sc1 (read through).  An
+        // agent-scope acquire / release here — buffer_inv / buffer_wbl2 of a whole L2 per tile — was tried in round 4 as
+        // the language-level statement of the same thing: the four-passes launch went from 0.95x to 1.7x the time of four
+        // launches (profiles/r04_multi_fences.txt).  What the language DOES have to be told is not to move the tile's
+        // loads above the poll loop: a wavefront-scope fence, which orders this wave's accesses and emits no cache
+        // operation.
         while (!__all(ok)) {
-            if (!ok) ok = __hip_atomic_load(word, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) >= need;
+            if (!ok) ok = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need;
             if (__all(ok)) break;
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > 100000000ull) {              // 1 s of the 100 MHz clock: never in a correct run
@@ -926,7 +931,7 @@ k_fused_multi(FusedMultiParams M)
                 break;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
     // ---- the tile -------------------------------------------------------------------------------------------
     // a wave that gave up stores nothing (the handle's error word is up: every later call returns CCP_ERR_STATE) but still
@@ -942,9 +947,10 @@ k_fused_multi(FusedMultiParams M)
         else fused_wave<T, false, 0, UNR, 1, false, true>(xin, xout, P.b + off, g, sx, r0, r1, acc);
     }
     // ---- publish: the (write-through) stores acknowledged, then the count ----------------------------------------
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");           // (compiler ordering: the stores stay above the count)
     __builtin_amdgcn_s_waitcnt(0);                                   // every (write-through) store of the tile acknowledged
     if (lane == 0)
-        __hip_atomic_fetch_add(M.cells + (long)q * cells_per_pass + ((long)ch * P.n_chunks + chunk) * P.n_strips + sx, 1u, __ATOMIC_RELEASE,
+        __hip_atomic_fetch_add(M.cells + (long)q * cells_per_pass + ((long)ch * P.n_chunks + chunk) * P.n_strips + sx, 1u, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_AGENT);
 }
 

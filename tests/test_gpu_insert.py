@@ -237,8 +237,9 @@ def test_a_batch_of_edits_equals_the_edits_one_by_one(capi, orc, sorted_by_row):
     rng = np.random.Generator(np.random.MT19937(11))
     n = 300
     a = sp.random(n, n, density=0.3, random_state=np.random.RandomState(3), data_rvs=lambda k: rng.integers(1, 50, k).astype(np.float64)).tocsr()
-    a.setdiag(np.asarray(abs(a).sum(axis=1)).ravel() + 7.0)
-    a = a.tocsr()
+    a = (a - sp.diags(a.diagonal()) + sp.diags(np.asarray(abs(a).sum(axis=1)).ravel() + 7.0)).tocsr()
+    a.sum_duplicates()
+    a.eliminate_zeros()
     v, c, r = csr_arrays(a)
     coo = a.tocoo()
     k_rm = rng.choice(len(coo.row), 4000, replace=False)

@@ -6,6 +6,8 @@ import json
 import os
 import sys
 
+ROUND = os.environ.get("ROUND", "r03")
+
 
 def rows(path):
     out = {}
@@ -45,8 +47,8 @@ def main(d, out_path):
         if f + w <= 0:
             return
         out[key] = {"hbm_bytes_per_launch": f + w, "fetch_bytes_corrected": f, "write_bytes": w, "kernels": found,
-                    "source": f"profiles/r03_pmc_FETCH_SIZE_{tag}.csv (FETCH_SIZE x 2: gfx950 correction) + profiles/r03_pmc_WRITE_SIZE_{tag}.csv; "
-                              f"separate --pmc passes, tools/profile_round3.sh; {note}"}
+                    "source": f"profiles/{ROUND}_pmc_FETCH_SIZE_{tag}.csv (FETCH_SIZE x 2: gfx950 correction) + profiles/{ROUND}_pmc_WRITE_SIZE_{tag}.csv; "
+                              f"separate --pmc passes, tools/profile_round{ROUND[-1]}.sh; {note}"}
         if extra:
             out[key].update(extra)
 

@@ -1,9 +1,9 @@
 #!/bin/bash
-# rocprofv3 passes of round 3 (run on the GPU box from the repo root): kernel trace + stats of the default bench.py
+# rocprofv3 passes of round 4 (run on the GPU box from the repo root): kernel trace + stats of the default bench.py
 # command; FETCH_SIZE / WRITE_SIZE passes (separate runs, as the guide prescribes) of the bench's timed kernels and of
-# the configs[1] / [4] / reference-order / CG kernels; summaries under gpurun_out/r03/prof/, copied to profiles/ by hand.
+# the configs[1] / [4] / reference-order / CG kernels; summaries under gpurun_out/r04/prof/, copied to profiles/ by hand.
 set -o pipefail
-out=$PWD/gpurun_out/r03/prof
+out=$PWD/gpurun_out/r04/prof
 mkdir -p "$out"
 export TMPDIR=/tmp
 lean="--no-configs --no-cpu-baseline --no-converge --no-parity --no-reference-order"
@@ -37,7 +37,11 @@ pass region python3 tools/profile_kernels.py region
 pass sell python3 tools/profile_kernels.py gs
 pass lex python3 tools/profile_kernels.py --sweeps 64 lex
 pass cg python3 tools/profile_kernels.py cg
-python3 tools/make_traffic.py "$out" "$out/traffic.json"
+# SQ counters of the reference-order sweep (how busy the SIMDs are over the launch)
+timeout -k 10 400 rocprofv3 --output-format csv --pmc SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAIT_INST_ANY -d "$out/pmc_sq_lex" -o k -- python3 tools/profile_kernels.py --sweeps 64 lex > "$out/pmc_sq_lex.txt" 2> "$out/pmc_sq_lex.log" \
+    && python3 tools/pmc_summary.py "$(find "$out/pmc_sq_lex" -name '*counter_collection.csv' | head -1)" "$out/pmc_sq_lex.csv"
+echo "pmc sq lex rc=$?"
+ROUND=r04 python3 tools/make_traffic.py "$out" "$out/traffic.json"
 find "$out" -name '*counter_collection.csv' -delete
 find "$out" -name '*kernel_trace.csv' -size +5M -delete
 ls "$out"
