@@ -88,9 +88,10 @@ def _share_rccl_with_torch() -> None:
     """The same for RCCL, which libccp_gs.so binds at run time by soname (ccp_comm.hpp): inside a Python
     process the HIP runtime is torch's, so the collective library must be the one torch ships with it.
     Importing torch (where it is installed) before the first communicator call loads that copy in torch's
-    own order; the soname lookup inside the library then finds it.  (Loading torch's librccl.so by hand
-    and importing torch LATER in the same process aborts at exit — "double free" in the teardown of the
-    two runtimes — measured on ROCm 7.0/7.2; tools/_tmp history)"""
+    own order; the soname lookup inside the library then finds it.  (Round 2 saw a process that bound torch's
+    librccl.so by hand and imported torch LATER abort at exit; root-caused in round 3 to RTLD_GLOBAL symbol
+    interposition between librocm_smi64 and libamd_smi and fixed in csrc/ccp_comm.hip — that order is a
+    regression test now, tests/test_gpu_rccl.py — so this import is about sharing ONE runtime, not about the exit.)"""
     import importlib.util
     if "torch" in sys.modules or os.environ.get("CCP_GS_NO_TORCH_HIP") or os.environ.get("CCP_GS_RCCL_LIB"):
         return
