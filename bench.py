@@ -400,13 +400,14 @@ def config0(capi):
     ups = W * H * iters / rep.seconds
     return {"workload": "512x512 single-channel Poisson, lexicographic Gauss-Seidel (reference order), 100 iterations",
             "kernel": "k_lex_wg (time-skewed strips: 8 sweeps per pass on the 8 compute waves of a workgroup, a loader and a "
-                      "storer wave, all passes in one launch per pass depth)", "ms": rep.seconds * 1e3,
+                      "storer wave; persistent workgroups, all 100 sweeps one pipeline: the last group passes 4 sweeps through)",
+            "ms": rep.seconds * 1e3,
             "pixel_updates_per_s": ups,
             "bytes_model": f"{LEX_WG_BYTES_PER_UPDATE:.2f} B per update at 8 sweeps per pass (b 76/62 x 8/8, x read 63/62 x 8/8, x write "
-                           "8/8, edge values 2 x 16/62); PMC on 16384^2: 4.2 B (profiles/r02_pmc_*_lex_wg_16384.csv)",
+                           "8/8, edge values 2 x 16/62); PMC on 16384^2: 4.25 B (profiles/r04_pmc_*_lex.csv)",
             "frac": ups * LEX_WG_BYTES_PER_UPDATE / 1e9 / HBM_PEAK_GBS,
-            "bound_note": "not a bandwidth-bound kernel: lock-step steps of ~0.2 us (LDS round trip + barrier, tools/step_bench.hip); at "
-                          "this size 10 strips x 12 passes on a critical path of ~(H + 64 + 60 strips) steps per pass",
+            "bound_note": "not a bandwidth-bound kernel: lock-step steps of ~0.23 us; at this size 9 strips x 13 groups on a critical path "
+                          "set by the lag between neighbouring strips (33 us) and between groups (40 us): profiles/r04_lex_trace.jsonl",
             "bit_identical_to_oracle": bool(np.array_equal(x, want)),
             "cpu_baseline": {"value": W * H * iters / secs, "unit": "pixel-updates/s", "cores": 1, "kind": kind,
                              "sample": f"the same system and iteration count, {secs:.3f} s"}}
@@ -745,7 +746,7 @@ def main():
         rep = g.gauss_seidel_lexicographic(0.0, args.reference_order_iters, 0)[0]
         extra["reference_order"] = {
             "what": "lexicographic Gauss-Seidel (the reference's index-order sweep, sparse-matrix.h:357-370), "
-                    "time-skewed strips, 8 sweeps per pass (k_lex_wg); iterates bit-identical to the reference's",
+                    "time-skewed strips, 8 sweeps per pass, persistent workgroups (k_lex_wg); iterates bit-identical to the reference's",
             "iterations": rep.iterations, "seconds": rep.seconds,
             "pixel_updates_per_s": float(W) * H * C * rep.iterations / rep.seconds,
             "rel_residual_after": float(solver.rel_residual().max())}
