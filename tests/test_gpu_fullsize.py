@@ -492,6 +492,40 @@ def test_full_width_16384_every_pixel_against_oracle(capi, orc, order):
     assert np.array_equal(got, want)
 
 
+def test_headline_shape_16384_squared_bands_against_oracle(capi, orc):
+    """BASELINE configs[2] at FULL size — 16384 x 16384, the system bench.py times (x_true and b generated on the device,
+    x0 = 1, the pinned tiling) — against the reference-pinned oracle, pixel for pixel, on three bands of rows: the top of
+    the image (pin row included), the middle, the bottom (the degree-1 / degree-0 rows included).  A red-black iterate
+    depends on what lies within 2 rows per iteration, so K iterations of a band are exactly K iterations of the oracle on
+    the rows of the band plus 2K rows either side (taken from the same b, cut out of the image): rows nearer than 2K to a
+    cut are thrown away.  (The oracle cannot hold the whole system: its int32 positions — the reference's — end at 2^30
+    entries; and the lexicographic order has no such locality: its full-width check is the 768-row test above.)"""
+    import oracle
+    import bench
+    from coursecomputationalphotography_amd import synth
+    W = H = 16384
+    K, band = 16, 64
+    T, R = bench.DEFAULT_TILING[(W, H, 1)]
+    g = capi.Grid(W, H, 1)
+    g.randomize_x(1234, 0.0, 255.0)
+    g.b_from_x()
+    g.fill_x(1.0)
+    g.set_tiling(T, R)
+    g.sweep(K)                                               # two passes of depth 8, as bench.py's steps are made of
+    pad = 2 * K + 2                                          # (+2: a margin over the one-row-per-half-sweep bound)
+    for y0 in (0, H // 2 - band // 2, H - band):
+        lo, hi = max(0, y0 - pad), min(H, y0 + band + pad)
+        lo -= lo & 1                                         # (an even first row keeps (x + y) & 1 the image's colouring)
+        hs = hi - lo
+        b = g.get_b(0, lo, hs).ravel()
+        v, c, r = synth.poisson_csr(W, hs)
+        want, _, _ = orc.multicolour_gauss_seidel(v, c, r, oracle.grid_colour(W, hs), b, 0.0, K)
+        want = want.reshape(hs, W)
+        got = g.get_x(0, y0, band)
+        assert np.array_equal(got, want[y0 - lo:y0 - lo + band]), y0
+    g.close()
+
+
 def test_config4_full_8192_mask_against_oracle(capi, orc):
     """BASELINE configs[4] at FULL size — 8192 x 8192 canvas, union-of-discs + brush mask (the generator
     tools/csr_bench.py and bench.py's configs[4] use), 41.75 M unknowns: SpMV bit-exact against the row-wise
