@@ -35,6 +35,7 @@ def test_bench_contract_line_single_gpu():
     assert d["roofline"]["launches_timed"] * d["roofline"]["iterations_per_launch"] == 2 * 16
     pc = d["parity_check"]
     assert pc["iterations"] == 48 and pc["abs_sum_equal"] and pc["residual_sums_equal"] and pc["bands_equal"]
+    assert pc["oracle_bands"]["bit_identical"] is True and pc["oracle_bands"]["iterations"] == 16       # ... and against the oracle
     assert "iters_to_1e-5" in d and d["rel_residual_after_timed"][0] == 48
     # the untimed reference-order run on the same system
     ro = d["reference_order"]
