@@ -51,3 +51,29 @@ def test_launcher_world_size_must_match():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], capture_output=True, text=True,
                          timeout=300, env=env)
     assert out.returncode != 0 and "--gpus 4 but the launcher started 2" in out.stderr
+
+
+def test_cpu_baseline_child_reports_its_phases(tmp_path):
+    """bench.py's CPU baseline runs in a child process (no torch, no GPU): one JSON line per sample and a wall-clock line per
+    phase in the log, so that a run that is cut short still says where the time went."""
+    import json
+    log = tmp_path / "phases.log"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--cpu-baseline-child", "96,160", "--cpu-iters", "3",
+                          "--cpu-threads", "2", "--cpu-log", str(log)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [json.loads(ln) for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert [d["sample"] for d in lines] == [96, 160]
+    for d in lines:
+        assert d["iters"] == 3 and d["value"] > 0 and d["index_type"] == "int" and d["kind"] in ("reference", "port")
+        assert set(d["phases_s"]) >= {"warm", "generator", "rhs"}
+    text = log.read_text()
+    for what in ("warm (first touch", "generator (closed form", "b = A x_true", "gaussSeidel, 3 sweeps"):
+        assert text.count(what) == 2, what
+
+
+def test_the_headline_system_needs_the_wide_index_type():
+    sys.path.insert(0, ROOT)
+    import bench
+    assert not bench.cpu_needs_wide_index(4096) and not bench.cpu_needs_wide_index(14336)
+    assert bench.cpu_needs_wide_index(16384)                   # 5 x 16384^2 > 2^30: getNearestIndex's (end + idx) / 2 overflows int
+    assert 50.0 < bench.cpu_system_gb(16384) < 70.0
