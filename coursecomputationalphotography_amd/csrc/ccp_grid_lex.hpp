@@ -490,16 +490,26 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
                                             int xs0, unsigned long long *tr)
 {
     constexpr int kCols = LexWgShape<T>::kCols;
-    const unsigned c_b0 = (unsigned)min(max(cb + lane, 0), W - 1);
-    const unsigned c_b1 = (unsigned)min(max(cb + kWave + min(lane, max(kCols - kWave - 1, 0)), 0), W - 1);
+    static_assert(kCols % 2 == 0 && kCols / 2 <= kWave && LexWgShape<T>::kRowW % 2 == 0, "a b row travels as pairs of columns");
+    // A b row of the strip (kCols = 62 + 2(T - 1) columns from column cb, which is even) travels as PAIRS of columns: lane l
+    // brings columns cb + 2l, cb + 2l + 1 in one 16-byte load and puts them into LDS in one 16-byte write (rows are 16-byte
+    // aligned on both sides: P and kRowW are even).  One load and one write per step instead of two and two (64 + 12
+    // columns; round 4).  A pair that starts left of the image is moved to column 0 and one that runs past the row's end
+    // reads the padding or the next row — allocated memory either way, values never used.
+    const bool b_lane = lane < kCols / 2;
+    const unsigned c_b = (unsigned)max(cb + 2 * min(lane, kCols / 2 - 1), 0);
     const unsigned c_x = (unsigned)min(max(xs0 + 2 + min(lane, kWave - 2), 0), W - 1);   // as sweep 0's lanes 2.. read x: one and two places to their left
     auto b_row = [&](int r) { return bp + (long)min(max(r, 0), n_diag - 1) * P; };
     auto x_row = [&](int r) { return xq + (long)min(max(r, 0), n_diag - 1) * P; };
+    auto b_pair = [&](const double *row) { return *reinterpret_cast<const double2 *>(row + c_b); };
     // MASKED: is (diagonal row r, this lane's column) a pixel of the canvas?
-    const int k_b0 = cb + lane, k_b1 = cb + kWave + lane, k_x = xs0 + 2 + lane;
+    const int k_b = cb + 2 * lane, k_x = xs0 + 2 + lane;
     auto on_canvas = [&](int r, int c) { return c >= 0 && c < W && (unsigned)(r - c) < (unsigned)H; };
     auto b_in = [&](double v, int r, int c) { return (!MASKED || on_canvas(r, c)) ? v : lex_fixed_marker(); };
     auto x_in = [&](double v, int r, int c) { return (!MASKED || (lane < kWave - 1 && on_canvas(r, c))) ? v : 0.0; };
+    auto put_b = [&](int slot, double2 v, int r) {
+        if (b_lane) *reinterpret_cast<double2 *>(&brow[slot][2 * lane]) = make_double2(b_in(v.x, r, k_b), b_in(v.y, r, k_b + 1));
+    };
     lex_wg_gate(st, db0);
     if (tr && lane == 0) tr[1] = wall_clock64();
     lex_lds_barrier();                                                       // (wave 0 fetches the first ghost batch behind the gate)
@@ -507,11 +517,11 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
     // waves, in the kernel)
 #pragma unroll
     for (int q = 0; q < 3; ++q) ring[0][(db0 + q) & (kLexRing - 1)][lane] = x_in(lex_ld(x_row(db0 + q) + c_x), db0 + q, k_x);
-    double qb[8], qb1[8], qx[8];
+    double2 qb[8];
+    double qx[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        qb[j] = b_row(db0 + 1 + j)[c_b0];
-        qb1[j] = kCols > kWave ? b_row(db0 + 1 + j)[c_b1] : 0.0;
+        qb[j] = b_pair(b_row(db0 + 1 + j));
         qx[j] = lex_ld(x_row(db0 + 3 + j) + c_x);
     }
     const double *rb = bp + (long)(db0 + 9) * P, *rx = xq + (long)(db0 + 11) * P;   // (uniform row bases: scalar registers)
@@ -526,14 +536,11 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
         // at the end of the rightmost strips (never used).  Running pointers, nothing to clamp.
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const int r = (db + j + 1) & (kLexBRows - 1);
-            if (kCols >= kWave || lane < kCols) brow[r][lane] = b_in(qb[j], db + j + 1, k_b0);   // b row d + 1 (T = 1: 62 columns)
-            if (kCols > kWave && lane < kCols - kWave) brow[r][kWave + lane] = b_in(qb1[j], db + j + 1, k_b1);
+            put_b((db + j + 1) & (kLexBRows - 1), qb[j], db + j + 1);           // b row d + 1
             ring[0][(j + 3) & (kLexRing - 1)][lane] = x_in(qx[j], db + j + 3, k_x);       // x row d + 3: read by sweep 0 at steps d+2, d+3
             asm volatile("" ::: "memory");
-            qb[j] = rb[c_b0];                                                // b row d + 9: plain loads (b does not change) — with
-            if (kCols > kWave) qb1[j] = rb[c_b1];                            // sc1 here two workgroups sharing a CU run at half speed
-            qx[j] = lex_ld(rx + c_x);                                        // x row d + 11
+            qb[j] = b_pair(rb);                                              // b row d + 9: plain loads (b does not change) — with
+            qx[j] = lex_ld(rx + c_x);                                        // sc1 here two workgroups sharing a CU run at half speed; x row d + 11
             rb += P;
             rx += P;
             lex_lds_barrier();
