@@ -203,6 +203,13 @@ constexpr int kLexSkewCols = kWave - 2;
 constexpr bool kLexShiftDown = CCP_LEX_SHIFT_DOWN != 0;   // interior bodies of k_lex_wg: `down` from `right` by a lane shift
 constexpr int kLexRing = 4;                        // result rows kept per sweep: written at step d, read at step d+3, free at d+4
 constexpr int kLexBRows = 32;
+// The ring of b rows in LDS carries kLexBMirror more rows: slot 32 + k is a copy of slot k (k < 4), kept by everybody who
+// writes a row (lex_b_slot_mirror).  A compute wave reads the 8 rows of a block at slots sb .. sb + 7 with sb = (db - 4t) & 31
+// a multiple of 4, i.e. up to slot 35: with the mirror the slot of step j is sb + j — a constant offset from the block's
+// base address — instead of (sb + j) & 31, which cost every compute wave a scalar and, a scalar multiply and a vector add
+// per step (round 4).
+constexpr int kLexBMirror = 4;
+__device__ __forceinline__ bool lex_b_slot_mirrored(int slot) { return slot < kLexBMirror; }
 constexpr int kLexSlackRows = 320;                 // diagonal rows allocated beyond the last one (k_lex_wg prefetches past the image)
 constexpr int kLexScratch = 32;                    // doubles per workgroup the storer of k_lex_wg may write to and nobody reads
 constexpr int kLexStoresPerBlock = 8 * 2 + 1;      // k_lex_wg's storer: two stores per step (x row, edge values) + the publication, per 8-step block
@@ -282,7 +289,11 @@ struct LexGhosts {
         for (int k = 0; k < kOps; ++k) {
             const int d = blk + g_k(lane);
             const bool valid = e_left != nullptr && d >= left_begin && d <= left_end;
-            if (lane_on(lane, k)) brow[(d - 4 * g_t(lane, k)) & (kLexBRows - 1)][g_col(lane, k)] = valid ? q[k] : 0.0;
+            const int slot = (d - 4 * g_t(lane, k)) & (kLexBRows - 1);
+            if (lane_on(lane, k)) {
+                brow[slot][g_col(lane, k)] = valid ? q[k] : 0.0;
+                if (lex_b_slot_mirrored(slot)) brow[kLexBRows + slot][g_col(lane, k)] = valid ? q[k] : 0.0;
+            }
         }
     }
     // step j of block db
@@ -366,7 +377,7 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
             // ghost lanes 0 and 1 never use either)
             const double right = ring[t][(j + 1) & (kLexRing - 1)][lds1];
             const double down = kLexShiftDown ? lane_prev(right) : ring[t][(j + 1) & (kLexRing - 1)][lds2];
-            const double vv = brow[(sb + j) & (kLexBRows - 1)][col];
+            const double vv = brow[sb + j][col];                            // (sb + j <= 35: the mirror rows)
             const double up = h1;
             const double left = lane_prev(h1);
             double nv = (vv + (((up + left) + right) + down)) * 0.25;        // (sparse-matrix.h:361-376 on a full row)
@@ -408,7 +419,7 @@ __device__ __forceinline__ void lex_wg_compute_masked(double &h1, double &acc, d
         for (int j = 0; j < 8; ++j) {
             const double right = ring[t][(j + 1) & (kLexRing - 1)][lds1];                  // (one LDS read and a lane shift: lex_wg_compute)
             const double down = kLexShiftDown ? lane_prev(right) : ring[t][(j + 1) & (kLexRing - 1)][lds2];
-            const double vv = brow[(sb + j) & (kLexBRows - 1)][col];
+            const double vv = brow[sb + j][col];
             const double up = h1;
             const double left = lane_prev(h1);
             double nv = (vv + (((up + left) + right) + down)) * 0.25;
@@ -439,10 +450,11 @@ __device__ __forceinline__ void lex_wg_pass_through(double (*ring)[kLexRing][kWa
     const int col = LexWgShape<T>::kGhost + 2 * t + (lane & 1);              // (the ghost lanes' column of a b row)
     double old = 0.0;
     for (int db = db0; db <= db1; db += 8) {
+        const int sb = (db - 4 * t) & (kLexBRows - 1);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const double down = ring[t][(j + 1) & (kLexRing - 1)][lds2];
-            const double vv = brow[(db + j - 4 * t) & (kLexBRows - 1)][col];
+            const double vv = brow[sb + j][col];
             const double nv = ghost ? vv : old;
             old = down;
             ring[t + 1][j & (kLexRing - 1)][lane] = nv;
@@ -508,7 +520,11 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
     auto b_in = [&](double v, int r, int c) { return (!MASKED || on_canvas(r, c)) ? v : lex_fixed_marker(); };
     auto x_in = [&](double v, int r, int c) { return (!MASKED || (lane < kWave - 1 && on_canvas(r, c))) ? v : 0.0; };
     auto put_b = [&](int slot, double2 v, int r) {
-        if (b_lane) *reinterpret_cast<double2 *>(&brow[slot][2 * lane]) = make_double2(b_in(v.x, r, k_b), b_in(v.y, r, k_b + 1));
+        if (b_lane) {
+            const double2 w = make_double2(b_in(v.x, r, k_b), b_in(v.y, r, k_b + 1));
+            *reinterpret_cast<double2 *>(&brow[slot][2 * lane]) = w;
+            if (lex_b_slot_mirrored(slot)) *reinterpret_cast<double2 *>(&brow[kLexBRows + slot][2 * lane]) = w;   // (uniform)
+        }
     };
     lex_wg_gate(st, db0);
     if (tr && lane == 0) tr[1] = wall_clock64();
@@ -656,7 +672,7 @@ __device__ __forceinline__ void lex_wg_body()
     static_assert(4 * (T - 1) + 4 <= kLexBRows, "a b row stays in LDS from step r-1 to step r+4(T-1)");
     constexpr int kRowW = LexWgShape<T>::kRowW;
     __shared__ double ring[T + 1][kLexRing][kWave];
-    __shared__ double brow[kLexBRows][kRowW];
+    __shared__ double brow[kLexBRows + kLexBMirror][kRowW];
     __shared__ unsigned s_ticket;
     const int ch = blockIdx.y;
     // Nothing of a strip may be carried around the persistent loop in VECTOR registers: the loader is held to 80 VGPRs
@@ -703,7 +719,7 @@ __device__ __forceinline__ void lex_wg_body()
 #pragma unroll
             for (int q = 0; q < kLexRing; ++q) ring[wv][q][lane] = zero;
         }
-        for (int i = tid; i < kLexBRows * kRowW; i += (T + 2) * kWave) (&brow[0][0])[i] = zero;
+        for (int i = tid; i < (kLexBRows + kLexBMirror) * kRowW; i += (T + 2) * kWave) (&brow[0][0])[i] = zero;
     }
     __syncthreads();
     const unsigned my_ticket = s_ticket;
@@ -759,8 +775,14 @@ __device__ __forceinline__ void lex_wg_body()
                 const double *row = bd + plane + (long)min(max(r, 0), lg.n_diag - 1) * lg.P;
                 const bool in0 = !MASKED || (cb + lane >= 0 && cb + lane < lg.W && (unsigned)(r - cb - lane) < (unsigned)lg.H);
                 const bool in1 = !MASKED || (cb + kWave + lane < lg.W && (unsigned)(r - cb - kWave - lane) < (unsigned)lg.H);
-                if (kCols >= kWave || lane < kCols) brow[r & (kLexBRows - 1)][lane] = in0 ? row[c0] : lex_fixed_marker();
-                if (kCols > kWave && lane < kCols - kWave) brow[r & (kLexBRows - 1)][kWave + lane] = in1 ? row[c1] : lex_fixed_marker();
+                const int slot = r & (kLexBRows - 1);
+                const double v0 = in0 ? row[c0] : lex_fixed_marker(), v1 = in1 ? row[c1] : lex_fixed_marker();
+                if (kCols >= kWave || lane < kCols) brow[slot][lane] = v0;
+                if (kCols > kWave && lane < kCols - kWave) brow[slot][kWave + lane] = v1;
+                if (lex_b_slot_mirrored(slot)) {
+                    if (kCols >= kWave || lane < kCols) brow[kLexBRows + slot][lane] = v0;
+                    if (kCols > kWave && lane < kCols - kWave) brow[kLexBRows + slot][kWave + lane] = v1;
+                }
             }
         }
     }
