@@ -213,8 +213,8 @@ __device__ __forceinline__ bool lex_b_slot_mirrored(int slot) { return slot < kL
 constexpr int kLexSlackRows = 320;                 // diagonal rows allocated beyond the last one (k_lex_wg prefetches past the image)
 constexpr int kLexScratch = 32;                    // doubles per workgroup the storer of k_lex_wg may write to and nobody reads
 constexpr int kLexStoresPerBlock = 8 * 2 + 1;      // k_lex_wg's storer: two stores per step (x row, edge values) + the publication, per 8-step block
-constexpr int kLexPublishLagBlocks = 2;            // ... publishes the steps before block db - 8*2 ...
-constexpr int kLexPublishVmcnt = 48;               // ... once at most this many of its stores are outstanding (< 3 blocks' worth)
+constexpr int kLexPublishLagBlocks = 1;            // ... publishes the steps before block db - 8*1 ...
+constexpr int kLexPublishVmcnt = 32;               // ... once at most this many of its stores are outstanding (< 2 blocks' worth)
 constexpr int kLexWordStride = 32;                 // progress words of k_lex_wg: one per 128-byte line (the word a strip's
                                                    // storer writes is polled by its neighbours' loaders)
 
@@ -343,6 +343,69 @@ __device__ __forceinline__ void lex_wg_general_block(double &h1, double &acc, do
     }
 }
 
+// One block at the HEAD of a strip (EDGE 0: every pixel the wave's real lanes touch in these 8 steps lies on a row
+// y <= H-2 — lanes come onto the image through row 0) or at its TAIL (EDGE 1: on a row y >= 1 — they leave through row
+// H-1), for an image of at least 2 x 3 pixels.  The row of the matrix a pixel has then follows from its column (as in the
+// inner blocks, lex_wg_compute: c_x0 / c_xl / c_off) and from ONE comparison of its y:
+//   row 0      no `up`: diagonal 3 (left, right, down; at x = 0: right, down and the corner's + 1), at x = W-1 `left` alone
+//   row H-1    `up` alone, diagonal 1; no row at x = W-1
+// in gs_update()'s accumulation order, a / 3 by lex_div3.  A third of body C's vector instructions (~25 a step against
+// ~60: classify() per pixel and step, the division sequence in diverged lanes) — and these blocks are what the start of
+// the NEXT strip waits for: its first gate opens when this strip has done its first ~100 steps, most of them here
+// (per-workgroup trace at 512^2: 36 us from strip to strip, 41 us from group to group, round 4).
+template <int T, bool CHECK, int KIND, int EDGE>
+__device__ __forceinline__ void lex_wg_edge_block(double &h1, double &acc, double &old, double (*ring)[kLexRing][kWave],
+                                                  double (*brow)[LexWgShape<T>::kRowW], int H, int t, int lane, int db, int xp,
+                                                  bool c_off, bool c_x0, bool c_xl, LexGhosts<T> &gh)
+{
+    const bool ghost = lane < 2;
+    const int lds2 = max(lane - 2, 0);
+    const int col = ghost ? LexWgShape<T>::kGhost + 2 * t + lane : lane - 2 - 2 * t + 2 * (T - 1);
+    int y = db - xp - 2 * t;
+#pragma unroll 1
+    for (int j = 0; j < 8; ++j, ++y) {
+        const double *in = &ring[t][(j + 1) & (kLexRing - 1)][lds2];
+        const double down = in[0];
+        const double right = in[1];
+        const double vv = brow[(db + j - 4 * t) & (kLexBRows - 1)][col];
+        const double up = h1;
+        const double left = lane_prev(h1);
+        double nv = (vv + (((up + left) + right) + down)) * 0.25;            // rows 1 .. H-2, by column: lex_wg_compute
+        double a3 = vv + ((up + right) + down);                              // ... x = 0
+        bool third = (KIND & 1) && c_x0;
+        bool row = !c_off;
+        if (EDGE == 0) {
+            const bool top = y == 0;
+            double at = vv + ((left + right) + down);
+            if (KIND & 1) at = c_x0 ? vv + (right + down) : at;
+            a3 = top ? at : a3;
+            third = third || top;
+            row = row && y >= 0;
+        }
+        if ((KIND & 1) || EDGE == 0) {
+            bool finite;
+            double q = lex_div3(a3, finite);
+            if (__any(third && !finite)) {
+                asm volatile("" ::: "memory");
+                q = a3 / 3.0;
+            }
+            nv = third ? q : nv;
+        }
+        if (KIND & 2) nv = c_xl ? vv + left : nv;                            // x = W-1, rows 0 .. H-2: `left` alone
+        if (EDGE == 1) {
+            nv = y == H - 1 ? vv + up : nv;
+            row = row && y < H && !((KIND & 2) && c_xl && y == H - 1);
+        }
+        nv = row ? nv : ghost ? vv : 0.0;
+        if (CHECK) acc += row ? fabs(nv - old) : 0.0;
+        old = down;
+        ring[t + 1][j & (kLexRing - 1)][lane] = nv;
+        h1 = nv;
+        gh.step(brow, db, j, lane);
+        lex_lds_barrier();
+    }
+}
+
 // Blocks db0 .. db1 of compute wave t.  A block whose 8 steps have 1 <= y <= H-2 for every real lane of the wave
 // (steps xs0+64+2t .. xs0+2t+H) takes body A (KIND 0) or B (1: the wave holds column 0 — only in strip 0, whose
 // ghost lanes lie off the image; 2: it holds column W-1; 3: both, an image narrower than a strip): the row of a
@@ -366,7 +429,14 @@ __device__ __forceinline__ void lex_wg_compute(double &h1, double &acc, double (
     double old = 0.0;
     for (int db = db0; db <= db1; db += 8) {
         if (db < in_lo || db + 7 > in_hi) {
-            lex_wg_general_block<T, CHECK>(h1, acc, old, ring, brow, g, W, H, t, lane, db, xs0 + lane, gh);
+            // rows of the real lanes (2 .. 63) in these 8 steps: y = d - (xs0 + lane) - 2t
+            const int y_lo = db - (xs0 + 63) - 2 * t, y_hi = db + 7 - (xs0 + 2) - 2 * t;
+            if (W >= 2 && H >= 3 && y_hi <= H - 2)
+                lex_wg_edge_block<T, CHECK, KIND, 0>(h1, acc, old, ring, brow, H, t, lane, db, xs0 + lane, c_off, c_x0, c_xl, gh);
+            else if (W >= 2 && H >= 3 && y_lo >= 1)
+                lex_wg_edge_block<T, CHECK, KIND, 1>(h1, acc, old, ring, brow, H, t, lane, db, xs0 + lane, c_off, c_x0, c_xl, gh);
+            else
+                lex_wg_general_block<T, CHECK>(h1, acc, old, ring, brow, g, W, H, t, lane, db, xs0 + lane, gh);
             continue;
         }
         const int sb = (db - 4 * t) & (kLexBRows - 1);
@@ -531,8 +601,11 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
     lex_lds_barrier();                                                       // (wave 0 fetches the first ghost batch behind the gate)
     // what the first steps read before the rings are rolling: x rows db0, db0+1, db0+2 (the b rows up to db0: by all
     // waves, in the kernel)
+    // (all nineteen loads go out before the first is waited for: one trip to memory between the gate and the strip's first
+    // step, not two — the next strip's gate waits for this strip's first ~100 steps and for everything in front of them)
+    double x3[3];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) ring[0][(db0 + q) & (kLexRing - 1)][lane] = x_in(lex_ld(x_row(db0 + q) + c_x), db0 + q, k_x);
+    for (int q = 0; q < 3; ++q) x3[q] = lex_ld(x_row(db0 + q) + c_x);
     double2 qb[8];
     double qx[8];
 #pragma unroll
@@ -540,6 +613,8 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
         qb[j] = b_pair(b_row(db0 + 1 + j));
         qx[j] = lex_ld(x_row(db0 + 3 + j) + c_x);
     }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) ring[0][(db0 + q) & (kLexRing - 1)][lane] = x_in(x3[q], db0 + q, k_x);
     const double *rb = bp + (long)(db0 + 9) * P, *rx = xq + (long)(db0 + 11) * P;   // (uniform row bases: scalar registers)
     lex_lds_barrier();                                                       // (every wave of the workgroup comes here)
     for (int db = db0; db <= db1; db += 8) {
@@ -626,9 +701,10 @@ __device__ __forceinline__ void lex_wg_store(LexWgStrip &st, double (*ring)[kLex
             }
         }
         // Stores complete in issue order, and a block issues kLexStoresPerBlock of them (two per step + this
-        // publication): once at most the kLexPublishVmcnt youngest are outstanding — this block's, the one before and
-        // most of a third — every store of the blocks before those three has been acknowledged.  Publish their steps
-        // (everything before block db - 8 kLexPublishLagBlocks), without draining.
+        // publication): once at most the kLexPublishVmcnt youngest are outstanding — this block's and all but one of the
+        // block before — every store of the blocks before those two has been acknowledged.  Publish their steps
+        // (everything before block db - 8 kLexPublishLagBlocks), without draining.  (Round 4: one block of lag, not two —
+        // a store is two blocks = 4 us old by then; eight steps less between a strip and the strips that wait for it.)
         // REQUIRED CODEGEN: exactly kLexStoresPerBlock vector-memory instructions per block in this wave — the three
         // branches above each issue their two stores per step unconditionally (masked lanes go to scratch slots) so
         // that the compiler can neither merge nor drop one; a build whose storer issued FEWER would publish early.

@@ -112,8 +112,31 @@ def show(path):
         print(json.dumps(out), flush=True)
 
 
+def table(path):
+    """the last record's first-gate and last-step times, microseconds from the first ticket, one line per group"""
+    last = None
+    for meta, r in records(path):
+        last = (meta, r)
+    meta, r = last
+    G, S = meta["groups"], meta["S"]
+    t0, t1, t2 = (r[:, k].astype(np.int64) for k in range(3))
+    ok = (t0 > 0) & (t2 > 0)
+    base = t0[ok].min()
+    tk = (r[:, 3] >> 32).astype(np.int64)
+    gate = np.full(G * S, -1.0)
+    end = np.full(G * S, -1.0)
+    gate[tk[ok]] = (t1[ok] - base) * 1e-2
+    end[tk[ok]] = (t2[ok] - base) * 1e-2
+    print(json.dumps(meta))
+    for g in range(G):
+        print("g%-3d gate " % g + " ".join("%7.1f" % v for v in gate[g * S:(g + 1) * S]))
+        print("     end  " + " ".join("%7.1f" % v for v in end[g * S:(g + 1) * S]))
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "run":
+    if sys.argv[1] == "table":
+        table(sys.argv[2])
+    elif sys.argv[1] == "run":
         run(int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), sys.argv[5] if len(sys.argv) > 5 else "gpurun_out/lex_trace.bin")
     else:
         show(sys.argv[2])
