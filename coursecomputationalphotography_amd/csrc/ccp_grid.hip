@@ -99,7 +99,7 @@ struct ccp_grid {
     int lex_tmax = 8;            // deepest time-skewed pass
     DevBuf<unsigned> lex_order;  // k_lex_wg: ticket -> group * strips + strip, in wavefront order
     std::vector<unsigned> lex_order_host;
-    int lex_order_groups = 0, lex_order_strips = 0;
+    int lex_order_groups = 0, lex_order_strips = 0, lex_order_depth = 0;
     LexGeom lexg{};
     DevBuf<double> stage;        // natural-order staging rows for host transfers
     long stage_rows = 0;
@@ -1468,9 +1468,15 @@ namespace {
 // partial sums one checked sweep writes per channel
 // (time-skewed strips: the strip count depends on the depth; the partial layout uses the largest, depth 8's —
 // slots a shallower launch does not write must read as zero, so the buffer is cleared per batch)
+// the diagonal-major arrays behind their front rows (kLexFrontRows: what k_lex_wg's loader prefetches for a strip that
+// starts left of the image lies up to 64 diagonals before the first one; never used)
+double *lex_xd(const ccp_grid *g) { return g->lex_x.p + (size_t)kLexFrontRows * g->lexg.P; }
+double *lex_bd(const ccp_grid *g) { return g->lex_b.p + (size_t)kLexFrontRows * g->lexg.P; }
+constexpr int kLexBatchSweeps = 128;     // sweeps in flight between two looks at the stop rule
+constexpr int kLexLaunchSweeps = 1024;   // most sweeps one launch of k_lex_wg carries (its strips move 2 columns left per sweep: lex_strip_count)
 long lex_partials_per_sweep(const ccp_grid *g)
 {
-    if (g->lex_mode == 3) return (long)((g->desc.width - 1 + 2 * 7) / kLexSkewCols + 1);
+    if (g->lex_mode == 3) return (long)lex_strip_count(g->desc.width, 1, kLexBatchSweeps);   // (T groups of a checked batch shift by 2 x its sweeps at most)
     return (long)g->lexg.n_diag * g->lexg.nbx;
 }
 
@@ -1482,7 +1488,9 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial, int
 {
     const LexGeom &lg = g->lexg;
     const int C = g->desc.channels;
-    const int S = (lg.W - 1 + 2 * (T - 1)) / kLexSkewCols + 1;
+    if ((long)groups * T > kLexLaunchSweeps) return CCP_ERR_STATE;
+    const int S = lex_strip_count(lg.W, T, groups);                      // strip slots per group (not every group has all of them)
+    const int S_cap = lex_strip_count(lg.W, 1, kLexLaunchSweeps);       // ... of the largest launch, whatever its depth
     const long edge_steps = kWave + lg.H + 2 * (T - 1);
     // persistent workgroups: as many as are resident at once (k_lex_wg's comment), each taking strips from the ticket counter
     int per_cu = 0, cus = 0;
@@ -1490,33 +1498,47 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial, int
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wg<T, false>, (T + 2) * kWave, 0);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device);
     const long resident = (long)std::max(per_cu, 1) * std::max(cus, 1);
-    const long wgs = std::max<long>(1, std::min<long>((long)groups * S, (resident + C - 1) / C));
-    // Buffers are sized for the largest launch a solve can issue (a batch holds at most 4096 sweeps: 512 groups), not
-    // for this one: a call with more sweeps than the call before must not pay a 0.5 GB reallocation inside its own
-    // timing (the kernel trace of round 4 showed 25 ms of it between the layout conversion and the launch).
+    // Buffers are sized for the largest launch a solve can issue (kLexLaunchSweeps), not for this one: a call with more
+    // sweeps than the call before must not pay a 0.5 GB reallocation inside its own timing (the kernel trace of round 4
+    // showed 25 ms of it between the layout conversion and the launch).
     const size_t need = (size_t)C * groups * S * kLexWordStride;
-    const size_t need_cap = (size_t)C * std::max(groups, 512) * S * kLexWordStride;
-    const size_t edges = (size_t)C * S * edge_steps * 2 * T + (size_t)C * resident * kLexScratch;   // (+ the storers' scratch slots, one set per resident workgroup)
-    const size_t edges_cap = (size_t)C * ((lg.W - 1 + 14) / kLexSkewCols + 1) * (kWave + lg.H + 14) * 16 + (size_t)C * resident * kLexScratch;   // (what depth 8 needs)
-    if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(need_cap));
-    if (g->lex_order_groups != groups || g->lex_order_strips != S) {
-        // Tickets in wavefront order: strip s of group k starts about (s + rho k) strip-lags after the first one,
-        // and a workgroup that is resident but waiting keeps a slot from one that could run.  Everything (k, s)
-        // waits for — (k, s-1), (k-1, s), (k-1, s+1) — sorts before it for any rho >= 1 (ties: lower group first).
-        const long rho = 3;
+    const size_t need_cap = (size_t)C * std::max(groups, kLexLaunchSweeps / 8) * S_cap * kLexWordStride;
+    const size_t edges = (size_t)kLexEdgeSets * C * S * edge_steps * 2 * T + (size_t)C * resident * kLexScratch;   // (+ the storers' scratch slots, one set per resident workgroup)
+    const size_t edges_cap = (size_t)kLexEdgeSets * C * S_cap * (kWave + lg.H + 14) * 16 + (size_t)C * resident * kLexScratch;   // (what depth 8 needs)
+    if (g->lex_progress.n < need) CCP_TRY(g->lex_progress.alloc(std::max(need, need_cap)));
+    if (g->lex_order_groups != groups || g->lex_order_strips != S || g->lex_order_depth != T) {
+        // Tickets in the order the strips can start: (k, s) follows its left neighbour (k, s-1) by a strip lag (the 62
+        // diagonals its first pixel lies further on + the 16 steps of edge values it wants to see published + the
+        // publication's own lag) and the same strip of the group before by a group lag; a workgroup that is resident but
+        // waiting keeps a slot from one that could run.  Everything a strip waits for holds a smaller ticket — a ticket's
+        // holder never waits for a larger one: no deadlock, whatever the residency.
+        const long strip_lag = kLexSkewCols + 34, group_lag = 19 + 4 * (T - 1) + 16;
+        struct Ticket { long start; int k, s; };
+        std::vector<long> start((size_t)groups * S, -1);
+        std::vector<Ticket> tickets;
+        for (int k = 0; k < groups; ++k)
+            for (int st = lex_strip_first(T, k); st <= lex_strip_last(lg.W, T, k); ++st) {
+                long t = 0;
+                if (lex_strip_exists(lg.W, T, k, st - 1)) t = std::max(t, start[(size_t)k * S + st - 1] + strip_lag);
+                if (lex_strip_exists(lg.W, T, k - 1, st)) t = std::max(t, start[(size_t)(k - 1) * S + st] + group_lag);
+                if (lex_strip_exists(lg.W, T, k - kLexEdgeSets, st + 1)) t = std::max(t, start[(size_t)(k - kLexEdgeSets) * S + st + 1] + 1);
+                start[(size_t)k * S + st] = t;
+                tickets.push_back({t, k, st});
+            }
+        std::stable_sort(tickets.begin(), tickets.end(), [](const Ticket &a, const Ticket &b) { return a.start < b.start; });
         std::vector<unsigned> &order = g->lex_order_host;       // (kept in the handle: the copy below needs no host sync)
-        order.assign((size_t)groups * S, 0u);
-        size_t n = 0;
-        for (long key = 0; key <= (long)(S - 1) + rho * (groups - 1); ++key)
-            for (long k = std::max(0L, (key - (S - 1) + rho - 1) / rho); k <= std::min<long>(groups - 1, key / rho); ++k)
-                order[n++] = (unsigned)(k * S + (key - rho * k));
-        if (n != order.size()) return CCP_ERR_STATE;
-        if (g->lex_order.n < order.size()) CCP_TRY(g->lex_order.alloc(std::max(order.size(), (size_t)512 * S)));
+        order.clear();
+        for (const Ticket &t : tickets) order.push_back((unsigned)((long)t.k * S + t.s));
+        if (order.empty()) return CCP_ERR_STATE;
+        if (g->lex_order.n < order.size()) CCP_TRY(g->lex_order.alloc(std::max(order.size(), (size_t)(kLexLaunchSweeps / 8) * S_cap)));
         CCP_HIP(hipStreamSynchronize(g->stream));               // (an earlier copy from this vector may still be in flight)
         CCP_HIP(hipMemcpyAsync(g->lex_order.p, order.data(), order.size() * sizeof(unsigned), hipMemcpyHostToDevice, g->stream));
         g->lex_order_groups = groups;
         g->lex_order_strips = S;
+        g->lex_order_depth = T;
     }
+    const unsigned n_tickets = (unsigned)g->lex_order_host.size();
+    const long wgs = std::max<long>(1, std::min<long>((long)n_tickets, (resident + C - 1) / C));
     if (g->lex_edges.n < edges) CCP_TRY(g->lex_edges.alloc(std::max(edges, edges_cap)));
     if (!g->lex_ticket.p) CCP_TRY(g->lex_ticket.alloc(kMaxChannels));
     CCP_HIP(hipMemsetAsync(g->lex_progress.p, 0, need * sizeof(unsigned), g->stream));
@@ -1536,7 +1558,7 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial, int
     }
 #define CCP_LEX_WG(KERNEL, CHECK, P, STRIDE)                                                                                        \
     hipLaunchKernelGGL((KERNEL<T, CHECK>), grid, block, 0, g->stream,                                                                \
-                       LexWgArgs{g->lex_x.p, g->lex_b.p, g->geom, lg, groups, S, g->lex_progress.p, g->lex_ticket.p, g->lex_order.p,  \
+                       LexWgArgs{lex_xd(g), lex_bd(g), g->geom, lg, groups, S, n_tickets, g->lex_progress.p, g->lex_ticket.p, g->lex_order.p,  \
                                  g->lex_edges.p, edge_steps, mask, P, STRIDE, trace, t_last})
     if (g->masked) {
         if (partial) CCP_LEX_WG(k_lex_wg_masked, true, partial, lex_partials_per_sweep(g));
@@ -1601,10 +1623,10 @@ int lex_run(ccp_grid *g, int iterations, unsigned mask, double *partial)
         if (k_hi < k_lo) continue;
         dim3 grid((unsigned)lg.nbx, (unsigned)(k_hi - k_lo + 1), (unsigned)C);
         if (partial)
-            hipLaunchKernelGGL((k_lex_plane<true>), grid, dim3(kBlock), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg,
+            hipLaunchKernelGGL((k_lex_plane<true>), grid, dim3(kBlock), 0, g->stream, lex_xd(g), lex_bd(g), g->geom, lg,
                                tau, k_lo, mask, partial);
         else
-            hipLaunchKernelGGL((k_lex_plane<false>), grid, dim3(kBlock), 0, g->stream, g->lex_x.p, g->lex_b.p, g->geom, lg,
+            hipLaunchKernelGGL((k_lex_plane<false>), grid, dim3(kBlock), 0, g->stream, lex_xd(g), lex_bd(g), g->geom, lg,
                                tau, k_lo, mask, static_cast<double *>(nullptr));
     }
     CCP_HIP(hipGetLastError());
@@ -1630,18 +1652,21 @@ try {
     lg.nbx = (std::min(W, H) + kLexTile - 1) / kLexTile;
     const size_t elems = (size_t)lg.plane * C;
     const size_t slack = (size_t)kLexSlackRows * lg.P;       // k_lex_wg prefetches some diagonals past the last one (never used)
-    if (g->lex_x.n != elems + slack) {
-        CCP_TRY(g->lex_x.alloc(elems + slack));
-        CCP_TRY(g->lex_b.alloc(elems + slack));
-        CCP_HIP(hipMemsetAsync(g->lex_x.p + elems, 0, slack * sizeof(double), g->stream));
-        CCP_HIP(hipMemsetAsync(g->lex_b.p + elems, 0, slack * sizeof(double), g->stream));
+    const size_t front = (size_t)kLexFrontRows * lg.P;       // ... and a strip that starts left of the image some diagonals before the first
+    if (g->lex_x.n != front + elems + slack) {
+        CCP_TRY(g->lex_x.alloc(front + elems + slack));
+        CCP_TRY(g->lex_b.alloc(front + elems + slack));
+        CCP_HIP(hipMemsetAsync(g->lex_x.p, 0, front * sizeof(double), g->stream));
+        CCP_HIP(hipMemsetAsync(g->lex_b.p, 0, front * sizeof(double), g->stream));
+        CCP_HIP(hipMemsetAsync(lex_xd(g) + elems, 0, slack * sizeof(double), g->stream));
+        CCP_HIP(hipMemsetAsync(lex_bd(g) + elems, 0, slack * sizeof(double), g->stream));
     }
     CCP_TRY(begin_timing(g));
     dim3 cgrid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, (unsigned)C);
     dim3 tgrid((unsigned)((W + kLexCT - 1) / kLexCT), (unsigned)((H + kLexCT - 1) / kLexCT), (unsigned)C);
-    hipLaunchKernelGGL((k_lex_convert_tiled<true>), tgrid, dim3(kBlock), 0, g->stream, g->x.p, g->lex_x.p, g->geom, lg);
-    if (g->masked) hipLaunchKernelGGL(k_lex_convert_b_masked, cgrid, dim3(kBlock), 0, g->stream, g->b.p, g->maskp.p, g->lex_b.p, g->geom, lg);
-    else hipLaunchKernelGGL((k_lex_convert_tiled<true>), tgrid, dim3(kBlock), 0, g->stream, g->b.p, g->lex_b.p, g->geom, lg);
+    hipLaunchKernelGGL((k_lex_convert_tiled<true>), tgrid, dim3(kBlock), 0, g->stream, g->x.p, lex_xd(g), g->geom, lg);
+    if (g->masked) hipLaunchKernelGGL(k_lex_convert_b_masked, cgrid, dim3(kBlock), 0, g->stream, g->b.p, g->maskp.p, lex_bd(g), g->geom, lg);
+    else hipLaunchKernelGGL((k_lex_convert_tiled<true>), tgrid, dim3(kBlock), 0, g->stream, g->b.p, lex_bd(g), g->geom, lg);
     CCP_HIP(hipGetLastError());
 
     const unsigned all = (C >= 32) ? 0xffffffffu : ((1u << C) - 1u);
@@ -1656,13 +1681,13 @@ try {
         // fixed count — or the reference loop never starts (eps = 10 <= epsilon)
         const int n = check_every == 0 ? max_iteration : 0;
         for (int done = 0; done < n;) {                    // gridDim.y carries the sweeps in flight: keep it small
-            const int kb = std::min(g->lex_mode != 0 ? 4096 : 32768, n - done);   // (k_lex_wg: one progress word per group and strip)
+            const int kb = std::min(g->lex_mode != 0 ? kLexLaunchSweeps : 32768, n - done);   // (k_lex_wg: one progress word per group and strip)
             CCP_TRY(lex_run(g, kb, all, nullptr));
             done += kb;
         }
         for (int ch = 0; ch < C; ++ch) iterations_of[ch] = n;
     } else {
-        const int batch_max = 128;                                       // sweeps in flight between two looks at the rule
+        const int batch_max = kLexBatchSweeps;                           // sweeps in flight between two looks at the rule
         const long per = lex_partials_per_sweep(g);                         // partials per (iteration, channel)
         if (g->lex_partial.n != (size_t)per * batch_max * C) CCP_TRY(g->lex_partial.alloc((size_t)per * batch_max * C));
         if (g->lex_eps.n != (size_t)batch_max * C) CCP_TRY(g->lex_eps.alloc((size_t)batch_max * C));
@@ -1672,7 +1697,7 @@ try {
         int done = 0;
         while (mask && done < max_iteration) {
             const int kb = std::min(batch_max, max_iteration - done);
-            CCP_HIP(hipMemcpyAsync(g->lex_snap.p, g->lex_x.p, elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
+            CCP_HIP(hipMemcpyAsync(g->lex_snap.p, lex_xd(g), elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
             if (g->lex_mode == 3) CCP_HIP(hipMemsetAsync(g->lex_partial.p, 0, sizeof(double) * (size_t)per * kb * C, g->stream));
             CCP_TRY(lex_run(g, kb, mask, g->lex_partial.p));
             hipLaunchKernelGGL(k_lex_reduce, dim3((unsigned)kb, (unsigned)C), dim3(kBlock), 0, g->stream, g->lex_partial.p, per,
@@ -1698,7 +1723,7 @@ try {
                 if (stop < kb - 1) {
                     // the pipeline ran past the sweep the rule stops at: redo exactly stop+1 sweeps of
                     // this channel from the snapshot taken before the batch
-                    CCP_HIP(hipMemcpyAsync(g->lex_x.p + (size_t)ch * lg.plane, g->lex_snap.p + (size_t)ch * lg.plane,
+                    CCP_HIP(hipMemcpyAsync(lex_xd(g) + (size_t)ch * lg.plane, g->lex_snap.p + (size_t)ch * lg.plane,
                                            (size_t)lg.plane * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
                     CCP_TRY(lex_run(g, stop + 1, 1u << ch, nullptr));
                 }
@@ -1708,7 +1733,7 @@ try {
         for (int ch = 0; ch < C; ++ch)
             if (!converged[ch]) iterations_of[ch] = done;
     }
-    hipLaunchKernelGGL((k_lex_convert_tiled<false>), tgrid, dim3(kBlock), 0, g->stream, g->x.p, g->lex_x.p, g->geom, lg);
+    hipLaunchKernelGGL((k_lex_convert_tiled<false>), tgrid, dim3(kBlock), 0, g->stream, g->x.p, lex_xd(g), g->geom, lg);
     CCP_HIP(hipGetLastError());
     CCP_TRY(end_timing(g));
     CCP_HIP(hipStreamSynchronize(g->stream));

@@ -171,6 +171,24 @@ __device__ __forceinline__ void lex_st(double *p, double v) { __hip_atomic_store
 // (group, s-1) through the same step; (group-1, s) and (group-1, s+1) through step + 1 + 4(T-1) (they wrote the x this
 // group's sweep 0 reads).  Only sweep 0 reads x and only sweep T-1 writes it; b is read once per pass.
 constexpr int kLexSkewCols = kWave - 2;
+// Strip s of group k (the k-th pass of T sweeps of one launch) starts 2T columns further LEFT than strip s of group k-1:
+// xs0 = kLexSkewCols s - 2 - 2T k.  The skew of a group (sweep t works 2t columns left of sweep 0) simply goes on into
+// the next group, and so what sweep 0 of (k, s) reads — x columns xs0+2 .. xs0+64 — was written by (k-1, s) (its last
+// sweep covers xs0+4 .. xs0+65 in the new strip's numbering) and, the first two columns, by (k-1, s-1), which is never
+// behind (k-1, s).  With the strips of all groups in the same place (rounds 2-4) it was (k-1, s) AND its right neighbour
+// (k-1, s+1), which starts a whole strip-to-strip stagger later: a group followed its predecessor 35 us behind instead
+// of 17 (512^2 trace, round 4).
+// Strips that hold no pixel of the image — on the left in late groups, on the right in early ones — get no ticket.
+__host__ __device__ inline int lex_strip_first(int T, int k) { return (2 * T * k) / kLexSkewCols; }
+__host__ __device__ inline int lex_strip_last(int W, int T, int k) { return (W - 1 + 2 * T * k + 2 * (T - 1)) / kLexSkewCols; }
+__host__ __device__ inline bool lex_strip_exists(int W, int T, int k, int s)
+{
+    return k >= 0 && s >= lex_strip_first(T, k) && s <= lex_strip_last(W, T, k);
+}
+__host__ __device__ inline int lex_strip_count(int W, int T, int groups) { return lex_strip_last(W, T, groups - 1) + 1; }
+// The edge values of a strip live in one of kLexEdgeSets buffers (group k: set k % kLexEdgeSets): (k, s) overwrites what
+// (k - kLexEdgeSets, s) left for (k - kLexEdgeSets, s+1), and waits until that strip has taken it (lex_wg_body).
+constexpr int kLexEdgeSets = 2;
 
 // ---------------------------------------------------------------------------------------------
 // The skewed pass with the T sweeps spread over the waves of a workgroup (k_lex_wg): a workgroup of T + 2 waves per
@@ -210,6 +228,7 @@ constexpr int kLexBRows = 32;
 // per step (round 4).
 constexpr int kLexBMirror = 4;
 __device__ __forceinline__ bool lex_b_slot_mirrored(int slot) { return slot < kLexBMirror; }
+constexpr int kLexFrontRows = 64;                  // diagonal rows allocated BEFORE the first one (a strip that starts left of the image prefetches them; never used)
 constexpr int kLexSlackRows = 320;                 // diagonal rows allocated beyond the last one (k_lex_wg prefetches past the image)
 constexpr int kLexScratch = 32;                    // doubles per workgroup the storer of k_lex_wg may write to and nobody reads
 constexpr int kLexStoresPerBlock = 8 * 2 + 1;      // k_lex_wg's storer: two stores per step (x row, edge values) + the publication, per 8-step block
@@ -622,7 +641,8 @@ __device__ __forceinline__ void lex_wg_load(LexWgStrip &st, double (*ring)[kLexR
         // issued here, looked at after the block's last step: no loaded value but the prefetch slots lives across
         // the loop's back edge
         const unsigned polled = __hip_atomic_load(st.words + st.watch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // The rows fetched from here on exist: b row d+9 >= 1 (the strip's first block starts at -8 or later), and
+        // The rows fetched from here on exist: b row d+9 >= -55 (a strip's first block starts at -64 or later: the
+        // leftmost strip of a group reaches at most 63 columns beyond the image; kLexFrontRows), and
         // the arrays carry kLexSlackRows rows beyond the last diagonal for the prefetches that run past the image
         // at the end of the rightmost strips (never used).  Running pointers, nothing to clamp.
 #pragma unroll
@@ -729,7 +749,8 @@ struct LexWgArgs {
     const double *bd;
     Geom g;
     LexGeom lg;
-    int G, S;
+    int G, S;                       // groups; strip slots per group (lex_strip_count: not all of them exist in every group)
+    unsigned n_tickets;             // strips that exist, over all groups
     unsigned *progress, *ticket;
     const unsigned *order;
     double *edges;
@@ -778,6 +799,7 @@ __device__ __forceinline__ void lex_wg_body()
     const Geom g = ap->g;
     const LexGeom lg = ap->lg;
     const int G = ap->G, S = ap->S;
+    const unsigned n_tickets = ap->n_tickets;
     unsigned *const progress = ap->progress, *const ticket = ap->ticket;
     const unsigned *const order = ap->order;
     double *const edges = ap->edges;
@@ -799,7 +821,7 @@ __device__ __forceinline__ void lex_wg_body()
     }
     __syncthreads();
     const unsigned my_ticket = s_ticket;
-    if (my_ticket >= (unsigned)(G * S)) break;               // (uniform)
+    if (my_ticket >= n_tickets) break;                       // (uniform)
     const unsigned tk = order[my_ticket];                    // (group, strip) in wavefront order
     const int grp = (int)(tk / (unsigned)S), s = (int)(tk % (unsigned)S);
     // CCP_GS_TRACE_FILE (diagnostics): per strip — ticket taken, first gate passed, last step done, where it ran
@@ -811,19 +833,21 @@ __device__ __forceinline__ void lex_wg_body()
                 | ((unsigned long long)tk << 32);
     }
     const int HS = lg.H + 2 * (T - 1);
-    const int xs0 = kLexSkewCols * s - 2;
+    const int xs0 = kLexSkewCols * s - 2 - 2 * T * grp;      // (lex_strip_first: where the strips of group grp lie)
+    const bool has_left = lex_strip_exists(lg.W, T, grp, s - 1);
     const int xl = xs0 + lane - 2 * t;                       // this lane's image column
     const bool lane_on = lane >= 2 && xl >= 0 && xl < lg.W;
     const int d_begin = xs0, d_end = xs0 + (kWave - 1) + HS - 1;
     const int db0 = d_begin & ~7, db1 = d_end & ~7;          // first and last block (floor to a multiple of 8, also when negative)
     const long plane = (long)ch * lg.plane;
-    double *e_mine = edges + ((long)ch * S + s) * edge_steps * (2 * T);
-    const double *e_left = s > 0 ? edges + ((long)ch * S + s - 1) * edge_steps * (2 * T) : nullptr;
+    double *e_set = edges + (long)(grp % kLexEdgeSets) * gridDim.y * S * edge_steps * (2 * T);
+    double *e_mine = e_set + ((long)ch * S + s) * edge_steps * (2 * T);
+    const double *e_left = has_left ? e_set + ((long)ch * S + s - 1) * edge_steps * (2 * T) : nullptr;
     const int left_begin = xs0 - kLexSkewCols, left_end = left_begin + (kWave - 1) + HS - 1;
     const int cb = xs0 + 2 - 2 * (T - 1);                    // the leftmost image column any sweep of the strip touches
 
     // One progress word per strip, written by the storer.  The loader watches: lane 0 the left strip (edge
-    // values), lanes 1 and 2 the two strips of the previous group sweep 0 reads x from.
+    // values), lane 1 the strip of the previous group sweep 0 reads x from, lane 2 the last reader of the edge buffer.
     LexWgStrip st;
     const unsigned my_word = (unsigned)((((long)ch * G + grp) * S + s) * kLexWordStride);
     st.words = progress;
@@ -831,13 +855,25 @@ __device__ __forceinline__ void lex_wg_body()
     st.watch = my_word;
     st.need_off = INT_MIN / 2;
     st.known = 0;
-    if (lane == 0 && s > 0) {
+    if (lane == 0 && has_left) {
         st.watch = my_word - kLexWordStride;
         st.need_off = 16;                                    // before block [db, db+7]: the ghost batch of block db+8
     }
-    if (grp > 0 && (lane == 1 || (lane == 2 && s + 1 < S))) {
-        st.watch = (unsigned)((((long)ch * G + grp - 1) * S + s + (lane - 1)) * kLexWordStride);
+    if (lane == 1 && lex_strip_exists(lg.W, T, grp - 1, s)) {
+        // (k-1, s): the x columns sweep 0 reads (but for the first two: (k-1, s-1)'s, which is never behind (k-1, s) —
+        // a strip passes a block's gate only when its left neighbour has PUBLISHED 16 steps beyond it).  What this strip
+        // WRITES to x (columns xs0+2-2(T-1) .. xs0+63-2(T-1), row d-4(T-1) at step d) was read by those same two strips.
+        st.watch = (unsigned)((((long)ch * G + grp - 1) * S + s) * kLexWordStride);
         st.need_off = 19 + 4 * (T - 1);                      // x row db+18, written by sweep T-1 at step db+18+4(T-1)
+    }
+    if (lane == 2 && lex_strip_exists(lg.W, T, grp - kLexEdgeSets, s + 1)) {
+        // (k-kLexEdgeSets, s+1) took its ghost values from the buffer this strip's edge values go to: the entries of
+        // this strip's block db are that strip's block db + 2T kLexEdgeSets (its xs0 lies that much further right),
+        // fetched during its block db + 2T kLexEdgeSets - 8 (LexGhosts) — taken once that block is complete.  (It started
+        // kLexEdgeSets group lags minus one strip lag before this strip AND a strip further along the diagonals: it is
+        // ~120 steps past that point when this strip starts; the watch is the guarantee.)
+        st.watch = (unsigned)((((long)ch * G + grp - kLexEdgeSets) * S + s + 1) * kLexWordStride);
+        st.need_off = 2 * T * kLexEdgeSets + 8;
     }
 
     {   // b rows db0 - 4(T-1) .. db0 into the ring, a few per wave: sweep t reads row d - 4t at step d (the loader
@@ -862,12 +898,12 @@ __device__ __forceinline__ void lex_wg_body()
             }
         }
     }
-    const bool strip_interior = s > 0 && xs0 + 2 - 2 * t >= 1 && xs0 + 63 - 2 * t <= lg.W - 2;
+    const bool strip_interior = has_left && xs0 + 2 - 2 * t >= 1 && xs0 + 63 - 2 * t <= lg.W - 2;
     const Stencil st_b = classify(g, lane_on ? xl : 0, 1, 1);                // (meaningful where H >= 3: inner blocks only)
     if (wv < T) {
         double h1 = 0.0, acc = 0.0;
         // which borders this wave's columns xs0+2-2t .. xs0+63-2t hold
-        const bool has_x0 = s == 0 && xs0 + 2 - 2 * t <= 0 && xs0 + 63 - 2 * t >= 0;
+        const bool has_x0 = xs0 + 2 - 2 * t <= 0 && xs0 + 63 - 2 * t >= 0;
         const bool has_xl = xs0 + 63 - 2 * t >= lg.W - 1;                // (column W-1, or nothing on the image at all)
         LexGhosts<T> gh;
         gh.e_left = e_left;
@@ -894,7 +930,7 @@ __device__ __forceinline__ void lex_wg_body()
         lex_wg_load<T, MASKED>(st, ring, brow, lane, db0, db1, bd + plane, xd + plane, lg.P, lg.n_diag, lg.W, lg.H, cb, xs0, tr);
     } else {
         // (scratch: kLexScratch doubles per resident workgroup behind the edge values of all strips)
-        double *scratch = edges + (long)gridDim.y * S * edge_steps * (2 * T) + ((long)ch * gridDim.x + blockIdx.x) * kLexScratch;
+        double *scratch = edges + (long)kLexEdgeSets * gridDim.y * S * edge_steps * (2 * T) + ((long)ch * gridDim.x + blockIdx.x) * kLexScratch;
         lex_wg_store<T, MASKED>(st, ring, g, lg.W, lg.H, lane, db0, db1, xd + plane, lg.P, xs0, d_begin, d_end, e_mine, scratch, strip_interior, st_b);
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");                   // compiler ordering only
