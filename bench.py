@@ -433,8 +433,9 @@ def config0(capi):
             "bytes_model": f"{LEX_WG_BYTES_PER_UPDATE:.2f} B per update at 8 sweeps per pass (b 76/62 x 8/8, x read 63/62 x 8/8, x write "
                            "8/8, edge values 2 x 16/62); PMC on 16384^2: 4.25 B (profiles/r04_pmc_*_lex.csv)",
             "frac": ups * LEX_WG_BYTES_PER_UPDATE / 1e9 / HBM_PEAK_GBS,
-            "bound_note": "not a bandwidth-bound kernel: lock-step steps of ~0.23 us; at this size 9 strips x 13 groups on a critical path "
-                          "set by the lag between neighbouring strips (33 us) and between groups (40 us): profiles/r04_lex_trace.jsonl",
+            "bound_note": "not a bandwidth-bound kernel: lock-step steps of ~0.23 us; at this size 13 groups of 9-12 strips on a critical "
+                          "path set by the lag between neighbouring strips (31 us: 62 diagonals of geometry + 32 steps of hand-off) and "
+                          "between groups (16 us): profiles/r04_lex_trace_512.jsonl",
             "bit_identical_to_oracle": bool(np.array_equal(x, want)),
             "cpu_baseline": {"value": W * H * iters / secs, "unit": "pixel-updates/s", "cores": 1, "kind": kind,
                              "sample": f"the same system and iteration count, {secs:.3f} s"}}
