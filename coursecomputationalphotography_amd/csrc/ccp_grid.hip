@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <functional>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 using namespace ccp;
@@ -97,8 +98,11 @@ struct ccp_grid {
     int lex_mode = 3;            // 3: time-skewed strips, the T sweeps of a pass on the T waves of a workgroup (k_lex_wg, default);
                                  // CCP_GS_LEX_MODE=planes -> 0: one launch per hyperplane (k_lex_plane, the independent engine)
     int lex_tmax = 8;            // deepest time-skewed pass
-    DevBuf<unsigned> lex_order;  // k_lex_wg: ticket -> group * strips + strip, in wavefront order
-    std::vector<unsigned> lex_order_host;
+                                 // k_lex_wg: ticket -> group * strips + strip, in the order the strips can start:
+    unsigned *lex_order_pin = nullptr;   // ... built here, in pinned host memory the kernel reads directly (one word per strip, long before
+    unsigned *lex_order_dev = nullptr;   //     the strip's gate opens): copying 34 KB to the device cost 7-8 ms of host time inside the timing
+    size_t lex_order_pin_cap = 0;        //     of a 256-sweep solve, from pageable and from pinned memory alike (CCP_GS_DEBUG laps, round 4)
+    size_t lex_order_count = 0;
     int lex_order_groups = 0, lex_order_strips = 0, lex_order_depth = 0;
     LexGeom lexg{};
     DevBuf<double> stage;        // natural-order staging rows for host transfers
@@ -943,6 +947,7 @@ try {
     if (g->edge_counter) (void)hipFree(g->edge_counter);
     if (g->edge_flag) (void)hipFree(g->edge_flag);
     if (g->edge_timeout) (void)hipHostFree(g->edge_timeout);
+    if (g->lex_order_pin) (void)hipHostFree(g->lex_order_pin);
     delete g;
     return CCP_OK;
 } CCP_ABI_CATCH
@@ -1489,6 +1494,11 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial, int
     const LexGeom &lg = g->lexg;
     const int C = g->desc.channels;
     if ((long)groups * T > kLexLaunchSweeps) return CCP_ERR_STATE;
+    const bool dbg = getenv("CCP_GS_DEBUG") != nullptr;
+    const auto t_in = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (dbg) fprintf(stderr, "[ccp_gs] lex_launch_skew %s at %.3f ms\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count());
+    };
     const int S = lex_strip_count(lg.W, T, groups);                      // strip slots per group (not every group has all of them)
     const int S_cap = lex_strip_count(lg.W, 1, kLexLaunchSweeps);       // ... of the largest launch, whatever its depth
     const long edge_steps = kWave + lg.H + 2 * (T - 1);
@@ -1498,6 +1508,7 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial, int
     else (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_lex_wg<T, false>, (T + 2) * kWave, 0);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, g->device);
     const long resident = (long)std::max(per_cu, 1) * std::max(cus, 1);
+    lap("occupancy known");
     // Buffers are sized for the largest launch a solve can issue (kLexLaunchSweeps), not for this one: a call with more
     // sweeps than the call before must not pay a 0.5 GB reallocation inside its own timing (the kernel trace of round 4
     // showed 25 ms of it between the layout conversion and the launch).
@@ -1526,24 +1537,35 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial, int
                 tickets.push_back({t, k, st});
             }
         std::stable_sort(tickets.begin(), tickets.end(), [](const Ticket &a, const Ticket &b) { return a.start < b.start; });
-        std::vector<unsigned> &order = g->lex_order_host;       // (kept in the handle: the copy below needs no host sync)
-        order.clear();
-        for (const Ticket &t : tickets) order.push_back((unsigned)((long)t.k * S + t.s));
-        if (order.empty()) return CCP_ERR_STATE;
-        if (g->lex_order.n < order.size()) CCP_TRY(g->lex_order.alloc(std::max(order.size(), (size_t)(kLexLaunchSweeps / 8) * S_cap)));
-        CCP_HIP(hipStreamSynchronize(g->stream));               // (an earlier copy from this vector may still be in flight)
-        CCP_HIP(hipMemcpyAsync(g->lex_order.p, order.data(), order.size() * sizeof(unsigned), hipMemcpyHostToDevice, g->stream));
+        if (tickets.empty()) return CCP_ERR_STATE;
+        lap("tickets sorted");
+        const size_t order_cap = std::max(tickets.size(), (size_t)(kLexLaunchSweeps / 8) * S_cap);
+        CCP_HIP(hipStreamSynchronize(g->stream));               // (an earlier copy from the pinned buffer may still be in flight)
+        lap("stream drained");
+        if (g->lex_order_pin_cap < tickets.size()) {
+            if (g->lex_order_pin) (void)hipHostFree(g->lex_order_pin);
+            g->lex_order_pin = g->lex_order_dev = nullptr;
+            g->lex_order_pin_cap = 0;
+            CCP_HIP(hipHostMalloc(reinterpret_cast<void **>(&g->lex_order_pin), order_cap * sizeof(unsigned), hipHostMallocMapped));
+            CCP_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&g->lex_order_dev), g->lex_order_pin, 0));
+            g->lex_order_pin_cap = order_cap;
+        }
+        for (size_t i = 0; i < tickets.size(); ++i) g->lex_order_pin[i] = (unsigned)((long)tickets[i].k * S + tickets[i].s);
+        __atomic_thread_fence(__ATOMIC_RELEASE);
+        g->lex_order_count = tickets.size();
         g->lex_order_groups = groups;
         g->lex_order_strips = S;
         g->lex_order_depth = T;
+        lap("order queued");
     }
-    const unsigned n_tickets = (unsigned)g->lex_order_host.size();
+    const unsigned n_tickets = (unsigned)g->lex_order_count;
     const long wgs = std::max<long>(1, std::min<long>((long)n_tickets, (resident + C - 1) / C));
     if (g->lex_edges.n < edges) CCP_TRY(g->lex_edges.alloc(std::max(edges, edges_cap)));
     if (!g->lex_ticket.p) CCP_TRY(g->lex_ticket.alloc(kMaxChannels));
     CCP_HIP(hipMemsetAsync(g->lex_progress.p, 0, need * sizeof(unsigned), g->stream));
     CCP_HIP(hipMemsetAsync(g->lex_ticket.p, 0, kMaxChannels * sizeof(unsigned), g->stream));
     dim3 grid((unsigned)wgs, (unsigned)C);
+    lap("buffers cleared");
     if (getenv("CCP_GS_DEBUG"))
         fprintf(stderr, "[ccp_gs] k_lex_wg<%d>: %d workgroups per CU on %d CUs, %ld persistent workgroups per channel for %d groups x %d strips\n",
                 T, per_cu, cus, wgs, groups, S);
@@ -1558,7 +1580,7 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial, int
     }
 #define CCP_LEX_WG(KERNEL, CHECK, P, STRIDE)                                                                                        \
     hipLaunchKernelGGL((KERNEL<T, CHECK>), grid, block, 0, g->stream,                                                                \
-                       LexWgArgs{lex_xd(g), lex_bd(g), g->geom, lg, groups, S, n_tickets, g->lex_progress.p, g->lex_ticket.p, g->lex_order.p,  \
+                       LexWgArgs{lex_xd(g), lex_bd(g), g->geom, lg, groups, S, n_tickets, g->lex_progress.p, g->lex_ticket.p, g->lex_order_dev,  \
                                  g->lex_edges.p, edge_steps, mask, P, STRIDE, trace, t_last})
     if (g->masked) {
         if (partial) CCP_LEX_WG(k_lex_wg_masked, true, partial, lex_partials_per_sweep(g));
