@@ -1613,11 +1613,13 @@ int lex_run_skew(ccp_grid *g, int iterations, unsigned mask, double *partial)
     const int C = g->desc.channels;
     const long per_sweep = (long)C * lex_partials_per_sweep(g);          // partial doubles per sweep (all channels)
     int left = iterations, done = 0;
-    if (!partial && g->lex_tmax >= 8 && left >= 8 && left % 8 != 0) {
-        // a count that is not a multiple of 8, no stop rule: ONE launch of depth-8 groups whose last group passes the
-        // sweeps it does not have through (lex_wg_pass_through) instead of remainder launches of depth 4, 2, 1
+    if (g->lex_tmax >= 8 && left >= 8 && left % 8 != 0) {
+        // a count that is not a multiple of 8: ONE launch of depth-8 groups whose last group passes the sweeps it does
+        // not have through (lex_wg_pass_through) instead of remainder launches of depth 4, 2, 1, each a pipeline of its
+        // own to fill and drain.  (With the stop rule too: the passed-through sweeps leave step sums of 0 in slots
+        // beyond the batch's last sweep, which nobody reads; the partial buffer holds kLexBatchSweeps whole groups.)
         const int groups = (left + 7) / 8;
-        return lex_launch_skew<8>(g, groups, mask, nullptr, left - 8 * (groups - 1));
+        return lex_launch_skew<8>(g, groups, mask, partial, left - 8 * (groups - 1));
     }
     for (int T = 8; T >= 1; T >>= 1) {
         if (T > g->lex_tmax || left < T) continue;

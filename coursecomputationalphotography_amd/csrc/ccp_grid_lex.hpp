@@ -917,7 +917,7 @@ __device__ __forceinline__ void lex_wg_body()
             gh.write(brow, db0, lane);
         }
         lex_lds_barrier();                                                   // (the priming barrier)
-        if (!CHECK && grp == G - 1 && t >= ap->t_last) lex_wg_pass_through<T>(ring, brow, t, lane, db0, db1, gh);
+        if (grp == G - 1 && t >= ap->t_last) lex_wg_pass_through<T>(ring, brow, t, lane, db0, db1, gh);   // (checked kernels: its step sum stays 0, a sweep nobody looks at)
         else if (MASKED) lex_wg_compute_masked<T, CHECK>(h1, acc, ring, brow, t, lane, db0, db1, gh);
         else if (strip_interior) lex_wg_compute<T, CHECK, 0>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b, gh);
         else if (has_x0 && !has_xl) lex_wg_compute<T, CHECK, 1>(h1, acc, ring, brow, g, lg.W, lg.H, t, lane, db0, db1, xs0, lane_on, st_b, gh);
