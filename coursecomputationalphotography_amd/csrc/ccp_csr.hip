@@ -144,7 +144,7 @@ struct ccp_csr {
     DevBuf<double> x, b, tmp, partial;
     DevBuf<double> pipe_partial, pipe_eps, pipe_snap;   // pipelined level schedule: step sums per sweep, snapshot
     bool allow_pipeline = true;            // CCP_GS_PIPELINE=0: one launch per level and sweep
-    DevBuf<double> cg_p, cg_ap;            // conjugate-gradient work vectors (allocated on first use)
+    DevBuf<double> cg_p, cg_p2, cg_ap;     // conjugate-gradient work vectors (allocated on first use; cg_p2: the fused loop's second direction buffer)
     DevBuf<double> cg_inv, cg_partial2;    // Jacobi-preconditioned variant: 1/a_ii, second pair of partial-sum regions
     DevBuf<CgState> cg_state;
     DevBuf<CsrSolveState> state;
@@ -2808,7 +2808,7 @@ try {
         CCP_TRY(m->cg_ap.alloc((size_t)std::max<long>(n, 2)));
         CCP_TRY(m->cg_state.alloc(1));
     }
-    const unsigned spmv_blocks = (unsigned)((m->natural.n_slices + kBlock / kWave - 1) / (kBlock / kWave));
+    const unsigned spmv_blocks = (unsigned)std::min<long>(2048, (m->natural.n_slices + kBlock / kWave - 1) / (kBlock / kWave));   // (k_sell_apply strides)
     CCP_TRY(ensure_partial(m, std::max<long>(2048, spmv_blocks)));
     if (rowblock) {
         // b, init, x_out: the block's own rows.  The loop runs on the extended system: a ghost is an empty row, so its
@@ -2856,8 +2856,25 @@ try {
         CCP_HIP(hipStreamSynchronize(s));
         return CCP_OK;
     }
-    CCP_TRY(cg_solve(spmv, spmv_dot, m->b.p, m->x.p, m->tmp.p, m->cg_p.p, m->cg_ap.p, n, epsilon, max_iteration, m->cg_state.p,
-                     m->partial.p, s, m->ev0, m->ev1, report));
+    // One GPU: the fused loop (ccp_cg.hpp: 12 nnz + 72 B per row and iteration instead of 12 nnz + 88; the same iterates
+    // bit for bit).  CCP_GS_CG_FUSED=0: the three-pass loop (the tests run both).  A row block keeps the three-pass loop:
+    // the fused pass would need the ghost rows' r as well as their p before every product (two exchanges, not one).
+    const bool fused = !(getenv("CCP_GS_CG_FUSED") && atoi(getenv("CCP_GS_CG_FUSED")) == 0);
+    if (fused && n_slices > 0) {
+        if (m->cg_p2.n < (size_t)std::max<long>(n, 2)) CCP_TRY(m->cg_p2.alloc((size_t)std::max<long>(n, 2)));
+        CCP_HIP(hipMemsetAsync(m->cg_p2.p, 0, sizeof(double) * (size_t)std::max<long>(n, 2), s));
+        auto apply = [&](double *xv, const double *rv, const double *p_in, double *p_out, double *apv, int *n_partials) -> int {
+            hipLaunchKernelGGL(k_sell_cg_apply, dim3(spmv_blocks), dim3(kBlock), 0, s, view, n_slices, xv, rv, p_in, p_out, apv, m->partial.p,
+                               m->cg_state.p);
+            *n_partials = (int)spmv_blocks;
+            return hipGetLastError() == hipSuccess ? CCP_OK : CCP_ERR_HIP;
+        };
+        CCP_TRY(cg_solve_fused(spmv, apply, m->b.p, m->x.p, m->tmp.p, m->cg_p.p, m->cg_p2.p, m->cg_ap.p, n, epsilon, max_iteration,
+                               m->cg_state.p, m->partial.p, s, m->ev0, m->ev1, report));
+    } else {
+        CCP_TRY(cg_solve(spmv, spmv_dot, m->b.p, m->x.p, m->tmp.p, m->cg_p.p, m->cg_ap.p, n, epsilon, max_iteration, m->cg_state.p,
+                         m->partial.p, s, m->ev0, m->ev1, report));
+    }
     if (n) CCP_HIP(hipMemcpyAsync(x_out, m->x.p, sizeof(double) * n, hipMemcpyDeviceToHost, s));
     CCP_HIP(hipStreamSynchronize(s));
     return CCP_OK;
@@ -2881,7 +2898,7 @@ try {
         CCP_TRY(m->cg_state.alloc(1));
     }
     if (!m->cg_state.p) CCP_TRY(m->cg_state.alloc(1));
-    const unsigned spmv_blocks = (unsigned)((m->natural.n_slices + kBlock / kWave - 1) / (kBlock / kWave));
+    const unsigned spmv_blocks = (unsigned)std::min<long>(2048, (m->natural.n_slices + kBlock / kWave - 1) / (kBlock / kWave));   // (k_sell_apply strides)
     CCP_TRY(ensure_partial(m, std::max<long>(2048, spmv_blocks)));
     if (m->cg_partial2.n != 4096) CCP_TRY(m->cg_partial2.alloc(4096));
     // extractDiagnolColInv (sparse-matrix.h:472-491): 1/a_ii of the first stored diagonal entry, 1 if absent or 0

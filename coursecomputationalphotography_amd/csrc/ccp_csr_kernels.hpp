@@ -12,6 +12,7 @@
 #pragma once
 
 #include "ccp_common.hpp"
+#include "ccp_cg.hpp"          // CgState (k_sell_cg_apply)
 
 namespace ccp {
 
@@ -182,9 +183,12 @@ k_sell_apply(SellView m, int n_slices, const double *__restrict__ in, double *__
 {
     __shared__ double scratch[kBlock / kWave];
     const int lane = threadIdx.x & (kWave - 1);
-    const int s = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave;
     double rr = 0.0, bb = 0.0;
-    if (s < n_slices && lane < m.slice_rows[s]) {
+    // a wave takes slices blockIdx.x * 4 + wave, + gridDim.x * 4, ...: a launch with fewer blocks than slices / 4 leaves
+    // fewer partial sums to add up (the conjugate-gradient loops: 2,048 instead of one per 256 rows — the one-block sum
+    // of 40,000 partials was 54 us of a 390 us iteration at 10 M rows); one with a block per 4 slices is the plain form
+    for (int s = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; s < n_slices; s += gridDim.x * (kBlock / kWave)) {
+        if (lane >= m.slice_rows[s]) continue;
         const int row = m.slice_row0[s] + lane;
         const long off = m.slice_off[s] + lane;
         const int width = m.slice_width[s];
@@ -198,12 +202,12 @@ k_sell_apply(SellView m, int n_slices, const double *__restrict__ in, double *__
             out[row] = sum;
         } else if (MODE == 2) {
             out[row] = sum;
-            rr = in[row] * sum;
+            rr += in[row] * sum;
         } else {
             const double bv = b[row];
             const double r = bv - sum;
-            rr = r * r;
-            bb = bv * bv;
+            rr += r * r;
+            bb += bv * bv;
         }
     }
     if (MODE == 1) {
@@ -218,6 +222,45 @@ k_sell_apply(SellView m, int n_slices, const double *__restrict__ in, double *__
         const double t0 = block_sum(rr, scratch);
         if (threadIdx.x == 0) partial[blockIdx.x] = t0;
     }
+}
+
+// Pass A of the fused conjugate-gradient iteration (ccp_cg.hpp, cg_solve_fused) on the stored matrix: for row i
+//   x_i += alpha p_old_i;   p_new_j = r_j + beta p_old_j for j = i and for every column j of the row (recomputed where it
+//   is used: a direction is one multiply-add of two values the gather brings anyway);   Ap_i = sum a_ij p_new_j in
+//   storage order (applyToVector, sparse-matrix.h:382-393);   one partial sum of p_new'Ap per block
+// — the operations of k_cg_direction, k_sell_apply<2> and the x half of k_cg_update on the same operands in the same
+// order, block for block: the iterates are the three-pass loop's bit for bit.  Per row and iteration 12 nnz + 72 B
+// instead of 12 nnz + 88 (p is no longer written and read back between the passes).  p is double-buffered: a row's
+// neighbours still read p_old while it stores its p_new.
+__global__ void __launch_bounds__(kBlock)
+k_sell_cg_apply(SellView m, int n_slices, double *__restrict__ x, const double *__restrict__ r, const double *__restrict__ p_old,
+                double *__restrict__ p_new, double *__restrict__ ap, double *__restrict__ partial, const CgState *__restrict__ st)
+{
+    __shared__ double scratch[kBlock / kWave];
+    const int lane = threadIdx.x & (kWave - 1);
+    double dot = 0.0;
+    const bool active = st->active != 0;
+    const double alpha = st->alpha, beta = st->beta;
+    for (int s = blockIdx.x * (kBlock / kWave) + threadIdx.x / kWave; active && s < n_slices; s += gridDim.x * (kBlock / kWave)) {   // (as k_sell_apply)
+        if (lane >= m.slice_rows[s]) continue;
+        const int row = m.slice_row0[s] + lane;
+        const long off = m.slice_off[s] + lane;
+        const int width = m.slice_width[s];
+        double sum = 0.0;
+        for (int k = 0; k < width; ++k) {
+            const int c = m.cols[off + (long)k * kWave];
+            const double v = m.vals[off + (long)k * kWave];
+            if (c >= 0) sum += v * (r[c] + beta * p_old[c]);
+        }
+        const double po = p_old[row];
+        const double pn = r[row] + beta * po;
+        x[row] = x[row] + alpha * po;
+        p_new[row] = pn;
+        ap[row] = sum;
+        dot += pn * sum;
+    }
+    const double t0 = block_sum(dot, scratch);
+    if (threadIdx.x == 0) partial[blockIdx.x] = t0;
 }
 
 // dst[i] = src[perm[i]] (gather into schedule order) / dst[perm[i]] = src[i] (scatter back).

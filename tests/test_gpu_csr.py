@@ -174,6 +174,49 @@ def test_conjugate_gradient_vs_oracle(capi, orc, golden, name):
     m.close()
 
 
+def test_stored_matrix_cg_fused_loop_equals_three_pass(capi, orc, monkeypatch):
+    """conjugateGradient on the STORED matrix (sliced ELL; recognition switched off): the fused loop (default: x's update
+    folded into the next pass over p, k_sell_cg_apply, 12 nnz + 72 B per row) gives the three-pass loop's iterates
+    (CCP_GS_CG_FUSED=0) bit for bit — every count, with and without an initial guess, and the same stop iteration — on
+    the Poisson matrix, on the Laplacian of an irregular region and on a matrix with rows of very different lengths;
+    both agree with the oracle to rounding."""
+    import scipy.sparse as sp
+    from coursecomputationalphotography_amd import synth
+    monkeypatch.setenv("CCP_GS_STRUCTURED", "0")
+    monkeypatch.setenv("CCP_GS_MASKED", "0")
+    systems = [synth.poisson_csr(61, 47)]
+    mask = synth.disc_mask(96, 96, seed=9)
+    systems.append(synth.masked_laplacian_csr(mask)[:3])
+    rng = np.random.default_rng(5)
+    n = 3000
+    a = sp.random(n, n, density=0.002, random_state=7, format="csr")
+    a = a + a.T
+    a = (a + sp.diags(np.asarray(abs(a).sum(axis=1)).ravel() + 1.0)).tocsr()          # symmetric, strictly diagonally dominant
+    a.sort_indices()
+    systems.append((a.data.astype(np.float64), a.indices.astype(np.int32), a.indptr.astype(np.int32)))
+    for v, c, r in systems:
+        nrows = len(r) - 1
+        x0 = rng.standard_normal(nrows)
+        om = orc.from_csr(v, c, r)
+        m = capi.CsrMatrix().upload_compressed(v, c, r)
+        b = m.apply_to_vector(rng.standard_normal(nrows))       # (consistent: the Poisson matrix has an empty row)
+        for k in (1, 2, 7, 40):
+            for ini in (None, x0):
+                monkeypatch.setenv("CCP_GS_CG_FUSED", "0")
+                xa, ra = m.conjugate_gradient(b, 1e-30, k, ini)
+                monkeypatch.delenv("CCP_GS_CG_FUSED")
+                xb, rb = m.conjugate_gradient(b, 1e-30, k, ini)
+                assert ra.iterations == rb.iterations == k and np.array_equal(xa, xb), (nrows, k, ini is not None)
+                want, _ = om.conjugate_gradient(b, 1e-30, k, ini)
+                assert rel_l2(xb, want) <= 1e-9
+        monkeypatch.setenv("CCP_GS_CG_FUSED", "0")
+        xa, ra = m.conjugate_gradient(b, 1e-9, 4000)
+        monkeypatch.delenv("CCP_GS_CG_FUSED")
+        xb, rb = m.conjugate_gradient(b, 1e-9, 4000)
+        assert ra.converged == rb.converged == 1 and ra.iterations == rb.iterations and np.array_equal(xa, xb)
+        m.close()
+
+
 def test_known_answer_cg(capi, orc, golden):
     d = golden("known_answer_4x4.npz")
     _, vals, cols, rb, nnz = dense_to_vector_arrays(orc, d["A"])
