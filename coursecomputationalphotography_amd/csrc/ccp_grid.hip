@@ -1688,9 +1688,10 @@ try {
     CCP_TRY(begin_timing(g));
     dim3 cgrid((unsigned)((W + kBlock - 1) / kBlock), (unsigned)H, (unsigned)C);
     dim3 tgrid((unsigned)((W + kLexCT - 1) / kLexCT), (unsigned)((H + kLexCT - 1) / kLexCT), (unsigned)C);
-    hipLaunchKernelGGL((k_lex_convert_tiled<true>), tgrid, dim3(kBlock), 0, g->stream, g->x.p, lex_xd(g), g->geom, lg);
+    dim3 sgrid((unsigned)((W + kLexCT - 1) / kLexCT), (unsigned)((lg.n_diag + kLexCT - 1) / kLexCT), (unsigned)C);
+    hipLaunchKernelGGL(k_lex_to_diag_sheared, sgrid, dim3(kBlock), 0, g->stream, g->x.p, lex_xd(g), g->geom, lg);
     if (g->masked) hipLaunchKernelGGL(k_lex_convert_b_masked, cgrid, dim3(kBlock), 0, g->stream, g->b.p, g->maskp.p, lex_bd(g), g->geom, lg);
-    else hipLaunchKernelGGL((k_lex_convert_tiled<true>), tgrid, dim3(kBlock), 0, g->stream, g->b.p, lex_bd(g), g->geom, lg);
+    else hipLaunchKernelGGL(k_lex_to_diag_sheared, sgrid, dim3(kBlock), 0, g->stream, g->b.p, lex_bd(g), g->geom, lg);
     CCP_HIP(hipGetLastError());
 
     const unsigned all = (C >= 32) ? 0xffffffffu : ((1u << C) - 1u);

@@ -54,31 +54,103 @@ k_lex_convert_tiled(double *__restrict__ split, double *__restrict__ diag, Geom 
     constexpr int kWaves = kBlock / kWave;
     double *__restrict__ sp = split + (long)ch * g.ch_stride;
     double *__restrict__ dg = diag + (long)ch * lg.plane;
-    auto rows = [&](bool to_tile) {
-        for (int r = wave; r < kLexCT; r += kWaves) {
-            const int x = x0 + lane, y = y0 + r;
-            if (x < lg.W && y < lg.H) {
-                const long s = row_off(g, y, (x + y) & 1) + (x >> 1);
-                if (to_tile) tile[r][lane] = sp[s];
-                else sp[s] = tile[r][lane];
-            }
-        }
+    // Both phases are written as batches: every load of a wave goes out before the first value is used (a rolled
+    // "load, wait, write to LDS" loop had ONE load in flight per wave: 1.1 ms per array at 16384^2 — ISA, round 4).
+    // A pixel off the image clamps to the tile's first one: loaded, never stored.
+    constexpr int kPer = kLexCT / kWaves;                    // image rows (anti-diagonal pairs) per wave
+    auto split_at = [&](int r, bool &on) {
+        const int x = x0 + lane, y = y0 + r;
+        on = x < lg.W && y < lg.H;
+        const int xc = on ? x : x0, yc = on ? y : y0;
+        return row_off(g, yc, (xc + yc) & 1) + (xc >> 1);
     };
     // (the tile's anti-diagonal k holds columns 0 .. k, its anti-diagonal k + 64 columns k+1 .. 63: one wave moves both —
     // 64 full instructions a tile instead of 127 that are half empty on average)
-    auto diagonals = [&](bool to_tile) {
-        for (int k = wave; k < kLexCT; k += kWaves) {
-            const int xx = lane, kk = xx <= k ? k : k + kLexCT, yy = kk - xx;
-            if (x0 + xx < lg.W && y0 + yy < lg.H) {
-                const long d = (long)(x0 + y0 + kk) * lg.P + (x0 + xx);
-                if (to_tile) tile[yy][xx] = dg[d];
-                else dg[d] = tile[yy][xx];
-            }
-        }
+    auto diag_at = [&](int k, int &yy, bool &on) {
+        const int xx = lane, kk = xx <= k ? k : k + kLexCT;
+        yy = kk - xx;
+        on = x0 + xx < lg.W && y0 + yy < lg.H;
+        return on ? (long)(x0 + y0 + kk) * lg.P + (x0 + xx) : (long)(x0 + y0) * lg.P + x0;
     };
-    if (TO_DIAG) rows(true); else diagonals(true);
+    double v[kPer];
+    if (TO_DIAG) {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            bool on;
+            v[i] = sp[split_at(wave + i * kWaves, on)];
+        }
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) tile[wave + i * kWaves][lane] = v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            int yy;
+            bool on;
+            v[i] = dg[diag_at(wave + i * kWaves, yy, on)];
+        }
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            int yy;
+            bool on;
+            (void)diag_at(wave + i * kWaves, yy, on);
+            tile[yy][lane] = v[i];                           // (a pixel off the image: a slot nobody reads)
+        }
+    }
     __syncthreads();
-    if (TO_DIAG) diagonals(false); else rows(false);
+    if (TO_DIAG) {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            int yy;
+            bool on;
+            const long d = diag_at(wave + i * kWaves, yy, on);
+            if (on) dg[d] = tile[yy][lane];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+            bool on;
+            const long at = split_at(wave + i * kWaves, on);
+            if (on) sp[at] = tile[wave + i * kWaves][lane];
+        }
+    }
+}
+
+// split colour planes -> diagonal-major with the tile cut the other way: 64 columns x 64 DIAGONALS (a sheared piece of the
+// image, 127 image rows high), so that the WRITE side moves whole 512-byte runs of a diagonal row and the partial runs —
+// pieces of image rows — are on the read side, where the neighbouring tile's re-read of a line comes from L2.  (With the
+// square tile above the forward conversion wrote two partial runs per instruction: 1.07 ms per array at 16384^2 against
+// 0.80 ms for the backward one, which reads them — kernel stats, round 4.)  Image row yb + j of the tile holds its columns
+// 63-j .. 63 (j <= 63), row yb + j + 64 columns 0 .. 62-j: one wave instruction moves both.
+// grid = (ceil(W/64), ceil((W+H-1)/64), channels), block = 256; tiles that miss the image leave at once.
+__global__ void __launch_bounds__(kBlock)
+k_lex_to_diag_sheared(const double *__restrict__ split, double *__restrict__ diag, Geom g, LexGeom lg)
+{
+    __shared__ double tile[kLexCT][kLexCT + 2];              // [diagonal][column]
+    const int x0 = blockIdx.x * kLexCT, d0 = blockIdx.y * kLexCT, ch = blockIdx.z;
+    const int yb = d0 - x0 - (kLexCT - 1);                   // the tile's first image row
+    if (yb + 2 * kLexCT - 2 < 0 || yb > lg.H - 1) return;    // (uniform)
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    constexpr int kWaves = kBlock / kWave, kPer = kLexCT / kWaves;
+    const double *__restrict__ sp = split + (long)ch * g.ch_stride;
+    double *__restrict__ dg = diag + (long)ch * lg.plane;
+    const int x = x0 + lane;
+    auto row_of = [&](int k) { return lane >= kLexCT - 1 - k ? k : k + kLexCT; };
+    double v[kPer];
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int y = yb + row_of(wave + i * kWaves);
+        const bool on = x < lg.W && y >= 0 && y < lg.H;
+        const int xc = on ? x : x0, yc = on ? y : max(yb, 0) < lg.H ? max(yb, 0) : 0;
+        v[i] = sp[row_off(g, yc, (xc + yc) & 1) + (xc >> 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) tile[row_of(wave + i * kWaves) - (kLexCT - 1) + lane][lane] = v[i];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < kPer; ++i) {
+        const int dd = wave + i * kWaves, d = d0 + dd, y = d - x;
+        if (x < lg.W && y >= 0 && y < lg.H) dg[(long)d * lg.P + x] = tile[dd][lane];
+    }
 }
 
 // Dirichlet-mask grids (k_lex_wg<.., MASKED>): b in diagonal-major layout with a marker — a signalling NaN no
