@@ -1477,11 +1477,11 @@ namespace {
 // starts left of the image lies up to 64 diagonals before the first one; never used)
 double *lex_xd(const ccp_grid *g) { return g->lex_x.p + (size_t)kLexFrontRows * g->lexg.P; }
 double *lex_bd(const ccp_grid *g) { return g->lex_b.p + (size_t)kLexFrontRows * g->lexg.P; }
-constexpr int kLexBatchSweeps = 128;     // sweeps in flight between two looks at the stop rule
+constexpr int kLexBatchSweeps = 128;     // sweeps in flight between two looks at the stop rule: the first batch (later ones grow while the rule is far off)
 constexpr int kLexLaunchSweeps = 1024;   // most sweeps one launch of k_lex_wg carries (its strips move 2 columns left per sweep: lex_strip_count)
 long lex_partials_per_sweep(const ccp_grid *g)
 {
-    if (g->lex_mode == 3) return (long)lex_strip_count(g->desc.width, 1, kLexBatchSweeps);   // (T groups of a checked batch shift by 2 x its sweeps at most)
+    if (g->lex_mode == 3) return (long)lex_strip_count(g->desc.width, 1, kLexLaunchSweeps);   // (the groups of a checked batch shift by 2 x its sweeps at most)
     return (long)g->lexg.n_diag * g->lexg.nbx;
 }
 
@@ -1617,7 +1617,7 @@ int lex_run_skew(ccp_grid *g, int iterations, unsigned mask, double *partial)
         // a count that is not a multiple of 8: ONE launch of depth-8 groups whose last group passes the sweeps it does
         // not have through (lex_wg_pass_through) instead of remainder launches of depth 4, 2, 1, each a pipeline of its
         // own to fill and drain.  (With the stop rule too: the passed-through sweeps leave step sums of 0 in slots
-        // beyond the batch's last sweep, which nobody reads; the partial buffer holds kLexBatchSweeps whole groups.)
+        // beyond the batch's last sweep, which nobody reads; the partial buffer holds whole groups.)
         const int groups = (left + 7) / 8;
         return lex_launch_skew<8>(g, groups, mask, partial, left - 8 * (groups - 1));
     }
@@ -1712,24 +1712,44 @@ try {
         }
         for (int ch = 0; ch < C; ++ch) iterations_of[ch] = n;
     } else {
-        const int batch_max = kLexBatchSweeps;                           // sweeps in flight between two looks at the rule
+        // Sweeps in flight between two looks at the rule: kLexBatchSweeps to begin with, doubled (up to one launch's worth)
+        // while every channel's step, at the rate it has been shrinking, is more than four batches away from epsilon.  A
+        // batch is one pipeline to fill and drain and one snapshot; a channel that stops inside a batch is redone from the
+        // snapshot for exactly the sweeps the reference would have made — the result does not depend on the batching.  (The
+        // reference's defaults, epsilon 1e-6 and 1,000 sweeps, never stop early on an image-sized system: 8 batches of 128
+        // were 7.0 ms at 512^2 where one pipeline of 1,000 sweeps is 2.5 ms.)
+        const int batch_cap = g->lex_mode == 3 ? kLexLaunchSweeps : kLexBatchSweeps;
+        int batch = kLexBatchSweeps;
         const long per = lex_partials_per_sweep(g);                         // partials per (iteration, channel)
-        if (g->lex_partial.n != (size_t)per * batch_max * C) CCP_TRY(g->lex_partial.alloc((size_t)per * batch_max * C));
-        if (g->lex_eps.n != (size_t)batch_max * C) CCP_TRY(g->lex_eps.alloc((size_t)batch_max * C));
+        if (g->lex_partial.n != (size_t)per * batch_cap * C) CCP_TRY(g->lex_partial.alloc((size_t)per * batch_cap * C));
+        if (g->lex_eps.n != (size_t)batch_cap * C) CCP_TRY(g->lex_eps.alloc((size_t)batch_cap * C));
         if (g->lex_snap.n != elems) CCP_TRY(g->lex_snap.alloc(elems));
-        std::vector<double> eps_host((size_t)batch_max * C);
+        std::vector<double> eps_vec((size_t)batch_cap * C);
+        double *eps_host = eps_vec.data();
         unsigned mask = all;
         int done = 0;
         while (mask && done < max_iteration) {
-            const int kb = std::min(batch_max, max_iteration - done);
+            const int kb = std::min(batch, max_iteration - done);
             CCP_HIP(hipMemcpyAsync(g->lex_snap.p, lex_xd(g), elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
             if (g->lex_mode == 3) CCP_HIP(hipMemsetAsync(g->lex_partial.p, 0, sizeof(double) * (size_t)per * kb * C, g->stream));
             CCP_TRY(lex_run(g, kb, mask, g->lex_partial.p));
             hipLaunchKernelGGL(k_lex_reduce, dim3((unsigned)kb, (unsigned)C), dim3(kBlock), 0, g->stream, g->lex_partial.p, per,
                                g->lex_eps.p);
             CCP_HIP(hipGetLastError());
-            CCP_HIP(hipMemcpyAsync(eps_host.data(), g->lex_eps.p, sizeof(double) * kb * C, hipMemcpyDeviceToHost, g->stream));
+            CCP_HIP(hipMemcpyAsync(eps_host, g->lex_eps.p, sizeof(double) * kb * C, hipMemcpyDeviceToHost, g->stream));
             CCP_HIP(hipStreamSynchronize(g->stream));
+            // how far the rule is, in sweeps, for the channel nearest to it (the step of the batch's last sweep against
+            // the one half a batch earlier)
+            double nearest = 1e300;
+            for (int ch = 0; ch < C && kb >= 2; ++ch) {
+                if (!((mask >> ch) & 1u)) continue;
+                const double e1 = eps_host[(size_t)(kb - 1) * C + ch], e0 = eps_host[(size_t)(kb / 2 - 1) * C + ch];
+                double left = 1e300;
+                if (!(e1 > epsilon)) left = 0.0;
+                else if (e1 < e0 && epsilon > 0.0) left = std::log(epsilon / e1) / (std::log(e1 / e0) / (double)(kb - kb / 2));
+                nearest = std::min(nearest, left);
+            }
+            if (nearest > 4.0 * batch) batch = std::min(batch * 2, batch_cap);
             for (int ch = 0; ch < C; ++ch) {
                 if (!((mask >> ch) & 1u)) continue;
                 int stop = -1;
