@@ -1371,8 +1371,12 @@ try {
             const int T = std::min(g->masked ? kMaskedMaxCheckedT : kFusedMaxCheckedT, max_iteration - k0);
             long blocks[2] = {0, 0};
             CCP_TRY(launch_fused(g, T, cur, alt, active, 2, blocks));
-            hipLaunchKernelGGL(k_check_multi, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
-                               g->partial.p + g->partial_region, blocks[1], T, k0 + 1, check_every, epsilon, g->state.p);
+            // the step of each sweep (a block per channel and sweep), then the rule on them in sweep order
+            if (!g->sweep_sums.p) CCP_TRY(g->sweep_sums.alloc((size_t)kFusedMaxCheckedT * kMaxChannels));
+            hipLaunchKernelGGL(k_sweep_sums_wide, dim3((unsigned)C, (unsigned)T), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
+                               g->partial.p + g->partial_region, blocks[1], g->sweep_sums.p);
+            hipLaunchKernelGGL(k_decide_sums, dim3(1), dim3(kMaxChannels), 0, g->stream, g->sweep_sums.p, C, T, k0 + 1, check_every, epsilon,
+                               g->state.p);
             CCP_HIP(hipGetLastError());
             CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));
             CCP_HIP(hipStreamSynchronize(g->stream));

@@ -396,9 +396,16 @@ __device__ __forceinline__ void fused_step(double (&wr)[NT], double (&wk)[NT], d
             }
         }
         if ((L1 == 1 && h >= HS - 1) || L1 == 2) {
-            const bool counted = cx.col_store && r >= cx.ra && r < cx.rb && r >= g.own_lo && r < g.own_hi &&
-                                 (MODE == kStepFast || cx.px_ok[p]);
-            if (counted) acc[L1 == 2 ? (h - 1) / 2 : 0] += fabs(nv - old);
+            // Every lane adds its step on the rows that count; the lanes whose columns another strip stores are dropped
+            // ONCE, at the end of fused_wave, instead of inside the test of every update (the checked pass is bound by
+            // vector issue: 4 instructions per update for the step on top of 7, 2.0 ms a pass against 1.4 without them —
+            // ISA and an experiment build, round 4).  A pixel that does not exist keeps its value (nv = old) and adds an
+            // exact 0.  The sums are the same sums, lane for lane.
+            // (The row test is wave-uniform, yet the compiler makes two selects per update of it.  Tried: a forced scalar
+            // branch — slower, 1.06 against 1.10e12 at 16384^2; bodies specialised for "every row of the trip counts",
+            // side by side in one loop or as three loops — the depth-8 kernel went from 210 VGPRs to 256 with 18-43 spills.)
+            const bool rows_count = r >= cx.ra && r < cx.rb && r >= g.own_lo && r < g.own_hi;
+            if (rows_count) acc[L1 == 2 ? (h - 1) / 2 : 0] += fabs(nv - old);
         }
         if (c) wk[sr] = nv; else wr[sr] = nv;
     }
@@ -578,6 +585,10 @@ __device__ __forceinline__ void fused_wave(const double *__restrict__ xin, doubl
                 qk[s0] = landm[i][1] ? kQuarterHi : 0;
             }
         }
+    }
+    if (L1 != 0) {                                       // (fused_step: the lanes of columns another strip stores do not count)
+#pragma unroll
+        for (int t = 0; t < AN; ++t) acc[t] = cx.col_store ? acc[t] : 0.0;
     }
 }
 
