@@ -80,6 +80,38 @@ def run(n, seed):
         if not np.array_equal(got, want):
             bad += 1
             print("MISMATCH reference order", W, H, iters, float(np.abs(got - want).max()), flush=True)
+    # reference order, MANY groups of sweeps: strips that move left from group to group, edge buffers that are used
+    # again two groups later, counts that are not multiples of 8, batches of the stop rule that grow (round 4)
+    for t in range(max(4, n // 5)):
+        W, H = int(rng.integers(1, 1500)), int(rng.integers(1, 400))
+        iters = int(rng.integers(13, 260))
+        if W * H < 2:
+            continue
+        iters = max(13, min(iters, int(4e7 // (W * H)) + 13))
+        b, _ = synth.poisson_system(W, H, int(rng.integers(1, 1000)))
+        om = orc.from_csr(*synth.poisson_csr(W, H))
+        want, _, _ = om.gauss_seidel(b, 0.0, iters)
+        g = capi.Grid(W, H, 1)
+        g.set_b(b)
+        g.fill_x(1.0)
+        g.gauss_seidel_lexicographic(0.0, iters, 0)
+        got = g.get_x().ravel().copy()
+        # ... and with the rule after every sweep, stopping at a sweep of the oracle's choosing
+        stop = int(rng.integers(1, iters + 1))
+        bs = b * 1e-6
+        _, _, eps_k = om.gauss_seidel(bs, 0.0, stop)
+        want_s, it_s, _ = om.gauss_seidel(bs, eps_k * (1.0 + 1e-9), iters)
+        g.set_b(bs)
+        g.fill_x(1.0)
+        rep = g.gauss_seidel_lexicographic(eps_k * (1.0 + 1e-9), iters, 1)[0]
+        got_s = g.get_x().ravel()
+        g.close()
+        if not np.array_equal(got, want):
+            bad += 1
+            print("MISMATCH reference order, many groups", W, H, iters, float(np.abs(got - want).max()), flush=True)
+        if rep.iterations != it_s or not np.array_equal(got_s, want_s):
+            bad += 1
+            print("MISMATCH reference order, stop rule", W, H, iters, stop, rep.iterations, it_s, flush=True)
     nontrivial = 0
     # the stop rule: fused passes against the in-place kernels (same stop sweep, same x), random check periods
     for t in range(max(6, n // 4)):
