@@ -76,6 +76,9 @@ def summarise(head, words, bins=24):
         busy.append(sum(r[1] - r[0] for r in v) / 100.0 / span / 8.0)  # fraction of the CU's 8 wave slots (2 per SIMD) over the span
     busy.sort()
     out["cu_slot_utilisation_min_med_max"] = [round(busy[0], 3), round(busy[len(busy) // 2], 3), round(busy[-1], 3)]
+    # the waves that end last: (kind, chunk, strip, start us, duration us)
+    out["last_waves"] = [[kinds.get(r[4], r[4]), r[5], r[6], round((r[0] - t_min) / 100.0, 1), round((r[1] - r[0]) / 100.0, 1)]
+                         for r in sorted(recs, key=lambda r: -r[1])[:8]]
     ends = sorted((r[1] - t_min) / 100.0 for r in recs)
     out["end_percentiles_us"] = {p: ends[min(len(ends) - 1, int(len(ends) * p / 100))] for p in (50, 75, 90, 95, 99, 100)}
     return out
