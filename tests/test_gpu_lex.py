@@ -74,6 +74,25 @@ def test_heads_and_tails_of_strips(capi, orc):
             assert abs(reps[0].last_l1_step - eps_want) <= 1e-12 * max(eps_want, 1e-300), (W, H)
 
 
+@pytest.mark.parametrize("W,H,sweeps", [(1300, 40, 260), (700, 90, 150), (130, 300, 100), (63, 500, 77)])
+def test_many_groups_of_sweeps_in_one_pipeline(capi, orc, W, H, sweeps):
+    """Dozens of groups of 8 sweeps in one launch: the strips of every group lie 16 columns left of the group before
+    (strips leave the image on the left and enter it on the right as the groups go by), the edge values of a strip are
+    written to the buffer its group shared with the group two before, and a count that is not a multiple of 8 ends in a
+    group that passes sweeps through — fixed count and the rule after every sweep, bit for bit."""
+    from coursecomputationalphotography_amd import synth
+    b, _ = synth.poisson_system(W, H, W + H)
+    m = orc.from_csr(*synth.poisson_csr(W, H))
+    want, _, _ = m.gauss_seidel(b, 0.0, sweeps)
+    x, reps = run_lex(capi, W, H, b, 0.0, sweeps, 0)
+    assert reps[0].iterations == sweeps and np.array_equal(x[0], want), (W, H, sweeps)
+    bs = b * 1e-6
+    want, it_want, eps_want = m.gauss_seidel(bs, 0.0, sweeps)
+    x, reps = run_lex(capi, W, H, bs, 0.0, sweeps, 1)
+    assert reps[0].iterations == it_want == sweeps and np.array_equal(x[0], want), (W, H, sweeps, "checked")
+    assert abs(reps[0].last_l1_step - eps_want) <= 1e-12 * eps_want
+
+
 def test_rows_divided_by_three_survive_infinities(capi, orc):
     """Row 0 and column 0 divide by 3 through lex_div3, which hands infinities and NaNs to the true division: same values
     as the oracle (NaN where it has NaN), in the strips' heads as in their inner blocks."""
