@@ -1018,7 +1018,8 @@ __device__ __forceinline__ void lex_wg_body()
 // 3, 3, 2, 2): at most 80 VGPRs — the loader, which decides the count, needs 82, and is held to 80 (2 spills) where
 // sharing pays: +5..11 % on plain grids from 4096^2 up.  (Above ~53 KB of LDS per workgroup the second one is not
 // placed at all — traced block start times — whatever the occupancy query says; the rings take 42 KB.)  The
-// Dirichlet-mask variant carries three more values in the loader and loses more to the spills than it gains.
+// Dirichlet-mask variant carried three more values in its loader and was built for 5 waves per SIMD (one workgroup per
+// CU) until the loader's b rows travelled as pairs (round 4): it fits the 80 now, without spills.
 template <int T, bool CHECK>
 __global__ void __launch_bounds__((T + 2) * kWave) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_lex_wg(LexWgArgs)
@@ -1027,7 +1028,7 @@ k_lex_wg(LexWgArgs)
 }
 
 template <int T, bool CHECK>
-__global__ void __launch_bounds__((T + 2) * kWave) __attribute__((amdgpu_waves_per_eu(5, 8)))
+__global__ void __launch_bounds__((T + 2) * kWave) __attribute__((amdgpu_waves_per_eu(6, 8)))
 k_lex_wg_masked(LexWgArgs)
 {
     lex_wg_body<T, CHECK, true>();
