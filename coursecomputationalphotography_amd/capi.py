@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "ccp_grid_create", "ccp_grid_destroy", "ccp_grid_get_layout", "ccp_grid_set_stream",
     "ccp_grid_synchronize", "ccp_grid_set_b_host", "ccp_grid_set_x_host", "ccp_grid_get_x_host",
     "ccp_grid_get_b_host", "ccp_grid_set_mask_host", "ccp_grid_fill_x", "ccp_grid_b_from_x", "ccp_grid_randomize_x",
-    "ccp_grid_sweep", "ccp_grid_sweep_edges_first", "ccp_grid_stream_wait_edges", "ccp_grid_tune", "ccp_grid_set_fused", "ccp_grid_set_tiling", "ccp_grid_get_tiling", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_gauss_seidel_lexicographic", "ccp_grid_conjugate_gradient",
+    "ccp_grid_sweep", "ccp_grid_sweep_edges_first", "ccp_grid_stream_wait_edges", "ccp_grid_tune", "ccp_grid_set_fused", "ccp_grid_set_tiling", "ccp_grid_get_tiling", "ccp_grid_sweep_l1", "ccp_grid_halo_refreshed", "ccp_grid_gauss_seidel", "ccp_grid_gauss_seidel_lexicographic", "ccp_debug_lex_tickets", "ccp_grid_conjugate_gradient",
     "ccp_grid_residual_norm2", "ccp_grid_abs_sum", "ccp_grid_assemble_rhs", "ccp_grid_assemble_from_images", "ccp_grid_store_u8",
     "ccp_grid_set_x_u8", "ccp_grid_last_timing", "ccp_grid_region_begin", "ccp_grid_region_end",
     "ccp_comm_probe", "ccp_comm_unique_id", "ccp_comm_create", "ccp_comm_destroy", "ccp_comm_info", "ccp_comm_all_reduce_sum", "ccp_comm_all_reduce_max",

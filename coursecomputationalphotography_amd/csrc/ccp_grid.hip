@@ -1477,6 +1477,34 @@ namespace {
 // partial sums one checked sweep writes per channel
 // (time-skewed strips: the strip count depends on the depth; the partial layout uses the largest, depth 8's —
 // slots a shallower launch does not write must read as zero, so the buffer is cleared per batch)
+// Tickets of a launch of `groups` groups of T sweeps on an image W pixels wide, in the order the strips can start: (k, s)
+// follows its left neighbour (k, s-1) by a strip lag (the 62 diagonals its first pixel lies further on + the 16 steps of
+// edge values it wants to see published + the publication's own lag) and the same strip of the group before by a group
+// lag; a workgroup that is resident but waiting keeps a slot from one that could run.  Everything a strip waits for —
+// (k, s-1), (k-1, s), the last reader of its edge buffer (k - kLexEdgeSets, s+1): lex_wg_body — holds a smaller ticket, and a
+// ticket's holder never waits for a larger one: no deadlock, whatever the residency (tests/test_lex_tickets.py checks
+// exactly that through ccp_debug_lex_tickets).  order[ticket] = k * strips + s, strips = lex_strip_count(W, T, groups).
+void lex_ticket_order(int W, int T, int groups, std::vector<unsigned> &order)
+{
+    const int S = lex_strip_count(W, T, groups);
+    const long strip_lag = kLexSkewCols + 34, group_lag = 19 + 4 * (T - 1) + 16;
+    struct Ticket { long start; int k, s; };
+    std::vector<long> start((size_t)groups * S, -1);
+    std::vector<Ticket> tickets;
+    for (int k = 0; k < groups; ++k)
+        for (int st = lex_strip_first(T, k); st <= lex_strip_last(W, T, k); ++st) {
+            long t = 0;
+            if (lex_strip_exists(W, T, k, st - 1)) t = std::max(t, start[(size_t)k * S + st - 1] + strip_lag);
+            if (lex_strip_exists(W, T, k - 1, st)) t = std::max(t, start[(size_t)(k - 1) * S + st] + group_lag);
+            if (lex_strip_exists(W, T, k - kLexEdgeSets, st + 1)) t = std::max(t, start[(size_t)(k - kLexEdgeSets) * S + st + 1] + 1);
+            start[(size_t)k * S + st] = t;
+            tickets.push_back({t, k, st});
+        }
+    std::stable_sort(tickets.begin(), tickets.end(), [](const Ticket &a, const Ticket &b) { return a.start < b.start; });
+    order.clear();
+    for (const Ticket &t : tickets) order.push_back((unsigned)((long)t.k * S + t.s));
+}
+
 // the diagonal-major arrays behind their front rows (kLexFrontRows: what k_lex_wg's loader prefetches for a strip that
 // starts left of the image lies up to 64 diagonals before the first one; never used)
 double *lex_xd(const ccp_grid *g) { return g->lex_x.p + (size_t)kLexFrontRows * g->lexg.P; }
@@ -1527,20 +1555,8 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial, int
         // publication's own lag) and the same strip of the group before by a group lag; a workgroup that is resident but
         // waiting keeps a slot from one that could run.  Everything a strip waits for holds a smaller ticket — a ticket's
         // holder never waits for a larger one: no deadlock, whatever the residency.
-        const long strip_lag = kLexSkewCols + 34, group_lag = 19 + 4 * (T - 1) + 16;
-        struct Ticket { long start; int k, s; };
-        std::vector<long> start((size_t)groups * S, -1);
-        std::vector<Ticket> tickets;
-        for (int k = 0; k < groups; ++k)
-            for (int st = lex_strip_first(T, k); st <= lex_strip_last(lg.W, T, k); ++st) {
-                long t = 0;
-                if (lex_strip_exists(lg.W, T, k, st - 1)) t = std::max(t, start[(size_t)k * S + st - 1] + strip_lag);
-                if (lex_strip_exists(lg.W, T, k - 1, st)) t = std::max(t, start[(size_t)(k - 1) * S + st] + group_lag);
-                if (lex_strip_exists(lg.W, T, k - kLexEdgeSets, st + 1)) t = std::max(t, start[(size_t)(k - kLexEdgeSets) * S + st + 1] + 1);
-                start[(size_t)k * S + st] = t;
-                tickets.push_back({t, k, st});
-            }
-        std::stable_sort(tickets.begin(), tickets.end(), [](const Ticket &a, const Ticket &b) { return a.start < b.start; });
+        std::vector<unsigned> tickets;
+        lex_ticket_order(lg.W, T, groups, tickets);
         if (tickets.empty()) return CCP_ERR_STATE;
         lap("tickets sorted");
         const size_t order_cap = std::max(tickets.size(), (size_t)(kLexLaunchSweeps / 8) * S_cap);
@@ -1554,7 +1570,7 @@ int lex_launch_skew(ccp_grid *g, int groups, unsigned mask, double *partial, int
             CCP_HIP(hipHostGetDevicePointer(reinterpret_cast<void **>(&g->lex_order_dev), g->lex_order_pin, 0));
             g->lex_order_pin_cap = order_cap;
         }
-        for (size_t i = 0; i < tickets.size(); ++i) g->lex_order_pin[i] = (unsigned)((long)tickets[i].k * S + tickets[i].s);
+        for (size_t i = 0; i < tickets.size(); ++i) g->lex_order_pin[i] = tickets[i];
         __atomic_thread_fence(__ATOMIC_RELEASE);
         g->lex_order_count = tickets.size();
         g->lex_order_groups = groups;
@@ -1797,6 +1813,21 @@ try {
             report[ch].last_l1_step = last_eps[ch];
             report[ch].seconds = ms * 1e-3;
         }
+    }
+    return CCP_OK;
+} CCP_ABI_CATCH
+
+int ccp_debug_lex_tickets(int32_t width, int32_t depth, int32_t groups, uint32_t *order, int64_t capacity, int32_t *strips, int64_t *count)
+try {
+    if (width < 1 || groups < 1 || (depth != 1 && depth != 2 && depth != 4 && depth != 8) || (long)groups * depth > kLexLaunchSweeps || !strips || !count)
+        return CCP_ERR_BAD_ARG;
+    std::vector<unsigned> t;
+    lex_ticket_order(width, depth, groups, t);
+    *strips = lex_strip_count(width, depth, groups);
+    *count = (int64_t)t.size();
+    if (order) {
+        if (capacity < (int64_t)t.size()) return CCP_ERR_BAD_ARG;
+        std::copy(t.begin(), t.end(), order);
     }
     return CCP_OK;
 } CCP_ABI_CATCH

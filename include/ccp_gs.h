@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define CCP_GS_ABI_VERSION 5
+#define CCP_GS_ABI_VERSION 6
 
 typedef enum ccp_status {
     CCP_OK = 0,
@@ -339,6 +339,14 @@ int ccp_grid_gauss_seidel(ccp_grid *g, double epsilon, int32_t max_iteration,
  * Whole-image handles only (no ghost rows: CCP_ERR_STATE).  check_every as above. */
 int ccp_grid_gauss_seidel_lexicographic(ccp_grid *g, double epsilon, int32_t max_iteration,
                                         int32_t check_every, ccp_gs_report *report);
+
+/* Diagnostics (host only, no device needed): the order in which a launch of the reference-order sweep hands its strips
+ * to the persistent workgroups — `groups` groups of `depth` (1, 2, 4, 8) sweeps on an image `width` pixels wide,
+ * groups * depth <= 1024.  order[ticket] = group * *strips + strip for the *count strips that hold a pixel of the image
+ * (order may be NULL to ask for the sizes).  A strip waits only for strips with smaller tickets: its left neighbour,
+ * the same strip of the group before, and strip + 1 of two groups before (tests/test_lex_tickets.py). */
+int ccp_debug_lex_tickets(int32_t width, int32_t depth, int32_t groups, uint32_t *order, int64_t capacity, int32_t *strips,
+                          int64_t *count);
 
 /* conjugateGradient (sparse-matrix.h:396-434) on the resident system, matrix-free, channel by
  * channel; the resident x is the initial guess (ccp_grid_fill_x(g, 0) for the reference default,

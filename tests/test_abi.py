@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"libccp_gs.so does not export {name}"
     assert sorted(capi.ABI_SYMBOLS) == declared, "capi.ABI_SYMBOLS out of sync with include/ccp_gs.h"
-    assert lib.ccp_abi_version() == 5
+    assert lib.ccp_abi_version() == 6
 
 
 def test_status_strings():
