@@ -1353,7 +1353,7 @@ try {
         // The reference tests its stop rule after EVERY sweep (check_every = 1; k > 1 tests every k-th
         // sweep with the same machinery).  A temporally blocked pass knows the
         // previous level of every pixel it updates, so it reports the step of each of its T sweeps
-        // (L1 = 2) at no extra traffic; k_check_multi finds the first sweep that meets the rule.  If
+        // (L1 = 2) at no extra traffic; k_decide_sums finds the first sweep that meets the rule.  If
         // that sweep is inside the pass, the channel is re-run from the pass's input buffer (still
         // intact: passes ping-pong) for exactly the missing sweeps — once per solve.
         const size_t elems = (size_t)g->geom.ch_stride * C;
@@ -2296,8 +2296,8 @@ try {
             const int since0 = g->half_sweeps_since_refresh;
             long blocks[2] = {0, 0};
             CCP_TRY(launch_fused(g, T, cur, alt, active, 2, blocks));
-            hipLaunchKernelGGL(k_sweep_sums, dim3((unsigned)C), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
-                               g->partial.p + g->partial_region, blocks[1], T, g->sweep_sums.p);
+            hipLaunchKernelGGL(k_sweep_sums_wide, dim3((unsigned)C, (unsigned)T), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
+                               g->partial.p + g->partial_region, blocks[1], g->sweep_sums.p);
             CCP_HIP(hipGetLastError());
             CCP_RCCL(api->AllReduce(g->sweep_sums.p, g->sweep_sums.p, (size_t)T * C, ncclDouble, ncclSum, g->comm->comm, g->stream));
             hipLaunchKernelGGL(k_decide_sums, dim3(1), dim3(64), 0, g->stream, g->sweep_sums.p, C, T, k0 + 1, check_every, epsilon, g->state.p);

@@ -271,60 +271,12 @@ k_check(const double *__restrict__ partial0, long blocks0, const double *__restr
     }
 }
 
-// The same rule for a temporally blocked pass that reported the step of EACH of its T sweeps
-// (partial[(t*channels + ch)*blocks + i], one region per launch of the pass): the first sweep whose step is not above epsilon stops
-// the channel, exactly where the reference loop would have stopped.  grid = channels.
-__global__ void __launch_bounds__(kBlock)
-k_check_multi(const double *__restrict__ partial0, long blocks0, const double *__restrict__ partial1, long blocks1,
-              int T, int first_sweep_index, int every, double epsilon, SolveState *__restrict__ st)
-{
-    __shared__ double scratch[kBlock / kWave];
-    const int ch = blockIdx.x;
-    const int channels = gridDim.x;
-    for (int t = 0; t < T; ++t) {
-        if ((first_sweep_index + t) % every != 0) continue;    // the rule is evaluated every `every`-th sweep (block-uniform)
-        // two regions: the ordinary launch and the border launch of the pass
-        double acc = 0.0;
-        const double *__restrict__ p = partial0 + ((long)t * channels + ch) * blocks0;
-        for (long i = threadIdx.x; i < blocks0; i += kBlock) acc += p[i];
-        const double *__restrict__ q = partial1 + ((long)t * channels + ch) * blocks1;
-        for (long i = threadIdx.x; i < blocks1; i += kBlock) acc += q[i];
-        const double eps = block_sum(acc, scratch);
-        if (threadIdx.x == 0 && st->active[ch]) {
-            st->last_eps[ch] = eps;
-            if (!(eps > epsilon)) {
-                st->active[ch] = 0;
-                st->converged[ch] = 1;
-                st->iterations[ch] = first_sweep_index + t;
-            }
-        }
-        __syncthreads();
-    }
-}
-
-// The two halves of k_check_multi for a row block: the block's step sums of every sweep of a checked pass
-// (sums[t*channels + ch], all-reduced over the ranks by the caller), then the rule on the summed values.
-__global__ void __launch_bounds__(kBlock)
-k_sweep_sums(const double *__restrict__ partial0, long blocks0, const double *__restrict__ partial1, long blocks1, int T,
-             double *__restrict__ sums)
-{
-    __shared__ double scratch[kBlock / kWave];
-    const int ch = blockIdx.x;
-    const int channels = gridDim.x;
-    for (int t = 0; t < T; ++t) {
-        double acc = 0.0;
-        const double *__restrict__ p = partial0 + ((long)t * channels + ch) * blocks0;
-        for (long i = threadIdx.x; i < blocks0; i += kBlock) acc += p[i];
-        const double *__restrict__ q = partial1 + ((long)t * channels + ch) * blocks1;
-        for (long i = threadIdx.x; i < blocks1; i += kBlock) acc += q[i];
-        const double eps = block_sum(acc, scratch);
-        if (threadIdx.x == 0) sums[t * channels + ch] = eps;
-        __syncthreads();
-    }
-}
-
-// k_sweep_sums with a block per (channel, sweep): grid = (channels, T).  The same sums in the same order; the T sweeps
-// side by side instead of one after the other in one block (85 us per pass of 2 ms at 16384^2 — kernel stats, round 4).
+// A temporally blocked pass that reported the step of EACH of its T sweeps (partial[(t*channels + ch)*blocks + i], one
+// region per launch of the pass: the ordinary and the border launch): k_sweep_sums_wide adds up the step of every sweep
+// (sums[t*channels + ch]; a row block all-reduces them over the ranks), k_decide_sums applies the rule in sweep order — the
+// first sweep whose step is not above epsilon stops the channel, exactly where the reference loop would have stopped.
+// A block per (channel, sweep): grid = (channels, T) — the T sweeps side by side (one block doing them one after the other
+// took 85 us per pass of 2 ms at 16384^2: kernel stats, round 4).
 __global__ void __launch_bounds__(kBlock)
 k_sweep_sums_wide(const double *__restrict__ partial0, long blocks0, const double *__restrict__ partial1, long blocks1,
                   double *__restrict__ sums)
