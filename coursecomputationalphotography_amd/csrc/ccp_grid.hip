@@ -1366,49 +1366,82 @@ try {
         double *cur = g->x.p, *alt = g->x_alt.p;
         int was_active[kMaxChannels];
         for (int ch = 0; ch < C; ++ch) was_active[ch] = 1;
-        int k0 = 0;
-        while (any_active && k0 < max_iteration) {
-            const int T = std::min(g->masked ? kMaskedMaxCheckedT : kFusedMaxCheckedT, max_iteration - k0);
+        // The host runs ONE PASS AHEAD of what it has looked at: pass n+1 is queued before the state after pass n is read
+        // back, so the chip does not idle through a host round trip per pass (a pass of 4096^2 x 3 takes 0.3 ms; the
+        // round trip was a tenth of it).  That is safe because the rule is applied on the device, in stream order: a
+        // channel that stops in pass n is frozen before pass n+1 starts, which then leaves it — and its buffers — alone.
+        if (!g->sweep_sums.p) CCP_TRY(g->sweep_sums.alloc((size_t)kFusedMaxCheckedT * kMaxChannels));
+        struct Queued {
+            SolveState st;
+            int k0 = 0, T = 0;
+            double *cur = nullptr, *alt = nullptr;     // the pass read cur and wrote alt
+            hipEvent_t ev = nullptr;
+        } ring[2];
+        for (Queued &q : ring) CCP_HIP(hipEventCreateWithFlags(&q.ev, hipEventDisableTiming));
+        int k0 = 0, n_queued = 0, n_seen = 0, status = CCP_OK;
+        auto queue_pass = [&]() -> int {
+            Queued &q = ring[n_queued & 1];
+            q.k0 = k0;
+            q.T = std::min(g->masked ? kMaskedMaxCheckedT : kFusedMaxCheckedT, max_iteration - k0);
+            q.cur = cur;
+            q.alt = alt;
             long blocks[2] = {0, 0};
-            CCP_TRY(launch_fused(g, T, cur, alt, active, 2, blocks));
+            CCP_TRY(launch_fused(g, q.T, cur, alt, active, 2, blocks));
             // the step of each sweep (a block per channel and sweep), then the rule on them in sweep order
-            if (!g->sweep_sums.p) CCP_TRY(g->sweep_sums.alloc((size_t)kFusedMaxCheckedT * kMaxChannels));
-            hipLaunchKernelGGL(k_sweep_sums_wide, dim3((unsigned)C, (unsigned)T), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
+            hipLaunchKernelGGL(k_sweep_sums_wide, dim3((unsigned)C, (unsigned)q.T), dim3(kBlock), 0, g->stream, g->partial.p, blocks[0],
                                g->partial.p + g->partial_region, blocks[1], g->sweep_sums.p);
-            hipLaunchKernelGGL(k_decide_sums, dim3(1), dim3(kMaxChannels), 0, g->stream, g->sweep_sums.p, C, T, k0 + 1, check_every, epsilon,
+            hipLaunchKernelGGL(k_decide_sums, dim3(1), dim3(kMaxChannels), 0, g->stream, g->sweep_sums.p, C, q.T, k0 + 1, check_every, epsilon,
                                g->state.p);
             CCP_HIP(hipGetLastError());
-            CCP_HIP(hipMemcpyAsync(&host, g->state.p, sizeof(host), hipMemcpyDeviceToHost, g->stream));
-            CCP_HIP(hipStreamSynchronize(g->stream));
+            CCP_HIP(hipMemcpyAsync(&q.st, g->state.p, sizeof(q.st), hipMemcpyDeviceToHost, g->stream));
+            CCP_HIP(hipEventRecord(q.ev, g->stream));
+            k0 += q.T;
+            std::swap(cur, alt);
+            ++n_queued;
+            return CCP_OK;
+        };
+        auto look_at_pass = [&]() -> int {
+            Queued &q = ring[n_seen & 1];
+            CCP_HIP(hipEventSynchronize(q.ev));
+            host = q.st;
             any_active = false;
             for (int ch = 0; ch < C; ++ch) {
                 any_active |= host.active[ch] != 0;
                 if (!was_active[ch] || host.active[ch]) continue;
                 was_active[ch] = 0;                                   // stopped inside this pass
-                const int m = host.iterations[ch] - k0;               // sweeps of the pass it wanted: 1..T
-                double *have = alt;                                   // where the channel's x_k is
-                if (m < T) {
+                const int m = host.iterations[ch] - q.k0;             // sweeps of the pass it wanted: 1..T
+                double *have = q.alt;                                 // where the channel's x_k is
+                if (m < q.T) {
                     int mask[kMaxChannels] = {0};
                     mask[ch] = 1;
                     CCP_HIP(hipMemcpyAsync(g->redo_mask.p, mask, sizeof(mask), hipMemcpyHostToDevice, g->stream));
-                    double *p = cur, *q = alt;
+                    double *p = q.cur, *r = q.alt;
                     for (int left = m; left > 0;) {
                         const int t = std::min(left, g->masked ? kMaskedMaxT : kFusedMaxT);
-                        CCP_TRY(launch_fused(g, t, p, q, g->redo_mask.p));
-                        std::swap(p, q);
+                        CCP_TRY(launch_fused(g, t, p, r, g->redo_mask.p));
+                        std::swap(p, r);
                         left -= t;
                     }
                     CCP_HIP(hipStreamSynchronize(g->stream));          // `mask` lives on this stack frame
                     have = p;
                 }
                 // a frozen channel is never touched again: keep its result in BOTH buffers
-                double *other = (have == cur) ? alt : cur;
+                double *other = (have == q.cur) ? q.alt : q.cur;
                 CCP_HIP(hipMemcpyAsync(other + (size_t)ch * g->geom.ch_stride, have + (size_t)ch * g->geom.ch_stride, plane,
                                        hipMemcpyDeviceToDevice, g->stream));
             }
-            k0 += T;
-            std::swap(cur, alt);
+            ++n_seen;
+            return CCP_OK;
+        };
+        while (status == CCP_OK && any_active && (n_seen < n_queued || k0 < max_iteration)) {
+            // keep two passes queued while there are sweeps left, then look at the older one
+            while (status == CCP_OK && n_queued - n_seen < 2 && k0 < max_iteration) status = queue_pass();
+            if (status == CCP_OK) status = look_at_pass();
         }
+        // (passes queued beyond the one that stopped the last channel find every channel frozen: they leave at once)
+        if (n_seen < n_queued) (void)hipStreamSynchronize(g->stream);      // (a copy into `ring` may still be in flight)
+        for (Queued &q : ring) (void)hipEventDestroy(q.ev);
+        CCP_TRY(status);
         if (cur != g->x.p)
             CCP_HIP(hipMemcpyAsync(g->x.p, cur, elems * sizeof(double), hipMemcpyDeviceToDevice, g->stream));
         issued = k0;
